@@ -1,0 +1,443 @@
+// capi.hip — the extern "C" boundary declared in include/sphx_c.h, a thin layer over the C++
+// drop-in classes (SPHParticles, the three solvers, SPHSystem).
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "BasicSPHSolver.h"
+#include "DFSPHSolver.h"
+#include "PBDSolver.h"
+#include "SPHSystem.h"
+#include "engine.hpp"
+#include "sphx_c.h"
+
+namespace sphx {
+const std::string& last_error_text();
+void set_error_text(const std::string& s);
+}  // namespace sphx
+using namespace sphx;
+
+struct sphx_system {
+    sphx_params params;
+    std::unique_ptr<SPHSystem> system;
+    BasicSPHSolver* wcsph = nullptr;   // non-owning views of the solver the system owns
+    DFSPHSolver* dfsph = nullptr;
+    PBDSolver* pbd = nullptr;
+    int n = 0, nb = 0, cells = 0;
+};
+
+static int fail(int code, const std::string& msg)
+{
+    set_error_text(msg);
+    return code;
+}
+
+extern "C" {
+
+const char* sphx_last_error(void) { return last_error_text().c_str(); }
+
+int sphx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int sphx_set_device(int ordinal)
+{
+    if (hipSetDevice(ordinal) != hipSuccess) return fail(SPHX_ERR_HIP, "hipSetDevice failed");
+    return SPHX_OK;
+}
+
+int sphx_sizeof_params(void) { return (int)sizeof(sphx_params); }
+
+// ------------------------------------------------------------------------------------ scene
+// Constants of main.cpp:54-67; block and shell samplers of main.cpp:73-117; scaling rule of
+// BASELINE.md §4 (s = nx/24; nx = 24 reproduces the reference scene bit-for-bit).
+int sphx_scene_params(int nx, sphx_params* P)
+{
+    if (!P || nx < 2 || (nx & 1)) return fail(SPHX_ERR_INVALID, "scene: nx must be even and >= 2");
+    std::memset(P, 0, sizeof(*P));
+    const float scale = (float)nx / 24.0f;
+    const float spacing = 0.02f;
+    for (int a = 0; a < 3; ++a) P->space[a] = scale;
+    P->radius = 2.0f * spacing;
+    P->cell_length = 1.01f * P->radius;
+    for (int a = 0; a < 3; ++a) P->cells[a] = (int)std::ceil(P->space[a] / P->cell_length);
+    P->dt = 0.002f;
+    P->rho0 = 1.0f;
+    P->rho_boundary = 1.4f * P->rho0;
+    P->m0 = 76.596750762082e-6f;
+    P->stiff = 10.0f;
+    P->gravity[0] = 0.0f; P->gravity[1] = -9.8f; P->gravity[2] = 0.0f;
+    P->visc = 5e-4f;
+    P->surface_tension = 0.0001f;
+    P->air_pressure = 0.0001f;
+    P->solver = SPHX_WCSPH;
+    P->dfsph_density_thr = 1e-3f; P->dfsph_divergence_thr = 1e-3f; P->dfsph_max_iter = 20;
+    P->dfsph_fixed_div = -1; P->dfsph_fixed_den = -1;
+    P->pbd_iters = 20; P->pbd_xsph_c = 0.05f; P->pbd_relaxation = 0.75f;
+    return SPHX_OK;
+}
+
+int sphx_scene_counts(int nx, int* n_fluid, int* n_boundary)
+{
+    sphx_params P;
+    const int rc = sphx_scene_params(nx, &P);
+    if (rc) return rc;
+    const long long sx = 2LL * P.cells[0], sy = 2LL * P.cells[1], sz = 2LL * P.cells[2];
+    const long long nf = (long long)nx * (3LL * nx / 2) * nx;
+    const long long nbnd = 2 * sx * sy + 2 * sx * (sz - 2) + 2 * (sy - 2) * (sz - 2);
+    if (nf > 2000000000LL || nbnd > 2000000000LL) return fail(SPHX_ERR_INVALID, "scene too large for int32 indices");
+    *n_fluid = (int)nf;
+    *n_boundary = (int)nbnd;
+    return SPHX_OK;
+}
+
+int sphx_scene_fill(int nx, float* fluid, float* boundary)
+{
+    sphx_params P;
+    const int rc = sphx_scene_params(nx, &P);
+    if (rc) return rc;
+    const float spacing = 0.02f, scale = P.space[0];
+    const float x0 = 0.27f * scale, y0 = 0.10f * scale, z0 = 0.27f * scale;
+    float* w = fluid;
+    for (int iy = 0; iy < 3 * nx / 2; ++iy)
+        for (int ix = 0; ix < nx; ++ix)
+            for (int iz = 0; iz < nx; ++iz) {
+                *w++ = x0 + spacing * ix;
+                *w++ = y0 + spacing * iy;
+                *w++ = z0 + spacing * iz;
+            }
+    const int shell[3] = {2 * P.cells[0], 2 * P.cells[1], 2 * P.cells[2]};
+    w = boundary;
+    auto emit = [&](int a, int b, int c) {
+        const int idx[3] = {a, b, c};
+        for (int d = 0; d < 3; ++d) {
+            const float t = (float)idx[d] / (float)(shell[d] - 1) * P.space[d];
+            *w++ = 0.99f * t + 0.005f * P.space[d];
+        }
+    };
+    for (int a = 0; a < shell[0]; ++a)              // the two z faces
+        for (int b = 0; b < shell[1]; ++b) { emit(a, b, 0); emit(a, b, shell[2] - 1); }
+    for (int a = 0; a < shell[0]; ++a)              // the two y faces, without the z edges
+        for (int c = 1; c < shell[2] - 1; ++c) { emit(a, 0, c); emit(a, shell[1] - 1, c); }
+    for (int b = 1; b < shell[1] - 1; ++b)          // the two x faces, without y and z edges
+        for (int c = 1; c < shell[2] - 1; ++c) { emit(0, b, c); emit(shell[0] - 1, b, c); }
+    return SPHX_OK;
+}
+
+// ------------------------------------------------------------------------------------ lifetime
+int sphx_create(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
+                sphx_system** out)
+{
+    if (!P || !out || n < 0 || nb < 0 || (n && !fluid) || (nb && !boundary)) return fail(SPHX_ERR_INVALID, "sphx_create: bad argument");
+    if (P->pow7_mode != 0 || P->xsph_mode != 0) return fail(SPHX_ERR_INVALID, "sphx_create: pow7_mode and xsph_mode must be 0");
+    if (P->cells[0] <= 0 || P->cells[1] <= 0 || P->cells[2] <= 0) return fail(SPHX_ERR_INVALID, "sphx_create: bad grid");
+    if (sphx_device_count() <= 0) return fail(SPHX_ERR_NO_DEVICE, "sphx_create: no HIP device (the engine has no CPU path)");
+    *out = nullptr;
+    std::unique_ptr<sphx_system> h(new sphx_system());
+    h->params = *P;
+    h->n = n; h->nb = nb; h->cells = P->cells[0] * P->cells[1] * P->cells[2];
+    std::vector<float3> fp((size_t)n), bp((size_t)nb);
+    for (int i = 0; i < n; ++i) fp[i] = make_float3(fluid[3 * i], fluid[3 * i + 1], fluid[3 * i + 2]);
+    for (int i = 0; i < nb; ++i) bp[i] = make_float3(boundary[3 * i], boundary[3 * i + 1], boundary[3 * i + 2]);
+    auto fluids = std::make_shared<SPHParticles>(fp);
+    auto walls = std::make_shared<SPHParticles>(bp);
+    std::shared_ptr<BaseSolver> solver;
+    switch (P->solver) {
+    case SPHX_DFSPH: {
+        auto s = std::make_shared<DFSPHSolver>(n, P->dfsph_density_thr, P->dfsph_divergence_thr, P->dfsph_max_iter);
+        if (P->dfsph_fixed_div >= 0 || P->dfsph_fixed_den >= 0) {
+            if (P->dfsph_fixed_div < 0 || P->dfsph_fixed_den < 0)
+                return fail(SPHX_ERR_INVALID, "sphx_create: fix both DFSPH iteration counts or neither");
+            s->setFixedIterations(P->dfsph_fixed_div, P->dfsph_fixed_den);
+        }
+        h->dfsph = s.get(); h->wcsph = s.get(); solver = s;
+        break;
+    }
+    case SPHX_PBD: {
+        auto s = std::make_shared<PBDSolver>(n, P->pbd_iters, P->pbd_xsph_c, P->pbd_relaxation);
+        h->pbd = s.get(); h->wcsph = s.get(); solver = s;
+        break;
+    }
+    case SPHX_WCSPH: {
+        auto s = std::make_shared<BasicSPHSolver>(n);
+        h->wcsph = s.get(); solver = s;
+        break;
+    }
+    default: return fail(SPHX_ERR_INVALID, "sphx_create: unknown solver");
+    }
+    const float3 space = make_float3(P->space[0], P->space[1], P->space[2]);
+    const float3 G = make_float3(P->gravity[0], P->gravity[1], P->gravity[2]);
+    const int3 cells = make_int3(P->cells[0], P->cells[1], P->cells[2]);
+    if (run_ctor_step)
+        h->system.reset(new SPHSystem(fluids, walls, solver, space, P->cell_length, P->radius, P->dt, P->m0, P->rho0,
+                                      P->rho_boundary, P->stiff, P->visc, P->surface_tension, P->air_pressure, G, cells));
+    else
+        h->system.reset(new SPHSystem(SPHSystem::NoInitialStep{}, fluids, walls, solver, space, P->cell_length, P->radius,
+                                      P->dt, P->m0, P->rho0, P->rho_boundary, P->stiff, P->visc, P->surface_tension,
+                                      P->air_pressure, G, cells));
+    if (hipStreamSynchronize(sphx::stream()) != hipSuccess) return fail(SPHX_ERR_HIP, last_error_text());
+    *out = h.release();
+    return SPHX_OK;
+}
+
+int sphx_destroy(sphx_system* h)
+{
+    if (!h) return SPHX_OK;
+    (void)hipStreamSynchronize(sphx::stream());
+    delete h;
+    return SPHX_OK;
+}
+
+// ------------------------------------------------------------------------------------ stepping
+int sphx_step(sphx_system* h, float* ms)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "sphx_step: null system");
+    const float t = h->system->step();
+    if (ms) *ms = t;
+    return SPHX_OK;
+}
+
+int sphx_step_n(sphx_system* h, int n, float* ms_total)
+{
+    if (!h || n < 0) return fail(SPHX_ERR_INVALID, "sphx_step_n: bad argument");
+    const float t = h->system->stepN(n);
+    if (ms_total) *ms_total = t;
+    return SPHX_OK;
+}
+
+int sphx_counts(const sphx_system* h, int* n, int* nb, int* cells)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "null system");
+    if (n) *n = h->n;
+    if (nb) *nb = h->nb;
+    if (cells) *cells = h->cells;
+    return SPHX_OK;
+}
+
+int sphx_iters(const sphx_system* h, int* div, int* den)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "null system");
+    if (div) *div = h->dfsph ? h->dfsph->lastDivergenceIterations() : 0;
+    if (den) *den = h->dfsph ? h->dfsph->lastDensityIterations() : 0;
+    return SPHX_OK;
+}
+
+// ------------------------------------------------------------------------------------ fields
+static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
+{
+    const auto f = h->system->getFluids();
+    const auto b = h->system->getBoundaries();
+    const size_t n = (size_t)h->n, nb = (size_t)h->nb;
+    void* p = nullptr; size_t sz = 0; bool known = true;
+    switch (field) {
+    case SPHX_F_POS: p = f->getPosPtr(); sz = 12 * n; break;
+    case SPHX_F_VEL: p = f->getVelPtr(); sz = 12 * n; break;
+    case SPHX_F_DENSITY: p = f->getDensityPtr(); sz = 4 * n; break;
+    case SPHX_F_PRESSURE: p = f->getPressurePtr(); sz = 4 * n; break;
+    case SPHX_F_MASS: p = f->getMassPtr(); sz = 4 * n; break;
+    case SPHX_F_CELL: p = f->getParticle2Cell(); sz = 4 * n; break;
+    case SPHX_F_CELLSTART_F: p = h->system->getCellStartFluid().addr(); sz = 4 * ((size_t)h->cells + 1); break;
+    case SPHX_F_CELLSTART_B: p = h->system->getCellStartBoundary().addr(); sz = 4 * ((size_t)h->cells + 1); break;
+    case SPHX_F_ID: p = f->getIdPtr(); sz = 4 * n; break;
+    case SPHX_F_BPOS: p = b->getPosPtr(); sz = 12 * nb; break;
+    case SPHX_F_BMASS: p = b->getMassPtr(); sz = 4 * nb; break;
+    case SPHX_F_ALPHA: if (h->dfsph) { p = h->dfsph->getAlpha().addr(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_KAPPA: if (h->dfsph) { p = h->dfsph->getStiffness().addr(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_ERROR: if (h->dfsph) { p = h->dfsph->getError().addr(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_WARM: if (h->dfsph) { p = h->dfsph->getWarmStiffness().addr(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_POS_LAST: if (h->pbd) { p = h->pbd->getPosLast().addr(); sz = 12 * n; } else known = false; break;
+    case SPHX_F_LAMBDA: if (h->pbd) { p = h->pbd->getLambda().addr(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_BUF3: if (h->wcsph) { p = h->wcsph->getColorGradient().addr(); sz = 12 * n; } else known = false; break;
+    default: known = false; break;
+    }
+    if (!known) return SPHX_ERR_INVALID;
+    *ptr = p; *bytes = sz;
+    return SPHX_OK;
+}
+
+int sphx_field_bytes(const sphx_system* h, int field, size_t* bytes)
+{
+    void* p;
+    if (!h || !bytes || locate(h, field, &p, bytes)) return fail(SPHX_ERR_INVALID, "sphx_field_bytes: unknown field for this solver");
+    return SPHX_OK;
+}
+
+int sphx_device_ptr(const sphx_system* h, int field, void** out)
+{
+    size_t sz;
+    if (!h || !out || locate(h, field, out, &sz)) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: unknown field for this solver");
+    return SPHX_OK;
+}
+
+int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
+{
+    void* p; size_t sz;
+    if (!h || !dst || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
+    if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_get: size mismatch");
+    if (!sz) return SPHX_OK;
+    if (hipMemcpyAsync(dst, p, sz, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+        hipStreamSynchronize(sphx::stream()) != hipSuccess)
+        return fail(SPHX_ERR_HIP, "sphx_get: copy failed");
+    return SPHX_OK;
+}
+
+int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
+{
+    if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM) return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
+    void* p; size_t sz;
+    if (!h || !src || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
+    if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
+    if (!sz) return SPHX_OK;
+    if (hipMemcpyAsync(p, src, sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
+        hipStreamSynchronize(sphx::stream()) != hipSuccess)
+        return fail(SPHX_ERR_HIP, "sphx_set: copy failed");
+    return SPHX_OK;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+int sphx_profile_step(sphx_system* h, int cap, char (*names)[48], float* ms, int* count)
+{
+    if (!h || !names || !ms || !count) return fail(SPHX_ERR_INVALID, "sphx_profile_step: bad argument");
+    KernelTimer::reset();
+    KernelTimer::enabled = true;
+    (void)h->system->step();
+    KernelTimer::enabled = false;
+    std::vector<std::string> nm; std::vector<float> t;
+    KernelTimer::collect(nm, t);
+    // merge spans of the same name, keep first-seen order
+    std::vector<std::string> un; std::vector<float> ut;
+    for (size_t i = 0; i < nm.size(); ++i) {
+        size_t k = 0;
+        while (k < un.size() && un[k] != nm[i]) ++k;
+        if (k == un.size()) { un.push_back(nm[i]); ut.push_back(0.0f); }
+        ut[k] += t[i];
+    }
+    *count = (int)std::min((size_t)cap, un.size());
+    for (int i = 0; i < *count; ++i) {
+        std::strncpy(names[i], un[i].c_str(), 47); names[i][47] = 0;
+        ms[i] = ut[i];
+    }
+    KernelTimer::reset();
+    return SPHX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------ probes
+__global__ void k_eval_kernels(const float3* __restrict__ r3, int n, KernelConsts k, float* __restrict__ W,
+                               float3* __restrict__ G, float* __restrict__ V, float3* __restrict__ S)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 d = r3[i];
+    const float r = len3(d);
+    const float q = q_of(r, k);
+    W[i] = kW(q, k);
+    G[i] = kGradW(d, q, k);
+    V[i] = kViscLap(r, k);
+    S[i] = kSurfGrad(d, r, k);
+}
+
+__global__ void k_ieee_probe(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int n,
+                             float* __restrict__ quot, float* __restrict__ root, int* __restrict__ trunc,
+                             float* __restrict__ muladd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    quot[i] = a[i] / b[i];
+    root[i] = sqrtf(fabsf(a[i]));
+    trunc[i] = (int)(a[i] / b[i]);
+    muladd[i] = a[i] * b[i] + c[i];
+}
+
+// generate_dots_CUDA, vbo.cu:26-44: copy positions, map density to the blue-white-pink ramp
+__global__ void k_generate_dots(float3* __restrict__ dot, float3* __restrict__ color, const float3* __restrict__ pos,
+                                const float* __restrict__ density, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dot[i] = pos[i];
+    const float rho = density[i];
+    const float3 water = v3(0.34f, 0.46f, 0.7f), foam = v3(0.9f, 0.9f, 0.9f), dense = v3(1.0f, 0.4f, 0.7f);
+    float3 out;
+    if (rho < 0.75f) {
+        out = water;
+    } else if (rho < 1.0f) {
+        const float w = (rho - 0.75f) * 4.0f;
+        out = add3(smul3(w, foam), smul3(1 - w, water));
+    } else {
+        float w = (rho * rho - 1.0f) * 4.0f;
+        w = fminf(w, 1.0f);
+        out = add3(smul3(1 - w, foam), smul3(w, dense));
+    }
+    color[i] = out;
+}
+
+namespace {
+template <class T>
+struct DeviceTemp {
+    T* p = nullptr;
+    explicit DeviceTemp(size_t count) { if (hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)) != hipSuccess) p = nullptr; }
+    ~DeviceTemp() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" {
+
+int sphx_eval_kernels(const float* r3, int n, float radius, float* W, float* G, float* V, float* S)
+{
+    if (n <= 0) return SPHX_OK;
+    if (sphx_device_count() <= 0) return fail(SPHX_ERR_NO_DEVICE, "no HIP device");
+    DeviceTemp<float3> dr(n), dG(n), dS(n);
+    DeviceTemp<float> dW(n), dV(n);
+    if (!dr.p || !dG.p || !dS.p || !dW.p || !dV.p) return fail(SPHX_ERR_HIP, "hipMalloc failed");
+    hipStream_t st = sphx::stream();
+    HIP_CALL(hipMemcpyAsync(dr.p, r3, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    k_eval_kernels<<<blocks_for(n), 256, 0, st>>>(dr.p, n, make_kernel_consts(radius), dW.p, dG.p, dV.p, dS.p);
+    HIP_CALL(hipMemcpyAsync(W, dW.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(G, dG.p, 12 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(V, dV.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(S, dS.p, 12 * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_eval_kernels failed");
+    return SPHX_OK;
+}
+
+int sphx_ieee_probe(const float* a, const float* b, const float* c, int n, float* quot, float* root, int* trunc, float* muladd)
+{
+    if (n <= 0) return SPHX_OK;
+    if (sphx_device_count() <= 0) return fail(SPHX_ERR_NO_DEVICE, "no HIP device");
+    DeviceTemp<float> da(n), db(n), dc(n), dq(n), dr(n), dm(n);
+    DeviceTemp<int> dt(n);
+    if (!da.p || !db.p || !dc.p || !dq.p || !dr.p || !dm.p || !dt.p) return fail(SPHX_ERR_HIP, "hipMalloc failed");
+    hipStream_t st = sphx::stream();
+    HIP_CALL(hipMemcpyAsync(da.p, a, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_CALL(hipMemcpyAsync(db.p, b, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_CALL(hipMemcpyAsync(dc.p, c, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    k_ieee_probe<<<blocks_for(n), 256, 0, st>>>(da.p, db.p, dc.p, n, dq.p, dr.p, dt.p, dm.p);
+    HIP_CALL(hipMemcpyAsync(quot, dq.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(root, dr.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(trunc, dt.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CALL(hipMemcpyAsync(muladd, dm.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_ieee_probe failed");
+    return SPHX_OK;
+}
+
+int sphx_generate_dots(const sphx_system* h, float* device_dot, float* device_color)
+{
+    if (!h || !device_dot || !device_color) return fail(SPHX_ERR_INVALID, "sphx_generate_dots: bad argument");
+    const auto f = h->system->getFluids();
+    const int n = h->n;
+    if (n > 0)
+        k_generate_dots<<<blocks_for(n), 256, 0, sphx::stream()>>>(reinterpret_cast<float3*>(device_dot),
+                                                                   reinterpret_cast<float3*>(device_color), f->getPosPtr(),
+                                                                   f->getDensityPtr(), n);
+    if (hipStreamSynchronize(sphx::stream()) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_generate_dots failed");
+    return SPHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// engine.hpp — host-side internals shared by the solver / system translation units.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "DArray.h"
+#include "SPHParticles.h"
+#include "sph_device.hpp"
+
+namespace sphx {
+
+// Builds the constant block of the smoothing kernels on the host with the same fp32 expressions
+// the device would use, and finds tCut by bisection over float bit patterns: the three support
+// tests (q > 2, r <= R, x > R) are monotone in r2 because correctly-rounded sqrt and division are
+// monotone, so "largest r2 that passes" is an exact threshold.
+KernelConsts make_kernel_consts(float radius);
+GridDesc make_grid_desc(int3 cellSize, float cellLength);
+
+// Per-solver packed views of the particle sets, refreshed when positions move.
+//   posm / bposm : float4 (x, y, z, mass) in cell-sorted order, one 16-byte load per candidate
+//   pterm        : p_j / max(EPS, rho_j^2), the per-particle half of the pressure-force weight
+struct SweepCache {
+    explicit SweepCache(int num);
+    int n;
+    DArray<float> posm;                      // 4 floats per fluid particle
+    DArray<float> pterm;
+    std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
+    int nb = 0;
+    bool fluidValid = false;
+    bool boundaryValid = false;
+    const void* boundaryKey = nullptr;       // boundary pos pointer the packed copy was made from
+    KernelConsts k{};
+    GridDesc g{};
+    float radiusKey = -1.0f, cellKey = -1.0f;
+    int3 cellsKey = make_int3(0, 0, 0);
+
+    void setup(int3 cellSize, float cellLength, float radius);
+    void packFluid(const SPHParticles& fluids);
+    void packBoundary(const SPHParticles& boundaries);
+    const float4* fluid4() const { return reinterpret_cast<const float4*>(posm.addr()); }
+    float4* fluid4w() { return reinterpret_cast<float4*>(posm.addr()); }
+    const float4* boundary4() const { return reinterpret_cast<const float4*>(bposm->addr()); }
+};
+
+inline unsigned int blocks_for(int n, int block = 256) { return n > 0 ? (unsigned int)((n - 1) / block + 1) : 1u; }
+
+// optional per-kernel timing (sphx_profile_step): when enabled every launch helper brackets the
+// kernel with hipEvents on sphx::stream().
+struct KernelTimer {
+    static bool enabled;
+    static void begin(const char* name);
+    static void end();
+    static void collect(std::vector<std::string>& names, std::vector<float>& ms);
+    static void reset();
+};
+struct ScopedKernel {
+    explicit ScopedKernel(const char* name) { if (KernelTimer::enabled) KernelTimer::begin(name); }
+    ~ScopedKernel() { if (KernelTimer::enabled) KernelTimer::end(); }
+};
+
+// generic element-wise device helpers implemented in elementwise.hip
+void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n);
+void ew_gather_float(float* dst, const float* src, const int* perm, int n);
+void ew_gather_int(int* dst, const int* src, const int* perm, int n);
+void ew_copy(void* dst, const void* src, size_t bytes);
+void ew_fill_float(float* dst, float value, int n);
+void ew_iota(int* dst, int n);
+
+const std::string& last_error_text();
+void set_error_text(const std::string& s);
+
+}  // namespace sphx

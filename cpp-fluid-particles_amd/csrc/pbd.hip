@@ -1,0 +1,119 @@
+// pbd.hip — PBDSolver (position-based fluids, Macklin & Mueller 2013) as HIP kernels for gfx950.
+//
+// Reference behaviour restated from src/PBDSolver.cu:34-258: fixed number of
+// Jacobi iterations on a fixed cell table while positions move, velocity from displacement, XSPH,
+// surface effects, gravity, then predict.  XSPH writes to a separate buffer (Jacobi) instead of
+// the reference's racy in-place update.
+#include "PBDSolver.h"
+#include "engine.hpp"
+#include "sweep_ops.hpp"
+
+using namespace sphx;
+
+PBDSolver::PBDSolver(int num, int defaultMaxIter, float defaultXSPH_c, float defaultRelaxation)
+    : BasicSPHSolver(num), maxIter(defaultMaxIter), xSPH_c(defaultXSPH_c), relaxation(defaultRelaxation),
+      fluidPosLast((unsigned)num), bufferFloat3((unsigned)num), bufferFloat((unsigned)num)
+{
+}
+
+PBDSolver::PBDSolver(const std::shared_ptr<SPHParticles>& particles, int defaultMaxIter, float defaultXSPH_c,
+                     float defaultRelaxation)
+    : BasicSPHSolver((int)particles->size()), maxIter(defaultMaxIter), xSPH_c(defaultXSPH_c),
+      relaxation(defaultRelaxation), fluidPosLast(particles->size()), bufferFloat3(particles->size()),
+      bufferFloat(particles->size())
+{
+    initializePosLast(particles->getPos());
+}
+
+PBDSolver::~PBDSolver() noexcept {}
+
+// PBDSolver.h:56-60
+void PBDSolver::initializePosLast(const DArray<float3>& posFluid)
+{
+    ew_copy(fluidPosLast.addr(), posFluid.addr(), sizeof(float3) * fluidPosLast.length());
+    posLastInitialized = true;
+}
+
+// PBDSolver::updateNeighborhood, PBDSolver.cu:81-87: carry last positions through this step's sort
+void PBDSolver::updateNeighborhood(const std::shared_ptr<SPHParticles>& particles)
+{
+    const int num = (int)particles->size();
+    ScopedKernel t("poslast_permute");
+    ew_gather_float3(bufferFloat3.addr(), fluidPosLast.addr(), particles->getSortPerm(), num);
+    ew_copy(fluidPosLast.addr(), bufferFloat3.addr(), sizeof(float3) * num);
+}
+
+// PBDSolver::diffuse, PBDSolver.cu:117-125 (XSPH viscosity)
+void PBDSolver::diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid, int3 cellSize,
+                        float cellLength, float rho0, float radius, float visc)
+{
+    SweepCache& c = cache();
+    c.setup(cellSize, cellLength, radius);
+    c.packFluid(*fluids);
+    const int num = (int)fluids->size();
+    ScopedKernel t("xsph");
+    OpXsph op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), fluids->getVelPtr(), bufferFloat3.addr(), visc, rho0};
+    launch_op(op, num);
+    ew_copy(fluids->getVelPtr(), bufferFloat3.addr(), sizeof(float3) * num);
+}
+
+// PBDSolver::project, PBDSolver.cu:225-258
+int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
+                       const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float rho0, int3 cellSize,
+                       float3 spaceSize, float cellLength, float radius, int maxIterations)
+{
+    SweepCache& c = cache();
+    c.setup(cellSize, cellLength, radius);
+    c.packFluid(*fluids);
+    c.packBoundary(*boundaries);
+    const int num = (int)fluids->size();
+    const OpLambda lam{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
+                       fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation};
+    const OpDeltaPos dp{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
+                        bufferFloat.addr(), bufferFloat3.addr(), rho0};
+    auto iter = 0;
+    while (iter < maxIterations) {
+        { ScopedKernel t("pbd_lambda"); launch_op(lam, num); }
+        { ScopedKernel t("pbd_delta_pos"); launch_op(dp, num); }
+        {
+            ScopedKernel t("pbd_apply_clamp");   // keeps the packed position view in step with pos
+            launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), bufferFloat3.addr(), spaceSize, num);
+        }
+        ++iter;
+    }
+    return iter;
+}
+
+// PBDSolver::predict, PBDSolver.cu:75-79
+void PBDSolver::predict(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize)
+{
+    ew_copy(fluidPosLast.addr(), fluids->getPosPtr(), sizeof(float3) * fluids->size());
+    advect(fluids, dt, spaceSize);
+}
+
+// PBDSolver::step, PBDSolver.cu:34-73
+void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
+                     const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float3 spaceSize,
+                     int3 cellSize, float cellLength, float radius, float dt, float rho0, float rhoB, float stiff,
+                     float visc, float3 G, float surfaceTensionIntensity, float airPressure)
+{
+    (void)stiff; (void)visc;
+    if (!posLastInitialized) {
+        initializePosLast(fluids->getPos());
+        throw "PBD: The last position of fluids is initialized.";
+    }
+    invalidatePositions();
+    updateNeighborhood(fluids);
+    project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, spaceSize, cellLength, radius, maxIter);
+    {
+        ScopedKernel t("pbd_velocity");
+        launch_velocity_from_displacement(fluids->getVelPtr(), fluids->getPosPtr(), fluidPosLast.addr(), dt,
+                                          (int)fluids->size());
+    }
+    diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, xSPH_c);
+    if (surfaceTensionIntensity > EPSILON || airPressure > EPSILON)
+        handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius, dt,
+                      surfaceTensionIntensity, airPressure);
+    force(fluids, dt, G);
+    predict(fluids, dt, spaceSize);
+}

@@ -1,0 +1,206 @@
+// runtime.hip — engine stream, error reporting, kernel constants, packed views, element-wise
+// helpers and the optional per-kernel timer.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "engine.hpp"
+
+namespace sphx {
+
+// ------------------------------------------------------------------------------ stream / errors
+static hipStream_t g_stream = nullptr;
+static std::once_flag g_stream_once;
+static thread_local std::string g_last_error;
+static std::string g_last_error_global;
+
+hipStream_t stream()
+{
+    std::call_once(g_stream_once, [] {
+        if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr;
+    });
+    return g_stream;
+}
+
+void report_hip_error(hipError_t e, const char* file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error at %s:%d: %s (%d)", file, line, hipGetErrorString(e), (int)e);
+    g_last_error_global = buf;
+    fprintf(stderr, "%s\n", buf);
+}
+
+const std::string& last_error_text() { return g_last_error_global; }
+void set_error_text(const std::string& s) { g_last_error_global = s; }
+
+// ------------------------------------------------------------------------------ kernel constants
+namespace {
+float f_cube(float x) { return x * x * x; }
+float bits_to_float(unsigned int b) { float f; std::memcpy(&f, &b, 4); return f; }
+
+// largest non-negative float r2 with pred(r2) true, assuming pred is true at 0 and monotone
+template <class Pred>
+float largest_true(Pred pred)
+{
+    unsigned int lo = 0u, hi = 0x7f7fffffu;   // +0 .. FLT_MAX
+    if (pred(bits_to_float(hi))) return bits_to_float(hi);
+    while (hi - lo > 1u) {
+        const unsigned int mid = lo + (hi - lo) / 2u;
+        if (pred(bits_to_float(mid))) lo = mid; else hi = mid;
+    }
+    return bits_to_float(lo);
+}
+}  // namespace
+
+KernelConsts make_kernel_consts(float R)
+{
+    KernelConsts k;
+    k.R = R;
+    k.wA = 0.25f / (kPi * R * R * R);
+    k.viscDen = kPi * powf(R, 6);
+    k.stK = kPi * f_cube(R) * f_cube(R) * f_cube(R);
+    k.stC = 0.0156f * f_cube(R) * f_cube(R);
+    // volatile keeps the host compiler from folding sqrt/div differently from run-time IEEE ops
+    const float tW = largest_true([R](float r2) { volatile float r = sqrtf(r2); volatile float q = 2.0f * r / R; return !(q > 2.0f); });
+    const float tR = largest_true([R](float r2) { volatile float r = sqrtf(r2); return r <= R; });
+    k.tCut = tW > tR ? tW : tR;
+    return k;
+}
+
+GridDesc make_grid_desc(int3 cs, float cellLength)
+{
+    GridDesc g;
+    g.gx = cs.x; g.gy = cs.y; g.gz = cs.z; g.C = cs.x * cs.y * cs.z;
+    g.cellLength = cellLength;
+    return g;
+}
+
+// ------------------------------------------------------------------------------ element-wise
+__global__ void k_gather_float3(float3* __restrict__ dst, const float3* __restrict__ src, const int* __restrict__ perm, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[perm[q]];
+}
+__global__ void k_gather_float(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ perm, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[perm[q]];
+}
+__global__ void k_gather_int(int* __restrict__ dst, const int* __restrict__ src, const int* __restrict__ perm, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[perm[q]];
+}
+__global__ void k_fill_float(float* __restrict__ dst, float v, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = v;
+}
+__global__ void k_iota(int* __restrict__ dst, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = q;
+}
+__global__ void k_pack4(float4* __restrict__ dst, const float3* __restrict__ pos, const float* __restrict__ w, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) { const float3 p = pos[q]; dst[q] = make_float4(p.x, p.y, p.z, w[q]); }
+}
+
+void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n)
+{
+    if (n <= 0) return;
+    ScopedKernel t("gather_float3");
+    k_gather_float3<<<blocks_for(n), 256, 0, stream()>>>(dst, src, perm, n);
+}
+void ew_gather_float(float* dst, const float* src, const int* perm, int n)
+{
+    if (n <= 0) return;
+    ScopedKernel t("gather_float");
+    k_gather_float<<<blocks_for(n), 256, 0, stream()>>>(dst, src, perm, n);
+}
+void ew_gather_int(int* dst, const int* src, const int* perm, int n)
+{
+    if (n <= 0) return;
+    ScopedKernel t("gather_int");
+    k_gather_int<<<blocks_for(n), 256, 0, stream()>>>(dst, src, perm, n);
+}
+void ew_copy(void* dst, const void* src, size_t bytes)
+{
+    if (bytes) HIP_CALL(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream()));
+}
+void ew_fill_float(float* dst, float value, int n)
+{
+    if (n <= 0) return;
+    k_fill_float<<<blocks_for(n), 256, 0, stream()>>>(dst, value, n);
+}
+void ew_iota(int* dst, int n)
+{
+    if (n <= 0) return;
+    k_iota<<<blocks_for(n), 256, 0, stream()>>>(dst, n);
+}
+
+// ------------------------------------------------------------------------------ SweepCache
+SweepCache::SweepCache(int num) : n(num), posm(4u * (unsigned)num), pterm((unsigned)num) {}
+
+void SweepCache::setup(int3 cellSize, float cellLength, float radius)
+{
+    if (radius != radiusKey) { k = make_kernel_consts(radius); radiusKey = radius; }
+    if (cellLength != cellKey || cellSize.x != cellsKey.x || cellSize.y != cellsKey.y || cellSize.z != cellsKey.z) {
+        g = make_grid_desc(cellSize, cellLength);
+        cellKey = cellLength; cellsKey = cellSize;
+    }
+}
+
+void SweepCache::packFluid(const SPHParticles& fluids)
+{
+    if (fluidValid) return;
+    ScopedKernel t("pack_fluid");
+    k_pack4<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), n);
+    fluidValid = true;
+}
+
+void SweepCache::packBoundary(const SPHParticles& boundaries)
+{
+    const int count = (int)boundaries.size();
+    if (boundaryValid && boundaryKey == (const void*)boundaries.getPosPtr() && nb == count) return;
+    if (!bposm || nb != count) bposm.reset(new DArray<float>(4u * (unsigned)(count > 0 ? count : 1)));
+    nb = count;
+    ScopedKernel t("pack_boundary");
+    if (count > 0)
+        k_pack4<<<blocks_for(count), 256, 0, stream()>>>(reinterpret_cast<float4*>(bposm->addr()), boundaries.getPosPtr(),
+                                                          boundaries.getMassPtr(), count);
+    boundaryKey = (const void*)boundaries.getPosPtr();
+    boundaryValid = true;
+}
+
+// ------------------------------------------------------------------------------ KernelTimer
+bool KernelTimer::enabled = false;
+namespace {
+struct TimedSpan { std::string name; hipEvent_t a, b; };
+std::vector<TimedSpan> g_spans;
+}
+void KernelTimer::begin(const char* name)
+{
+    TimedSpan s; s.name = name;
+    HIP_CALL(hipEventCreate(&s.a)); HIP_CALL(hipEventCreate(&s.b));
+    HIP_CALL(hipEventRecord(s.a, stream()));
+    g_spans.push_back(s);
+}
+void KernelTimer::end() { HIP_CALL(hipEventRecord(g_spans.back().b, stream())); }
+void KernelTimer::collect(std::vector<std::string>& names, std::vector<float>& ms)
+{
+    HIP_CALL(hipStreamSynchronize(stream()));
+    for (auto& s : g_spans) {
+        float t = 0.0f;
+        HIP_CALL(hipEventElapsedTime(&t, s.a, s.b));
+        names.push_back(s.name); ms.push_back(t);
+    }
+}
+void KernelTimer::reset()
+{
+    for (auto& s : g_spans) { HIP_CALL(hipEventDestroy(s.a)); HIP_CALL(hipEventDestroy(s.b)); }
+    g_spans.clear();
+}
+
+}  // namespace sphx

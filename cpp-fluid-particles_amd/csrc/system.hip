@@ -1,0 +1,380 @@
+// system.hip — Particles / SPHParticles / SPHSystem of the drop-in API: uploads, the uniform-grid
+// neighbour search (stable counting sort by cell id), boundary-mass precompute and the timed,
+// optionally hipGraph-replayed, step loop.
+//
+// Reference behaviour restated (never copied): src/Particles.h:22-25, src/Particles.cu:28-36,
+// src/SPHParticles.h:22-29, src/SPHSystem.cu:33-158, src/CUDAFunctions.cuh:56-78.
+#include <algorithm>
+#include <iostream>
+
+#include "SPHSystem.h"
+#include "engine.hpp"
+
+using namespace sphx;
+
+// ================================================================================ particle sets
+Particles::Particles(const std::vector<float3>& p) : pos((unsigned)p.size()), vel((unsigned)p.size())
+{
+    if (!p.empty()) {
+        HIP_CALL(hipMemcpyAsync(pos.addr(), p.data(), sizeof(float3) * p.size(), hipMemcpyHostToDevice, sphx::stream()));
+        HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    }
+}
+
+__global__ void k_advect_only(float3* __restrict__ pos, const float3* __restrict__ vel, float dt, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] = add3(pos[i], smul3(dt, vel[i]));
+}
+
+// Particles::advect, Particles.cu:28-36: pos += dt * vel
+void Particles::advect(float dt)
+{
+    const int n = (int)size();
+    if (n <= 0) return;
+    ScopedKernel t("advect");
+    k_advect_only<<<blocks_for(n), 256, 0, sphx::stream()>>>(pos.addr(), vel.addr(), dt, n);
+}
+
+SPHParticles::SPHParticles(const std::vector<float3>& p)
+    : Particles(p), pressure((unsigned)p.size()), density((unsigned)p.size()), mass((unsigned)p.size()),
+      particle2Cell((unsigned)p.size()), sortPerm((unsigned)p.size()), ids((unsigned)p.size())
+{
+    ew_iota(ids.addr(), (int)p.size());
+    ew_iota(sortPerm.addr(), (int)p.size());
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+}
+
+// ================================================================================ grid kernels
+namespace sphx {
+
+struct GridScratch {
+    explicit GridScratch(int maxParticles, int cells)
+        : slot((unsigned)maxParticles), order((unsigned)maxParticles), tmp3((unsigned)maxParticles),
+          tmpi((unsigned)maxParticles), blockSums((unsigned)(cells / 2048 + 2)), posm(4u * (unsigned)maxParticles)
+    {
+    }
+    DArray<int> slot;       // arrival slot of particle i inside its cell (atomic order, arbitrary)
+    DArray<int> order;      // particle index stored at each bucket position (unordered inside a cell)
+    DArray<float3> tmp3;    // gather target
+    DArray<int> tmpi;
+    DArray<int> blockSums;  // scan scratch
+    DArray<float> posm;     // packed boundary positions for the boundary-mass sweep
+};
+
+struct StepGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool tried = false;
+    ~StepGraph()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
+
+}  // namespace sphx
+
+// mapParticles2Cells_CUDA + countingInCell_CUDA (CUDAFunctions.cuh:56-78) fused: cell id by true
+// fp32 division and truncation, histogram by atomics; the returned arrival slot is remembered.
+__global__ void k_cell_and_count(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts,
+                                 const float3* __restrict__ pos, GridDesc g, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int3 c = cell_of(pos[i], g.cellLength);
+    const int id = cell_id(c.x, c.y, c.z, g);
+    p2c[i] = id;
+    slot[i] = atomicAdd(&counts[id], 1);
+}
+
+// ---- exclusive scan over C+1 ints (replaces thrust::exclusive_scan, SPHSystem.cu:125) ----------
+constexpr int kScanItems = 8;                      // items per thread
+constexpr int kScanTile = 256 * kScanItems;        // items per block
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total)
+{
+    __shared__ int waveSums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) waveSums[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += waveSums[w];
+    const int tot = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int* __restrict__ blockSums, int n)
+{
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) { v[t] = (base + t < n) ? data[base + t] : 0; sum += v[t]; }
+    int total;
+    int run = block_exclusive_scan_256(sum, &total);
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) { if (base + t < n) data[base + t] = run; run += v[t]; }
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+// one block walks all tile totals with a running carry (any length)
+__global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ blockSums, int m)
+{
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += 256) {
+        const int idx = base + threadIdx.x;
+        const int v = idx < m ? blockSums[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, &total);
+        const int c = carry;
+        if (idx < m) blockSums[idx] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+__global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict__ blockSums, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += blockSums[i / kScanTile];
+}
+
+// bucket placement in arrival order, then the stable fix-up: inside a cell the reference order is
+// ascending original index (stable sort), so the rank of particle i is the number of bucket
+// mates with a smaller index.  Cells hold a handful of particles, so the count is a short loop.
+__global__ void k_place(int* __restrict__ order, const int* __restrict__ p2c, const int* __restrict__ slot,
+                        const int* __restrict__ cellStart, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[cellStart[p2c[i]] + slot[i]] = i;
+}
+__global__ void k_stable_rank(int* __restrict__ perm, const int* __restrict__ order, const int* __restrict__ p2c,
+                              const int* __restrict__ cellStart, int n, int cellsPlusOne)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int i = order[q];
+    const int c = p2c[i];
+    const int s = cellStart[c];
+    const int e = (c + 1 < cellsPlusOne) ? cellStart[c + 1] : n;   // sentinel bucket runs to n
+    int rank = 0;
+    for (int t = s; t < e; ++t) rank += (order[t] < i) ? 1 : 0;
+    perm[s + rank] = i;
+}
+
+// computeBoundaryMass_CUDA, SPHSystem.cu:79-105: mass_b = rhoB / max(EPS, sum_j W_ij) over the
+// boundary grid (the self term is excluded by W(0) = 0).
+struct BoundaryMassBody {
+    const KernelConsts& k;
+    float sum;
+    __device__ __forceinline__ void fluid(int, float3, float, float) {}
+    __device__ __forceinline__ void boundary(int, float3, float r2, float) { sum += kW(q_of(sqrtf(r2), k), k); }
+};
+__global__ void __launch_bounds__(256) k_boundary_mass(float* __restrict__ mass, const float4* __restrict__ posm,
+                                                       const int* __restrict__ csB, GridDesc g, KernelConsts k,
+                                                       float rhoB, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BoundaryMassBody body{k, 0.0f};
+    sweep27<false, true>(g, k, nullptr, nullptr, csB, posm, xyz(posm[i]), body);
+    mass[i] = rhoB / max_eps(body.sum);
+}
+__global__ void k_pack_pos_only(float4* __restrict__ dst, const float3* __restrict__ pos, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) { const float3 p = pos[q]; dst[q] = make_float4(p.x, p.y, p.z, 0.0f); }
+}
+
+// ================================================================================ SPHSystem
+#define SPHX_SYSTEM_INIT_LIST                                                                          \
+    _fluids(std::move(fluidParticles)), _boundaries(std::move(boundaryParticles)), _solver(std::move(solver)), \
+        cellStartFluid((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)),                          \
+        cellStartBoundary((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)), _spaceSize(spaceSize), \
+        _sphSmoothingRadius(sphSmoothingRadius), _sphCellLength(sphCellLength), _dt(dt), _sphRho0(sphRho0), \
+        _sphRhoBoundary(sphRhoBoundary), _sphStiff(sphStiff), _sphG(sphG), _sphVisc(sphVisc),           \
+        _sphSurfaceTensionIntensity(sphSurfaceTensionIntensity), _sphAirPressure(sphAirPressure),       \
+        _cellSize(cellSize),                                                                            \
+        bufferInt((unsigned)std::max(totalSize(), cellSize.x * cellSize.y * cellSize.z + 1))
+
+SPHSystem::SPHSystem(std::shared_ptr<SPHParticles>& fluidParticles, std::shared_ptr<SPHParticles>& boundaryParticles,
+                     std::shared_ptr<BaseSolver>& solver, const float3 spaceSize, const float sphCellLength,
+                     const float sphSmoothingRadius, const float dt, const float sphM0, const float sphRho0,
+                     const float sphRhoBoundary, const float sphStiff, const float sphVisc,
+                     const float sphSurfaceTensionIntensity, const float sphAirPressure, const float3 sphG,
+                     const int3 cellSize)
+    : SPHX_SYSTEM_INIT_LIST
+{
+    initialise(sphM0, true);
+}
+
+SPHSystem::SPHSystem(NoInitialStep, std::shared_ptr<SPHParticles>& fluidParticles,
+                     std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+                     const float3 spaceSize, const float sphCellLength, const float sphSmoothingRadius, const float dt,
+                     const float sphM0, const float sphRho0, const float sphRhoBoundary, const float sphStiff,
+                     const float sphVisc, const float sphSurfaceTensionIntensity, const float sphAirPressure,
+                     const float3 sphG, const int3 cellSize)
+    : SPHX_SYSTEM_INIT_LIST
+{
+    initialise(sphM0, false);
+}
+
+SPHSystem::~SPHSystem() noexcept {}
+
+// the constructor sequence of SPHSystem.cu:68-76
+void SPHSystem::initialise(float sphM0, bool runStep)
+{
+    const int cells = _cellSize.x * _cellSize.y * _cellSize.z;
+    _grid.reset(new GridScratch(std::max(std::max(fluidSize(), boundarySize()), 1), cells));
+    _graph.reset(new StepGraph());
+    neighborSearch(_boundaries, cellStartBoundary);
+    computeBoundaryMass();
+    ew_fill_float(_fluids->getMassPtr(), sphM0, fluidSize());
+    neighborSearch(_fluids, cellStartFluid);
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    if (runStep) step();
+}
+
+void SPHSystem::computeBoundaryMass()
+{
+    const int nb = boundarySize();
+    if (nb <= 0) return;
+    const KernelConsts k = make_kernel_consts(_sphSmoothingRadius);
+    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength);
+    float4* posm = reinterpret_cast<float4*>(_grid->posm.addr());
+    ScopedKernel t("boundary_mass");
+    k_pack_pos_only<<<blocks_for(nb), 256, 0, sphx::stream()>>>(posm, _boundaries->getPosPtr(), nb);
+    k_boundary_mass<<<blocks_for(nb), 256, 0, sphx::stream()>>>(_boundaries->getMassPtr(), posm, cellStartBoundary.addr(), g, k,
+                                                                 _sphRhoBoundary, nb);
+}
+
+// SPHSystem::neighborSearch, SPHSystem.cu:114-127, as one stable counting sort:
+//   cell id + histogram -> exclusive scan -> bucket placement -> stable rank -> gather pos, vel, id.
+// particle2Cell keeps the PRE-sort keys; the permutation is published through
+// SPHParticles::getSortPerm() for solver-owned persistent arrays.
+void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart)
+{
+    const int num = (int)particles->size();
+    const int cellsPlusOne = _cellSize.x * _cellSize.y * _cellSize.z + 1;
+    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength);
+    hipStream_t st = sphx::stream();
+    int* p2c = particles->getParticle2Cell();
+    int* perm = particles->getSortPerm();
+
+    HIP_CALL(hipMemsetAsync(cellStart.addr(), 0, sizeof(int) * cellsPlusOne, st));
+    if (num > 0) {
+        ScopedKernel t("grid_cell_count");
+        k_cell_and_count<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), particles->getPosPtr(), g, num);
+    }
+    {
+        ScopedKernel t("grid_scan");
+        const int tiles = (cellsPlusOne - 1) / kScanTile + 1;
+        k_scan_tiles<<<tiles, 256, 0, st>>>(cellStart.addr(), _grid->blockSums.addr(), cellsPlusOne);
+        if (tiles > 1) {
+            k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles);
+            k_scan_add_offsets<<<blocks_for(cellsPlusOne), 256, 0, st>>>(cellStart.addr(), _grid->blockSums.addr(), cellsPlusOne);
+        }
+    }
+    if (num <= 0) return;
+    {
+        ScopedKernel t("grid_stable_rank");
+        k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
+        k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), num, cellsPlusOne);
+    }
+    {
+        ScopedKernel t("grid_gather");
+        ew_gather_float3(_grid->tmp3.addr(), particles->getPosPtr(), perm, num);
+        ew_copy(particles->getPosPtr(), _grid->tmp3.addr(), sizeof(float3) * num);
+        ew_gather_float3(_grid->tmp3.addr(), particles->getVelPtr(), perm, num);
+        ew_copy(particles->getVelPtr(), _grid->tmp3.addr(), sizeof(float3) * num);
+        ew_gather_int(_grid->tmpi.addr(), particles->getIdPtr(), perm, num);
+        ew_copy(particles->getIdPtr(), _grid->tmpi.addr(), sizeof(int) * num);
+    }
+}
+
+void SPHSystem::enqueueStep()
+{
+    neighborSearch(_fluids, cellStartFluid);
+    _solver->step(_fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
+                  _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphStiff, _sphVisc, _sphG,
+                  _sphSurfaceTensionIntensity, _sphAirPressure);
+}
+
+// SPHSystem::step, SPHSystem.cu:129-158
+float SPHSystem::step()
+{
+    hipStream_t st = sphx::stream();
+    hipEvent_t start, stop;
+    HIP_CALL(hipEventCreate(&start));
+    HIP_CALL(hipEventCreate(&stop));
+    HIP_CALL(hipEventRecord(start, st));
+    try {
+        enqueueStep();
+        HIP_CALL(hipStreamSynchronize(st));
+        CHECK_KERNEL();
+    } catch (const char* s) {
+        std::cout << s << "\n";
+    } catch (...) {
+        std::cout << "Unknown exception in SPHSystem::step\n";
+    }
+    float milliseconds = 0.0f;
+    HIP_CALL(hipEventRecord(stop, st));
+    HIP_CALL(hipEventSynchronize(stop));
+    HIP_CALL(hipEventElapsedTime(&milliseconds, start, stop));
+    HIP_CALL(hipEventDestroy(start));
+    HIP_CALL(hipEventDestroy(stop));
+    return milliseconds;
+}
+
+// n steps, one sync.  When the solver is graph-safe the step is captured once and replayed.
+float SPHSystem::stepN(int n)
+{
+    if (n <= 0) return 0.0f;
+    hipStream_t st = sphx::stream();
+    const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled;
+    if (wantGraph && !_graph->exec && !_graph->tried) {
+        _graph->tried = true;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            try { enqueueStep(); } catch (...) { ok = false; }
+            hipGraph_t gph = nullptr;
+            if (hipStreamEndCapture(st, &gph) != hipSuccess) ok = false;
+            if (ok && gph && hipGraphInstantiate(&_graph->exec, gph, nullptr, nullptr, 0) == hipSuccess) {
+                _graph->graph = gph;
+            } else {
+                if (gph) (void)hipGraphDestroy(gph);
+                _graph->exec = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    hipEvent_t start, stop;
+    HIP_CALL(hipEventCreate(&start));
+    HIP_CALL(hipEventCreate(&stop));
+    HIP_CALL(hipEventRecord(start, st));
+    for (int s = 0; s < n; ++s) {
+        if (wantGraph && _graph->exec) {
+            HIP_CALL(hipGraphLaunch(_graph->exec, st));
+        } else {
+            try { enqueueStep(); } catch (const char* msg) { std::cout << msg << "\n"; }
+        }
+    }
+    HIP_CALL(hipEventRecord(stop, st));
+    HIP_CALL(hipEventSynchronize(stop));
+    HIP_CALL(hipStreamSynchronize(st));
+    float milliseconds = 0.0f;
+    HIP_CALL(hipEventElapsedTime(&milliseconds, start, stop));
+    HIP_CALL(hipEventDestroy(start));
+    HIP_CALL(hipEventDestroy(stop));
+    return milliseconds;
+}

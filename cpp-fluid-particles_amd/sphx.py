@@ -1,0 +1,208 @@
+"""ctypes binding of libsphx.so (include/sphx_c.h) — the host-side Python view of the engine.
+
+This is plumbing for tests, bench.py and the multi-GPU driver: every call goes straight through
+the C ABI into the HIP engine.  There is no CPU path; without the built library or without a HIP
+device the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsphx.so")
+
+WCSPH, DFSPH, PBD = 0, 1, 2
+
+(F_POS, F_VEL, F_DENSITY, F_PRESSURE, F_MASS, F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID, F_BPOS,
+ F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3) = range(18)
+
+_INT_FIELDS = (F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID)
+_VEC_FIELDS = (F_POS, F_VEL, F_BPOS, F_POS_LAST, F_BUF3)
+
+EXPORTS = [
+    "sphx_last_error", "sphx_device_count", "sphx_set_device", "sphx_sizeof_params",
+    "sphx_scene_params", "sphx_scene_counts", "sphx_scene_fill", "sphx_create", "sphx_destroy",
+    "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
+    "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
+    "sphx_generate_dots",
+]
+
+
+class Params(C.Structure):
+    """sphx_params (include/sphx_c.h)."""
+    _fields_ = [
+        ("space", C.c_float * 3), ("cells", C.c_int * 3),
+        ("cell_length", C.c_float), ("radius", C.c_float), ("dt", C.c_float), ("m0", C.c_float),
+        ("rho0", C.c_float), ("rho_boundary", C.c_float), ("stiff", C.c_float), ("visc", C.c_float),
+        ("surface_tension", C.c_float), ("air_pressure", C.c_float), ("gravity", C.c_float * 3),
+        ("solver", C.c_int),
+        ("dfsph_density_thr", C.c_float), ("dfsph_divergence_thr", C.c_float),
+        ("dfsph_max_iter", C.c_int), ("dfsph_fixed_div", C.c_int), ("dfsph_fixed_den", C.c_int),
+        ("pbd_iters", C.c_int), ("pbd_xsph_c", C.c_float), ("pbd_relaxation", C.c_float),
+        ("pow7_mode", C.c_int), ("xsph_mode", C.c_int), ("reserved", C.c_int * 4),
+    ]
+
+    def copy(self):
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        return q
+
+
+class SphxError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libsphx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SphxError("libsphx.so is not built (run `make -C cpp-fluid-particles_amd` or "
+                            "__graft_entry__.build()); the engine has no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.sphx_last_error.restype = C.c_char_p
+        L.sphx_scene_params.argtypes = [C.c_int, C.POINTER(Params)]
+        L.sphx_scene_counts.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sphx_scene_fill.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.sphx_create.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                  C.POINTER(C.c_void_p)]
+        L.sphx_destroy.argtypes = [C.c_void_p]
+        L.sphx_step.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.sphx_step_n.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.sphx_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        L.sphx_iters.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 2
+        L.sphx_field_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        L.sphx_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.sphx_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.sphx_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.sphx_profile_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.sphx_eval_kernels.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
+        L.sphx_ieee_probe.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
+        L.sphx_generate_dots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if L.sphx_sizeof_params() != C.sizeof(Params):
+            raise SphxError("sphx_params layout mismatch between sphx.py and libsphx.so")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SphxError("sphx error %d: %s" % (rc, lib().sphx_last_error().decode()))
+
+
+def device_count():
+    return lib().sphx_device_count()
+
+
+def set_device(ordinal):
+    _check(lib().sphx_set_device(ordinal))
+
+
+def scene(nx):
+    """(params, fluid[n,3], boundary[nb,3]) of the dam-break scene (nx=24: the reference scene)."""
+    L = lib()
+    P = Params()
+    _check(L.sphx_scene_params(nx, C.byref(P)))
+    n, nb = C.c_int(), C.c_int()
+    _check(L.sphx_scene_counts(nx, C.byref(n), C.byref(nb)))
+    fluid = np.empty((n.value, 3), np.float32)
+    boundary = np.empty((nb.value, 3), np.float32)
+    _check(L.sphx_scene_fill(nx, fluid.ctypes.data, boundary.ctypes.data))
+    return P, fluid, boundary
+
+
+class System:
+    """One SPHSystem on the current HIP device."""
+
+    def __init__(self, params, fluid, boundary, ctor_step=True):
+        fluid = np.ascontiguousarray(fluid, np.float32).reshape(-1, 3)
+        boundary = np.ascontiguousarray(boundary, np.float32).reshape(-1, 3)
+        self.n, self.nb = len(fluid), len(boundary)
+        self.cells = params.cells[0] * params.cells[1] * params.cells[2]
+        self.params = params
+        h = C.c_void_p()
+        _check(lib().sphx_create(C.byref(params), fluid.ctypes.data, self.n, boundary.ctypes.data, self.nb,
+                                 int(ctor_step), C.byref(h)))
+        self._h = h
+
+    def step(self):
+        ms = C.c_float()
+        _check(lib().sphx_step(self._h, C.byref(ms)))
+        return ms.value
+
+    def step_n(self, n):
+        ms = C.c_float()
+        _check(lib().sphx_step_n(self._h, n, C.byref(ms)))
+        return ms.value
+
+    def iters(self):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().sphx_iters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def get(self, field):
+        nbytes = C.c_size_t()
+        _check(lib().sphx_field_bytes(self._h, field, C.byref(nbytes)))
+        dt = np.int32 if field in _INT_FIELDS else np.float32
+        out = np.empty(nbytes.value // 4, dt)
+        _check(lib().sphx_get(self._h, field, out.ctypes.data, nbytes.value))
+        return out.reshape(-1, 3) if field in _VEC_FIELDS else out
+
+    def set(self, field, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().sphx_set(self._h, field, arr.ctypes.data, arr.nbytes))
+
+    def device_ptr(self, field):
+        p = C.c_void_p()
+        _check(lib().sphx_device_ptr(self._h, field, C.byref(p)))
+        return p.value
+
+    def profile_step(self, cap=64):
+        names = (C.c_char * 48 * cap)()
+        ms = (C.c_float * cap)()
+        cnt = C.c_int()
+        _check(lib().sphx_profile_step(self._h, cap, names, ms, C.byref(cnt)))
+        return [(names[i].value.decode(), ms[i]) for i in range(cnt.value)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sphx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def eval_kernels(r3, radius):
+    r3 = np.ascontiguousarray(r3, np.float32).reshape(-1, 3)
+    n = len(r3)
+    W = np.empty(n, np.float32); G = np.empty((n, 3), np.float32)
+    V = np.empty(n, np.float32); S = np.empty((n, 3), np.float32)
+    _check(lib().sphx_eval_kernels(r3.ctypes.data, n, radius, W.ctypes.data, G.ctypes.data, V.ctypes.data,
+                                   S.ctypes.data))
+    return W, G, V, S
+
+
+def ieee_probe(a, b, c):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    c = np.ascontiguousarray(c, np.float32)
+    n = len(a)
+    q = np.empty(n, np.float32); r = np.empty(n, np.float32)
+    t = np.empty(n, np.int32); m = np.empty(n, np.float32)
+    _check(lib().sphx_ieee_probe(a.ctypes.data, b.ctypes.data, c.ctypes.data, n, q.ctypes.data, r.ctypes.data,
+                                 t.ctypes.data, m.ctypes.data))
+    return q, r, t, m

@@ -1,0 +1,60 @@
+// BasicSPHSolver.h — weakly-compressible SPH solver (reference: src/BasicSPHSolver.h:20-52,
+// src/BasicSPHSolver.cu:32-381).
+//
+// step() = gravity -> viscosity -> [colour-gradient surface detection + surface tension / air
+// pressure] -> density -> Tait pressure -> pressure force -> advect + box clamp.
+// The protected virtuals keep the reference's names and argument lists so derived solvers
+// (DFSPHSolver, PBDSolver, user subclasses) compose the same building blocks.
+//
+// Engine side: every neighbour sweep is a hand-written HIP kernel over cell-sorted, float4-packed
+// views (position+mass) that the solver refreshes whenever positions change; see DESIGN.md.
+#pragma once
+
+#include <memory>
+#include "BaseSolver.h"
+
+namespace sphx { struct SweepCache; }
+
+class BasicSPHSolver : public BaseSolver {
+public:
+    explicit BasicSPHSolver(int num);
+    virtual ~BasicSPHSolver() noexcept;
+
+    virtual void step(std::shared_ptr<SPHParticles>& fluids,
+                      const std::shared_ptr<SPHParticles>& boundaries,
+                      const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary,
+                      float3 spaceSize, int3 cellSize, float cellLength, float radius, float dt,
+                      float rho0, float rhoB, float stiff, float visc, float3 G,
+                      float surfaceTensionIntensity, float airPressure) override;
+
+    bool graphSafe() const override { return true; }
+    // engine extension: viscosity delta-v during diffuse(), colour gradient after handleSurface()
+    const DArray<float3>& getColorGradient() const { return bufferFloat3; }
+
+protected:
+    virtual void force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G) override final;
+    virtual void advect(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize) override final;
+    virtual void project(std::shared_ptr<SPHParticles>& fluids,
+                         const std::shared_ptr<SPHParticles>& boundaries,
+                         const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary,
+                         float rho0, float stiff, int3 cellSize, float cellLength, float radius,
+                         float dt);
+    virtual void diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
+                         int3 cellSize, float cellLength, float rho0, float radius, float visc,
+                         float dt);
+    virtual void handleSurface(std::shared_ptr<SPHParticles>& fluids,
+                               const std::shared_ptr<SPHParticles>& boundaries,
+                               const DArray<int>& cellStartFluid,
+                               const DArray<int>& cellStartBoundary, float rho0, float rhoB,
+                               int3 cellSize, float cellLength, float radius, float dt,
+                               float surfaceTensionIntensity, float airPressure);
+
+    // engine: packed per-step views shared with the derived solvers
+    sphx::SweepCache& cache() { return *_cache; }
+    // marks the packed position view stale (call after anything that moves particles)
+    void invalidatePositions();
+
+private:
+    DArray<float3> bufferFloat3;   // viscosity delta-v, then the colour gradient
+    std::unique_ptr<sphx::SweepCache> _cache;
+};

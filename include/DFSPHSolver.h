@@ -1,0 +1,73 @@
+// DFSPHSolver.h — divergence-free SPH solver (reference: src/DFSPHSolver.h:20-65,
+// src/DFSPHSolver.cu:33-363).
+//
+// step() = density+alpha -> divergence-free solve -> gravity, viscosity, surface effects ->
+// constant-density solve with warm start -> advect.  Loop semantics follow
+// SURVEY.md Q9; the termination sum is an exact fixed-point reduction (deviation D2).
+// Engine extension: setFixedIterations(v, d) runs exactly v divergence and d density iterations
+// with no device->host read-back, which makes the whole step hipGraph-capturable.
+#pragma once
+
+#include "BasicSPHSolver.h"
+
+class DFSPHSolver final : public BasicSPHSolver {
+public:
+    explicit DFSPHSolver(int num, float defaultDensityErrorThreshold = 1e-3f,
+                         float defaultDivergenceErrorThreshold = 1e-3f, int defaultMaxIter = 20);
+    virtual ~DFSPHSolver() noexcept;
+
+    virtual void step(std::shared_ptr<SPHParticles>& fluids,
+                      const std::shared_ptr<SPHParticles>& boundaries,
+                      const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary,
+                      float3 spaceSize, int3 cellSize, float cellLength, float radius, float dt,
+                      float rho0, float rhoB, float stiff, float visc, float3 G,
+                      float surfaceTensionIntensity, float airPressure) override;
+
+    // --- engine extensions ---------------------------------------------------------------
+    void setFixedIterations(int divergenceIters, int densityIters)
+    {
+        fixedDiv = divergenceIters;
+        fixedDen = densityIters;
+    }
+    bool graphSafe() const override { return fixedDiv >= 0 && fixedDen >= 0; }
+    int lastDivergenceIterations() const { return lastDiv; }
+    int lastDensityIterations() const { return lastDen; }
+    const DArray<float>& getAlpha() const { return alpha; }
+    const DArray<float>& getStiffness() const { return bufferFloat; }
+    const DArray<float>& getError() const { return error; }
+    DArray<float>& getWarmStiffness() { return denWarmStiff; }
+
+protected:
+    // hides BasicSPHSolver::project (different signature), as in the reference
+    virtual int project(std::shared_ptr<SPHParticles>& fluids,
+                        const std::shared_ptr<SPHParticles>& boundaries,
+                        const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary,
+                        float rho0, int3 cellSize, float cellLength, float radius, float dt,
+                        float errorThreshold, int maxIter);
+
+private:
+    void computeDensityAlpha(std::shared_ptr<SPHParticles>& fluids,
+                             const std::shared_ptr<SPHParticles>& boundaries,
+                             const DArray<int>& cellStartFluid,
+                             const DArray<int>& cellStartBoundary, int3 cellSize, float cellLength,
+                             float radius);
+    int correctDivergenceError(std::shared_ptr<SPHParticles>& fluids,
+                               const std::shared_ptr<SPHParticles>& boundaries,
+                               const DArray<int>& cellStartFluid,
+                               const DArray<int>& cellStartBoundary, float rho0, int3 cellSize,
+                               float cellLength, float radius, float dt, float errorThreshold,
+                               int maxIter);
+    float readErrorTotal();
+
+    DArray<float> alpha;
+    DArray<float> bufferFloat;     // stiffness kappa
+    DArray<float> error;
+    DArray<float> denWarmStiff;
+    DArray<float> scratch;         // permutation target for denWarmStiff
+    DArray<int> errorAccum;        // 2 ints = one 64-bit fixed-point accumulator
+    const float densityErrorThreshold;
+    const float divergenceErrorThreshold;
+    const int maxIter;
+    int fixedDiv = -1, fixedDen = -1;
+    int lastDiv = 0, lastDen = 0;
+};

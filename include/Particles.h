@@ -1,0 +1,30 @@
+// Particles.h — position/velocity state of the drop-in API (reference: src/Particles.h:20-50).
+//
+// Constructed from host positions (blocking upload, velocities start at zero); getPosPtr /
+// getVelPtr are raw device pointers to AoS float3 arrays (12-byte stride) and stay valid and
+// current after every SPHSystem::step().  advect(dt) is pos += dt * vel (Particles.cu:28-36).
+#pragma once
+
+#include <vector>
+#include "DArray.h"
+
+class Particles {
+public:
+    explicit Particles(const std::vector<float3>& p);
+
+    Particles(const Particles&) = delete;
+    Particles& operator=(const Particles&) = delete;
+
+    unsigned int size() const { return pos.length(); }
+    float3* getPosPtr() const { return pos.addr(); }
+    float3* getVelPtr() const { return vel.addr(); }
+    const DArray<float3>& getPos() const { return pos; }
+
+    void advect(float dt);
+
+    virtual ~Particles() noexcept {}
+
+protected:
+    DArray<float3> pos;
+    DArray<float3> vel;
+};

@@ -1,0 +1,79 @@
+// SPHSystem.h — owner of the particle sets, the uniform grid and the time-step loop of the
+// drop-in API (reference: src/SPHSystem.h:20-84, src/SPHSystem.cu:33-158).
+//
+// Construction takes ownership by MOVING from the caller's shared_ptrs (they become null), then
+// runs: boundary neighbour search -> boundary masses -> uniform fluid mass -> fluid neighbour
+// search -> one full step().  step() = neighbour search + solver->step() + device
+// sync, returns the hipEvent-timed milliseconds.  The neighbour search is a stable counting sort
+// by linear cell id (x slowest) written as HIP kernels; it reproduces thrust::sort_by_key's
+// permutation exactly (DESIGN.md "Neighbour grid").
+#pragma once
+
+#include <memory>
+#include "BaseSolver.h"
+
+namespace sphx { struct GridScratch; struct StepGraph; }
+
+class SPHSystem {
+public:
+    SPHSystem(std::shared_ptr<SPHParticles>& fluidParticles,
+              std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+              float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
+              float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
+              float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
+    SPHSystem(const SPHSystem&) = delete;
+    SPHSystem& operator=(const SPHSystem&) = delete;
+    ~SPHSystem() noexcept;
+
+    float step();
+
+    int size() const { return fluidSize(); }
+    int fluidSize() const { return (*_fluids).size(); }
+    int boundarySize() const { return (*_boundaries).size(); }
+    int totalSize() const { return (*_fluids).size() + (*_boundaries).size(); }
+    auto getFluids() const { return static_cast<const std::shared_ptr<SPHParticles>>(_fluids); }
+    auto getBoundaries() const { return static_cast<const std::shared_ptr<SPHParticles>>(_boundaries); }
+
+    // --- engine extensions -------------------------------------------------------------------
+    // n steps back to back with a single sync at the end; replays a captured hipGraph when the
+    // solver reports graphSafe().  Returns the hipEvent time of the whole batch in ms.
+    float stepN(int n);
+    // engine construction without the trailing step() of the reference constructor (used by the
+    // C ABI when run_ctor_step = 0, for per-kernel tests)
+    struct NoInitialStep {};
+    SPHSystem(NoInitialStep, std::shared_ptr<SPHParticles>& fluidParticles,
+              std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+              float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
+              float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
+              float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
+    const DArray<int>& getCellStartFluid() const { return cellStartFluid; }
+    const DArray<int>& getCellStartBoundary() const { return cellStartBoundary; }
+    BaseSolver* getSolver() const { return _solver.get(); }
+
+private:
+    void initialise(float sphM0, bool runStep);
+    void computeBoundaryMass();
+    void neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart);
+    void enqueueStep();   // neighbour search + solver step, no sync
+
+    std::shared_ptr<SPHParticles> _fluids;
+    const std::shared_ptr<SPHParticles> _boundaries;
+    std::shared_ptr<BaseSolver> _solver;
+    DArray<int> cellStartFluid;
+    DArray<int> cellStartBoundary;
+    const float3 _spaceSize;
+    const float _sphSmoothingRadius;
+    const float _sphCellLength;
+    const float _dt;
+    const float _sphRho0;
+    const float _sphRhoBoundary;
+    const float _sphStiff;
+    const float3 _sphG;
+    const float _sphVisc;
+    const float _sphSurfaceTensionIntensity;
+    const float _sphAirPressure;
+    const int3 _cellSize;
+    DArray<int> bufferInt;
+    std::unique_ptr<sphx::GridScratch> _grid;
+    std::unique_ptr<sphx::StepGraph> _graph;
+};

@@ -1,0 +1,150 @@
+/*
+ * sphx_c.h — C ABI of the MI355X-native SPH engine (libsphx.so).
+ *
+ * The reference (zhai-xiao/CPP-Fluid-Particles) exposes its hot path as C++ classes, not as a C
+ * plugin interface; the source-compatible C++ mirror of those classes lives next to this file
+ * (DArray.h, Particles.h, SPHParticles.h, BaseSolver.h, BasicSPHSolver.h, DFSPHSolver.h,
+ * PBDSolver.h, SPHSystem.h).  This header is the flat `extern "C"` boundary a binding (ctypes,
+ * cgo, JNI, ...) uses: plain pointers and sizes, no C++ or torch types.  Every entry point names
+ * the reference interface it stands for.  INTEGRATION.md shows the reference-side stub.
+ *
+ * All functions return 0 on success or a negative sphx_status; sphx_last_error() gives text.
+ * There is no CPU fallback: without a HIP device sphx_create fails with SPHX_ERR_NO_DEVICE.
+ */
+#ifndef SPHX_C_H
+#define SPHX_C_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sphx_status {
+    SPHX_OK = 0,
+    SPHX_ERR_INVALID = -1,     /* bad argument / size mismatch */
+    SPHX_ERR_NO_DEVICE = -2,   /* no HIP device visible */
+    SPHX_ERR_HIP = -3,         /* a HIP runtime call failed */
+    SPHX_ERR_STATE = -4        /* call not valid in the current state */
+} sphx_status;
+
+/* solver kinds: the three BaseSolver implementations selected in main.cpp:119-130 */
+enum { SPHX_WCSPH = 0, SPHX_DFSPH = 1, SPHX_PBD = 2 };
+
+/*
+ * Scalars of one simulation: the SPHSystem constructor arguments (SPHSystem.h:22-38) — which are
+ * also the 14 scalars of BaseSolver::step (BaseSolver.h:22-26) plus m0 — followed by the solver
+ * constructor knobs (DFSPHSolver.h:27-39, PBDSolver.h:27-38).
+ */
+typedef struct sphx_params {
+    float space[3];            /* spaceSize */
+    int   cells[3];            /* cellSize = ceil(spaceSize / cellLength), main.cpp:67 */
+    float cell_length;         /* sphCellLength */
+    float radius;              /* sphSmoothingRadius */
+    float dt;
+    float m0;                  /* sphM0, uniform fluid particle mass */
+    float rho0;                /* sphRho0 */
+    float rho_boundary;        /* sphRhoBoundary */
+    float stiff;               /* sphStiff (WCSPH Tait EOS) */
+    float visc;                /* sphVisc */
+    float surface_tension;     /* sphSurfaceTensionIntensity */
+    float air_pressure;        /* sphAirPressure */
+    float gravity[3];          /* sphG */
+    int   solver;              /* SPHX_WCSPH / SPHX_DFSPH / SPHX_PBD */
+    float dfsph_density_thr;   /* DFSPHSolver ctor: defaultDensityErrorThreshold (1e-3) */
+    float dfsph_divergence_thr;/* DFSPHSolver ctor: defaultDivergenceErrorThreshold (1e-3) */
+    int   dfsph_max_iter;      /* DFSPHSolver ctor: defaultMaxIter (20) */
+    int   dfsph_fixed_div;     /* <0: adaptive loop of DFSPHSolver.cu:347-361; >=0: exactly that many */
+    int   dfsph_fixed_den;     /* <0: adaptive loop of DFSPHSolver.cu:187-208; >=0: exactly that many */
+    int   pbd_iters;           /* PBDSolver ctor: defaultMaxIter (20), always all are run */
+    float pbd_xsph_c;          /* PBDSolver ctor: defaultXSPH_c (0.05) */
+    float pbd_relaxation;      /* PBDSolver ctor: defaultRelaxation (0.75) */
+    int   pow7_mode;           /* must be 0 (fp64 multiply chain for the Tait exponent) */
+    int   xsph_mode;           /* must be 0 (Jacobi XSPH) */
+    int   reserved[4];
+} sphx_params;
+
+/* device-resident fields readable through sphx_get (host copy) / sphx_device_ptr (raw pointer) */
+typedef enum sphx_field {
+    SPHX_F_POS = 0,        /* float[3n]  SPHParticles::getPosPtr,  Particles.h:32-34   */
+    SPHX_F_VEL,            /* float[3n]  SPHParticles::getVelPtr,  Particles.h:35-37   */
+    SPHX_F_DENSITY,        /* float[n]   getDensityPtr, SPHParticles.h:40-42          */
+    SPHX_F_PRESSURE,       /* float[n]   getPressurePtr, SPHParticles.h:34-36         */
+    SPHX_F_MASS,           /* float[n]   getMassPtr, SPHParticles.h:49-51             */
+    SPHX_F_CELL,           /* int[n]     getParticle2Cell (pre-sort order), :46-48    */
+    SPHX_F_CELLSTART_F,    /* int[C+1]   SPHSystem::cellStartFluid, SPHSystem.h:67    */
+    SPHX_F_CELLSTART_B,    /* int[C+1]   SPHSystem::cellStartBoundary, SPHSystem.h:68 */
+    SPHX_F_ID,             /* int[n]     original index of the particle now in slot q  */
+    SPHX_F_BPOS,           /* float[3nb] boundary positions (cell-sorted)              */
+    SPHX_F_BMASS,          /* float[nb]  boundary masses, SPHSystem.cu:79-112          */
+    SPHX_F_ALPHA,          /* float[n]   DFSPHSolver::alpha                            */
+    SPHX_F_KAPPA,          /* float[n]   DFSPHSolver::bufferFloat (stiffness)          */
+    SPHX_F_ERROR,          /* float[n]   DFSPHSolver::error                            */
+    SPHX_F_WARM,           /* float[n]   DFSPHSolver::denWarmStiff                     */
+    SPHX_F_POS_LAST,       /* float[3n]  PBDSolver::fluidPosLast                       */
+    SPHX_F_LAMBDA,         /* float[n]   PBDSolver::bufferFloat (lambda)               */
+    SPHX_F_BUF3,           /* float[3n]  BasicSPHSolver::bufferFloat3 (colour gradient)*/
+    SPHX_F_COUNT_
+} sphx_field;
+
+typedef struct sphx_system sphx_system;   /* opaque: owns SPHParticles x2, a solver, an SPHSystem */
+
+/* library / device ------------------------------------------------------------------------- */
+const char *sphx_last_error(void);
+int  sphx_device_count(void);                         /* hipGetDeviceCount; 0 when no GPU */
+int  sphx_set_device(int ordinal);                    /* hipSetDevice (one process per GPU) */
+int  sphx_sizeof_params(void);
+
+/* scene of main.cpp:54-117, scaled by nx/24 as BASELINE.md §4 prescribes (nx=24: the reference
+ * scene).  Two-call protocol: counts first, then fill caller-owned host buffers.              */
+int  sphx_scene_params(int nx, sphx_params *out);
+int  sphx_scene_counts(int nx, int *n_fluid, int *n_boundary);
+int  sphx_scene_fill(int nx, float *fluid_xyz, float *boundary_xyz);
+
+/* SPHSystem::SPHSystem (SPHSystem.cu:33-77) incl. make_shared<SPHParticles> x2 and the solver
+ * (main.cpp:86,117,119-134).  Host buffers are copied (Particles.h:22-25).  run_ctor_step=1
+ * reproduces the reference constructor, which ends with one full step() (SPHSystem.cu:76).   */
+int  sphx_create(const sphx_params *params, const float *fluid_xyz, int n_fluid,
+                 const float *boundary_xyz, int n_boundary, int run_ctor_step, sphx_system **out);
+int  sphx_destroy(sphx_system *sys);
+
+/* SPHSystem::step (SPHSystem.cu:129-158): neighbour search + solver step + device sync;
+ * *ms receives the hipEvent-timed duration the reference returns.                             */
+int  sphx_step(sphx_system *sys, float *ms);
+/* n back-to-back steps with one sync at the end (fixed-iteration modes replay a captured
+ * hipGraph); *ms_total is the hipEvent time of the whole batch.                               */
+int  sphx_step_n(sphx_system *sys, int n, float *ms_total);
+
+/* SPHSystem::size/boundarySize (SPHSystem.h:44-55) and grid size */
+int  sphx_counts(const sphx_system *sys, int *n_fluid, int *n_boundary, int *n_cells);
+/* iteration counts of the last DFSPH step (the values DFSPHSolver.cu:49,65 compute and drop) */
+int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iters);
+
+/* field access: blocking D2H / H2D copies of whole fields, and raw device pointers */
+int  sphx_field_bytes(const sphx_system *sys, int field, size_t *bytes);
+int  sphx_get(const sphx_system *sys, int field, void *host_dst, size_t bytes);
+int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM */
+int  sphx_device_ptr(const sphx_system *sys, int field, void **device_ptr);
+
+/* per-kernel timing of the last sphx_profile_step: names/ms arrays of up to cap entries */
+int  sphx_profile_step(sphx_system *sys, int cap, char (*names)[48], float *ms, int *count);
+
+/* pointwise evaluation of the four smoothing kernels of CUDAFunctions.cuh:23-98 on the device
+ * (device-function parity test): r3 = n displacement vectors, outputs W[n], gradW[3n],
+ * viscosity laplacian[n], surface-tension gradient[3n].  Host pointers.                       */
+int  sphx_eval_kernels(const float *r3, int n, float radius, float *W, float *gradW,
+                       float *visc_lap, float *surf_grad);
+
+/* IEEE self-test: evaluates a/b, sqrt(a), (int)(a/b), a*b+c (uncontracted) on the device for n
+ * host-supplied operands so a test can compare them bit-for-bit with the host.               */
+int  sphx_ieee_probe(const float *a, const float *b, const float *c, int n,
+                     float *quot, float *root, int *trunc, float *muladd);
+
+/* generate_dots (vbo.cu:26-51): position copy + density colour ramp into caller device
+ * buffers dot[3n], color[3n] (the render-side consumer of the path).                          */
+int  sphx_generate_dots(const sphx_system *sys, float *device_dot, float *device_color);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_C_H */

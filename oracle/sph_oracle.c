@@ -90,6 +90,14 @@ static inline f3 div3s(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static inline float len3(f3 a) { return sqrtf(dot3(a, a)); }
 
+
+/* fmaxf/fminf restated with explicit compares so that signed zeros and NaNs behave the same on
+ * every toolchain (PTX max/min order -0 < +0; libm and v_max_f32 need not agree bit-for-bit):
+ *   max_eps(x) = fmaxf(EPSILON, x);  max0(x) = fmaxf(x, 0.0f);  min0(x) = fminf(x, 0.0f).       */
+static inline float max_eps(float x) { return (x > ORACLE_EPS) ? x : ORACLE_EPS; }
+static inline float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
+static inline float min0(float x) { return (x < 0.0f) ? x : ((x == 0.0f) ? x : 0.0f); }
+
 /* ------------------------------------------------------------- CUDAFunctions.cuh kernels ---- */
 /* cubic_spline_kernel, CUDAFunctions.cuh:23-35 */
 static inline float kW(float r, float R)
@@ -212,7 +220,7 @@ static void boundary_mass(oracle_sys *s)
             for (int j = s->csB[cid]; j < s->csB[cid + 1]; ++j)
                 sum += kW(len3(sub3(s->bpos[i], s->bpos[j])), P->radius);
         SWEEP_END
-        s->bmass[i] = P->rho_boundary / fmaxf(ORACLE_EPS, sum);
+        s->bmass[i] = P->rho_boundary / max_eps(sum);
     }
 }
 
@@ -262,7 +270,7 @@ static void k_color_grad(oracle_sys *s)
                 den += s->bmass[j] / P->rho_boundary * kW(len3(d), P->radius);
             }
         SWEEP_END
-        s->buf3[i] = div3s(cg, fmaxf(ORACLE_EPS, den));
+        s->buf3[i] = div3s(cg, max_eps(den));
     }
 }
 /* surfaceTensionAndAirPressure_CUDA, BasicSPHSolver.cu:332-370 */
@@ -283,7 +291,7 @@ static void k_surface(oracle_sys *s)
                 a = add3(a, div3s(mul3s(smul3(P->air_pressure * s->mass[j] / (P->rho0 * P->rho0),
                                               kGradW(d, P->radius)),
                                         len3(cgv[i])),
-                                  fmaxf(ORACLE_EPS, len3(cgv[i]))));
+                                  max_eps(len3(cgv[i]))));
             }
         SWEEP_END
         s->tmp3[i] = add3(s->vel[i], mul3s(a, P->dt));   /* no neighbour reads vel here */
@@ -342,12 +350,12 @@ static void k_pressure_force(oracle_sys *s)
             for (int j = s->csF[cid]; j < s->csF[cid + 1]; ++j) {
                 if (i == j) continue;
                 const float dj = s->density[j];
-                a = add3(a, smul3(-s->mass[j] * (pri / fmaxf(ORACLE_EPS, di * di)
-                                                 + s->pressure[j] / fmaxf(ORACLE_EPS, dj * dj)),
+                a = add3(a, smul3(-s->mass[j] * (pri / max_eps(di * di)
+                                                 + s->pressure[j] / max_eps(dj * dj)),
                                   kGradW(sub3(pi, s->pos[j]), P->radius)));
             }
             for (int j = s->csB[cid]; j < s->csB[cid + 1]; ++j)
-                a = add3(a, smul3(-s->bmass[j] * (pri / fmaxf(ORACLE_EPS, di * di)),
+                a = add3(a, smul3(-s->bmass[j] * (pri / max_eps(di * di)),
                                   kGradW(sub3(pi, s->bpos[j]), P->radius)));
         SWEEP_END
         if (len3(a) > ORACLE_MAX_A)   /* normalize(a) = a * (1/sqrt(dot)) (helper_math, IEEE) */
@@ -367,12 +375,12 @@ static void k_advect(oracle_sys *s)
         const float lx = P->space[0] * .00f, hx = P->space[0] * .99f;
         const float ly = P->space[1] * .00f, hy = P->space[1] * .99f;
         const float lz = P->space[2] * .00f, hz = P->space[2] * .99f;
-        if (p.x <= lx) { p.x = lx; v.x = fmaxf(v.x, 0.0f); }
-        if (p.x >= hx) { p.x = hx; v.x = fminf(v.x, 0.0f); }
-        if (p.y <= ly) { p.y = ly; v.y = fmaxf(v.y, 0.0f); }
-        if (p.y >= hy) { p.y = hy; v.y = fminf(v.y, 0.0f); }
-        if (p.z <= lz) { p.z = lz; v.z = fmaxf(v.z, 0.0f); }
-        if (p.z >= hz) { p.z = hz; v.z = fminf(v.z, 0.0f); }
+        if (p.x <= lx) { p.x = lx; v.x = max0(v.x); }
+        if (p.x >= hx) { p.x = hx; v.x = min0(v.x); }
+        if (p.y <= ly) { p.y = ly; v.y = max0(v.y); }
+        if (p.y >= hy) { p.y = hy; v.y = min0(v.y); }
+        if (p.z <= lz) { p.z = lz; v.z = max0(v.z); }
+        if (p.z >= hz) { p.z = hz; v.z = min0(v.z); }
         s->pos[i] = p; s->vel[i] = v;
     }
 }
@@ -413,7 +421,7 @@ static void k_density_alpha(oracle_sys *s)
             }
         SWEEP_END
         s->density[i] = den;
-        s->alpha[i] = -1.0f / fmaxf(ORACLE_EPS, dot3(gs, gs) + sl);
+        s->alpha[i] = -1.0f / max_eps(dot3(gs, gs) + sl);
     }
 }
 /* shared body of computeDivergenceError_CUDA (DFSPHSolver.cu:261-306) and
@@ -436,7 +444,7 @@ static void k_divergence_error(oracle_sys *s)
     const oracle_params *P = &s->P;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < s->n; ++i) {
-        float err = fmaxf(0.0f, rate_sum(s, i));
+        float err = max0(rate_sum(s, i));
         if (s->density[i] + P->dt * err < P->rho0 && s->density[i] <= P->rho0) err = 0.0f;
         s->error[i] = err;
         s->kappa[i] = err * s->alpha[i];
@@ -447,7 +455,7 @@ static void k_density_error(oracle_sys *s)
     const oracle_params *P = &s->P;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < s->n; ++i) {
-        const float err = fmaxf(0.0f, P->dt * rate_sum(s, i) + s->density[i] - P->rho0);
+        const float err = max0(P->dt * rate_sum(s, i) + s->density[i] - P->rho0);
         s->error[i] = err;
         s->kappa[i] = err * s->alpha[i];
     }

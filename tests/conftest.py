@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def sphx():
+    import sphx as mod
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as mod
+    mod.lib()
+    return mod
+
+
+def same_params(dst, src):
+    """copy every field of a Params-like ctypes struct into another (oracle <-> sphx)."""
+    for name, _ in src._fields_:
+        setattr(dst, name, getattr(src, name))
+    return dst
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_bit_equal(got, want, what):
+    got = np.ascontiguousarray(got); want = np.ascontiguousarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    gb, wb = bits(got), bits(want)
+    if not np.array_equal(gb, wb):
+        bad = np.flatnonzero(gb.reshape(-1) != wb.reshape(-1))
+        i = bad[0]
+        raise AssertionError("%s: %d of %d elements differ bitwise; first at flat %d: got %r want %r" % (
+            what, bad.size, gb.size, i, got.reshape(-1)[i], want.reshape(-1)[i]))
