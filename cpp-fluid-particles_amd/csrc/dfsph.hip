@@ -38,8 +38,8 @@ void launch_rate(const OpRate& op, int n, bool reduce)
 {
     if (n <= 0) return;
     OpRate o = op;
-    if (!reduce) o.accum = nullptr;
-    else HIP_CALL(hipMemsetAsync(o.accum, 0, sizeof(unsigned long long), sphx::stream()));
+    if (!reduce) o.out.accum = nullptr;
+    else HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long), sphx::stream()));
     k_rate<DENSITY_MODE, WARM><<<blocks_for(n), 256, 0, sphx::stream()>>>(o, n);
 }
 }  // namespace
@@ -53,13 +53,16 @@ void DFSPHSolver::computeDensityAlpha(std::shared_ptr<SPHParticles>& fluids, con
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const int num = (int)fluids->size();
+    if (num <= 0) return;
     ScopedKernel t("density_alpha");
-    OpDensityAlpha op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                      fluids->getDensityPtr(), alpha.addr()};
-    launch_op(op, (int)fluids->size());
+    OpDfsphHead op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{}};
+    k_dfsph_head<false><<<blocks_for(num), 256, 0, sphx::stream()>>>(op, num);
 }
 
-// correctDivergenceError, DFSPHSolver.cu:331-363
+// correctDivergenceError, DFSPHSolver.cu:331-363.  `firstErrorDone`: the fused head sweep has
+// already produced error/stiffness for the current velocities (DFSPHSolver.cu:341).
 int DFSPHSolver::correctDivergenceError(std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
                                         const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float rho0,
                                         int3 cellSize, float cellLength, float radius, float dt, float errorThreshold,
@@ -69,19 +72,21 @@ int DFSPHSolver::correctDivergenceError(std::shared_ptr<SPHParticles>& fluids, c
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     const int num = (int)fluids->size();
     const bool adaptive = fixedDiv < 0;
     auto totalError = std::numeric_limits<float>::max();
     auto iter = 0;
-    const OpRate rate{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                      fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(), error.addr(), bufferFloat.addr(),
-                      nullptr, reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0};
-    const OpCorrect<false> correct{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                                   bufferFloat.addr(), fluids->getVelPtr(), dt};
-    {
+    const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                      RateOut{error.addr(), bufferFloat.addr(), nullptr,
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0}};
+    const OpCorrect<false> correct{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt};
+    if (!headDidFirstError) {
         ScopedKernel t("divergence_error");
         launch_rate<false, 0>(rate, num, false);
     }
+    headDidFirstError = false;
     while (adaptive ? ((iter < 1 || totalError > errorThreshold * num * rho0) && iter < maxIterations) : (iter < fixedDiv)) {
         {
             ScopedKernel t("divergence_correct");
@@ -106,6 +111,8 @@ int DFSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::share
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     const int num = (int)fluids->size();
     const bool adaptive = fixedDen < 0;
     auto totalError = std::numeric_limits<float>::max();
@@ -116,11 +123,10 @@ int DFSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::share
         ew_gather_float(scratch.addr(), denWarmStiff.addr(), fluids->getSortPerm(), num);
         ew_copy(denWarmStiff.addr(), scratch.addr(), sizeof(float) * num);
     }
-    const OpRate rate{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                      fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(), error.addr(), bufferFloat.addr(),
-                      denWarmStiff.addr(), reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0};
-    OpCorrect<true> correct{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                            denWarmStiff.addr(), fluids->getVelPtr(), dt};
+    const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                      RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(),
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0}};
+    OpCorrect<true> correct{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt};
     {
         ScopedKernel t("density_correct");   // warm start
         launch_op(correct, num);
@@ -154,14 +160,55 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
 {
     (void)stiff;
     invalidatePositions();
-    computeDensityAlpha(fluids, boundaries, cellStartFluid, cellStartBoundary, cellSize, cellLength, radius);
+    SweepCache& c = cache();
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
+    const int num = (int)fluids->size();
+    if (!c.fused()) {
+        computeDensityAlpha(fluids, boundaries, cellStartFluid, cellStartBoundary, cellSize, cellLength, radius);
+        lastDiv = correctDivergenceError(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength,
+                                         radius, dt, divergenceErrorThreshold, maxIter);
+        force(fluids, dt, G);
+        BasicSPHSolver::diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
+        if (surface)
+            handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius,
+                          dt, surfaceTensionIntensity, airPressure);
+        lastDen = project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength, radius, dt,
+                          densityErrorThreshold, maxIter);
+        advect(fluids, dt, spaceSize);
+        return;
+    }
+    // fused schedule: [density+alpha+first divergence error] -> divergence loop -> gravity ->
+    // [viscosity+colour gradient] -> [surface (+ vel += deltaV)] -> density solve -> advect
+    c.setup(cellSize, cellLength, radius);
+    c.packFluid(*fluids);
+    c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+    if (num > 0) {
+        ScopedKernel t("density_alpha_diverr");
+        OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                       RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0}};
+        k_dfsph_head<true><<<blocks_for(num), 256, 0, sphx::stream()>>>(op, num);
+    }
+    headDidFirstError = true;
     lastDiv = correctDivergenceError(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength,
                                      radius, dt, divergenceErrorThreshold, maxIter);
     force(fluids, dt, G);
-    BasicSPHSolver::diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
-    if (surfaceTensionIntensity > EPSILON || airPressure > EPSILON)
-        handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius, dt,
-                      surfaceTensionIntensity, airPressure);
+    DArray<float3>& cg = colorGradientBuffer();
+    if (surface) {
+        {
+            ScopedKernel t("visc_color");
+            OpFluidProps<true, true, false> op{ctx, fluids->getVelPtr(), c.aux3.addr(), cg.addr(), nullptr, nullptr, nullptr,
+                                               rho0, rhoB, visc, dt, 0.0f};
+            launch_op(op, num);
+        }
+        ScopedKernel t("surface_tension");
+        OpSurface op{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0, surfaceTensionIntensity,
+                     airPressure, dt};
+        launch_op(op, num);
+    } else {
+        BasicSPHSolver::diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
+    }
     lastDen = project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength, radius, dt,
                       densityErrorThreshold, maxIter);
     advect(fluids, dt, spaceSize);

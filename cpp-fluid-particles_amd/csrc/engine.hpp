@@ -18,18 +18,30 @@ namespace sphx {
 KernelConsts make_kernel_consts(float radius);
 GridDesc make_grid_desc(int3 cellSize, float cellLength);
 
-// Per-solver packed views of the particle sets, refreshed when positions move.
-//   posm / bposm : float4 (x, y, z, mass) in cell-sorted order, one 16-byte load per candidate
+// Per-solver packed views of the particle sets and the per-step neighbour list, refreshed when
+// positions move.
+//   posm / bposm : float4 (x, y, z, mass) in cell-sorted order, one 16-byte load per neighbour
 //   pterm        : p_j / max(EPS, rho_j^2), the per-particle half of the pressure-force weight
+//   nbr/nbrCount : wave-interleaved compact neighbour rows (sph_device.hpp), `cap` entries/particle
+//   aux3         : second float3 scratch (viscosity delta-v while bufferFloat3 holds the colour
+//                  gradient in the fused sweeps)
+enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2 };
+
 struct SweepCache {
     explicit SweepCache(int num);
     int n;
     DArray<float> posm;                      // 4 floats per fluid particle
     DArray<float> pterm;
+    DArray<float3> aux3;
+    DArray<int> nbrCount;
+    std::unique_ptr<DArray<int>> nbr;        // allocated on first use
     std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
     int nb = 0;
+    int cap = 96;
+    int flags = 0;
     bool fluidValid = false;
     bool boundaryValid = false;
+    bool listValid = false;
     const void* boundaryKey = nullptr;       // boundary pos pointer the packed copy was made from
     KernelConsts k{};
     GridDesc g{};
@@ -38,7 +50,14 @@ struct SweepCache {
 
     void setup(int3 cellSize, float cellLength, float radius);
     void packFluid(const SPHParticles& fluids);
+    // pack and apply the gravity kick vel += dv in one pass (only valid right after a re-sort)
+    void packFluidKick(const SPHParticles& fluids, float3 dv);
     void packBoundary(const SPHParticles& boundaries);
+    void invalidatePositions() { fluidValid = false; listValid = false; }
+    // build the neighbour rows for the current positions (no-op when valid or disabled)
+    void ensureList(const DArray<int>& csF, const DArray<int>& csB);
+    SweepCtx ctx(const DArray<int>& csF, const DArray<int>& csB) const;
+    bool fused() const { return (flags & kFlagUnfused) == 0; }
     const float4* fluid4() const { return reinterpret_cast<const float4*>(posm.addr()); }
     float4* fluid4w() { return reinterpret_cast<float4*>(posm.addr()); }
     const float4* boundary4() const { return reinterpret_cast<const float4*>(bposm->addr()); }

@@ -52,12 +52,14 @@ void PBDSolver::diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray<int>
     c.packFluid(*fluids);
     const int num = (int)fluids->size();
     ScopedKernel t("xsph");
-    OpXsph op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), fluids->getVelPtr(), bufferFloat3.addr(), visc, rho0};
+    OpXsph<false> op{c.ctx(cellStartFluid, cellStartFluid), fluids->getVelPtr(), bufferFloat3.addr(), nullptr, visc, rho0, 0.0f};
     launch_op(op, num);
     ew_copy(fluids->getVelPtr(), bufferFloat3.addr(), sizeof(float3) * num);
 }
 
-// PBDSolver::project, PBDSolver.cu:225-258
+// PBDSolver::project, PBDSolver.cu:225-258.  Positions move every iteration while the cell table
+// stays fixed, so the neighbour rows are rebuilt per iteration (shared by the
+// lambda and delta-p sweeps of that iteration).
 int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
                        const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float rho0, int3 cellSize,
                        float3 spaceSize, float cellLength, float radius, int maxIterations)
@@ -67,17 +69,24 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
     const int num = (int)fluids->size();
-    const OpLambda lam{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                       fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation};
-    const OpDeltaPos dp{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                        bufferFloat.addr(), bufferFloat3.addr(), rho0};
     auto iter = 0;
     while (iter < maxIterations) {
-        { ScopedKernel t("pbd_lambda"); launch_op(lam, num); }
-        { ScopedKernel t("pbd_delta_pos"); launch_op(dp, num); }
+        c.ensureList(cellStartFluid, cellStartBoundary);
+        const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+        {
+            ScopedKernel t("pbd_lambda");
+            OpLambda lam{ctx, fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation};
+            launch_op(lam, num);
+        }
+        {
+            ScopedKernel t("pbd_delta_pos");
+            OpDeltaPos dp{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0};
+            launch_op(dp, num);
+        }
         {
             ScopedKernel t("pbd_apply_clamp");   // keeps the packed position view in step with pos
             launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), bufferFloat3.addr(), spaceSize, num);
+            c.listValid = false;
         }
         ++iter;
     }
@@ -103,17 +112,49 @@ void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_pt
         throw "PBD: The last position of fluids is initialized.";
     }
     invalidatePositions();
+    SweepCache& c = cache();
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
+    const int num = (int)fluids->size();
     updateNeighborhood(fluids);
     project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, spaceSize, cellLength, radius, maxIter);
     {
         ScopedKernel t("pbd_velocity");
-        launch_velocity_from_displacement(fluids->getVelPtr(), fluids->getPosPtr(), fluidPosLast.addr(), dt,
-                                          (int)fluids->size());
+        launch_velocity_from_displacement(fluids->getVelPtr(), fluids->getPosPtr(), fluidPosLast.addr(), dt, num);
     }
-    diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, xSPH_c);
-    if (surfaceTensionIntensity > EPSILON || airPressure > EPSILON)
-        handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius, dt,
-                      surfaceTensionIntensity, airPressure);
-    force(fluids, dt, G);
-    predict(fluids, dt, spaceSize);
+    if (!c.fused()) {
+        diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, xSPH_c);
+        if (surface)
+            handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius,
+                          dt, surfaceTensionIntensity, airPressure);
+        force(fluids, dt, G);
+        predict(fluids, dt, spaceSize);
+        return;
+    }
+    // fused tail: [XSPH + colour gradient] -> [surface, reading the XSPH result] -> one pass for
+    // gravity + remember positions + advect + clamp
+    c.setup(cellSize, cellLength, radius);
+    c.packFluid(*fluids);
+    c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+    DArray<float3>& cg = colorGradientBuffer();
+    if (surface) {
+        {
+            ScopedKernel t("xsph_color");
+            OpXsph<true> op{ctx, fluids->getVelPtr(), bufferFloat3.addr(), cg.addr(), xSPH_c, rho0, rhoB};
+            launch_op(op, num);
+        }
+        ScopedKernel t("surface_tension");
+        OpSurface op{ctx, cg.addr(), bufferFloat3.addr(), nullptr, fluids->getVelPtr(), rho0, surfaceTensionIntensity,
+                     airPressure, dt};
+        launch_op(op, num);
+    } else {
+        diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, xSPH_c);
+    }
+    {
+        ScopedKernel t("kick_remember_advect");
+        launch_kick_remember_advect(fluids->getPosPtr(), fluids->getVelPtr(), fluidPosLast.addr(),
+                                    make_float3(dt * G.x, dt * G.y, dt * G.z), dt, spaceSize, num);
+        invalidatePositions();
+    }
 }

@@ -1,6 +1,7 @@
 // runtime.hip — engine stream, error reporting, kernel constants, packed views, element-wise
 // helpers and the optional per-kernel timer.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -141,7 +142,27 @@ void ew_iota(int* dst, int n)
 }
 
 // ------------------------------------------------------------------------------ SweepCache
-SweepCache::SweepCache(int num) : n(num), posm(4u * (unsigned)num), pterm((unsigned)num) {}
+__global__ void k_pack_kick_rt(float4* __restrict__ posm, const float3* __restrict__ pos, const float* __restrict__ mass,
+                               float3* __restrict__ vel, float3 dv, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 p = pos[i];
+    posm[i] = make_float4(p.x, p.y, p.z, mass[i]);
+    vel[i] = add3(vel[i], dv);
+}
+__global__ void __launch_bounds__(256) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) build_neighbor_row(c, nbr, nbrCount, i);
+}
+
+SweepCache::SweepCache(int num)
+    : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), nbrCount((unsigned)num)
+{
+    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
+    if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
+}
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
 {
@@ -156,8 +177,18 @@ void SweepCache::packFluid(const SPHParticles& fluids)
 {
     if (fluidValid) return;
     ScopedKernel t("pack_fluid");
-    k_pack4<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), n);
+    if (n > 0) k_pack4<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), n);
     fluidValid = true;
+    listValid = false;
+}
+
+void SweepCache::packFluidKick(const SPHParticles& fluids, float3 dv)
+{
+    ScopedKernel t("pack_kick");
+    if (n > 0)
+        k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), dv, n);
+    fluidValid = true;
+    listValid = false;
 }
 
 void SweepCache::packBoundary(const SPHParticles& boundaries)
@@ -172,6 +203,33 @@ void SweepCache::packBoundary(const SPHParticles& boundaries)
                                                           boundaries.getMassPtr(), count);
     boundaryKey = (const void*)boundaries.getPosPtr();
     boundaryValid = true;
+    listValid = false;
+}
+
+SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
+{
+    SweepCtx c;
+    c.g = g; c.k = k;
+    c.csF = csF.addr(); c.posm = fluid4();
+    c.csB = csB.addr(); c.bposm = bposm ? boundary4() : nullptr;
+    const bool use = listValid && nbr && !(flags & kFlagNoList);
+    c.nbr = use ? reinterpret_cast<const unsigned int*>(nbr->addr()) : nullptr;
+    c.nbrCount = nbrCount.addr();
+    c.cap = cap;
+    return c;
+}
+
+void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
+{
+    if (listValid || (flags & kFlagNoList) || n <= 0) return;
+    const unsigned long long entries = (unsigned long long)((n + 63) / 64) * 64ull * (unsigned long long)cap;
+    if (entries > 0xfffffff0ull) { flags |= kFlagNoList; return; }   // beyond DArray's 32-bit length
+    if (!nbr) nbr.reset(new DArray<int>((unsigned)entries));
+    SweepCtx c = ctx(csF, csB);
+    c.nbr = nullptr;
+    ScopedKernel t("build_neighbor_list");
+    k_build_list<<<blocks_for(n), 256, 0, stream()>>>(c, reinterpret_cast<unsigned int*>(nbr->addr()), nbrCount.addr(), n);
+    listValid = true;
 }
 
 // ------------------------------------------------------------------------------ KernelTimer
@@ -179,15 +237,21 @@ bool KernelTimer::enabled = false;
 namespace {
 struct TimedSpan { std::string name; hipEvent_t a, b; };
 std::vector<TimedSpan> g_spans;
+std::vector<size_t> g_open;      // indices of spans begun but not ended (scopes may nest)
 }
 void KernelTimer::begin(const char* name)
 {
     TimedSpan s; s.name = name;
     HIP_CALL(hipEventCreate(&s.a)); HIP_CALL(hipEventCreate(&s.b));
     HIP_CALL(hipEventRecord(s.a, stream()));
+    g_open.push_back(g_spans.size());
     g_spans.push_back(s);
 }
-void KernelTimer::end() { HIP_CALL(hipEventRecord(g_spans.back().b, stream())); }
+void KernelTimer::end()
+{
+    HIP_CALL(hipEventRecord(g_spans[g_open.back()].b, stream()));
+    g_open.pop_back();
+}
 void KernelTimer::collect(std::vector<std::string>& names, std::vector<float>& ms)
 {
     HIP_CALL(hipStreamSynchronize(stream()));
@@ -201,6 +265,7 @@ void KernelTimer::reset()
 {
     for (auto& s : g_spans) { HIP_CALL(hipEventDestroy(s.a)); HIP_CALL(hipEventDestroy(s.b)); }
     g_spans.clear();
+    g_open.clear();
 }
 
 }  // namespace sphx

@@ -159,6 +159,132 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
     }
 }
 
+// ---- per-step compact neighbour list ---------------------------------------------------------------
+// While positions are frozen (all sweeps of a WCSPH/DFSPH step; the two sweeps of one PBD
+// iteration) every sweep of particle i meets the same candidates and rejects the same ones, and a
+// rejected candidate contributes exactly +0.  The first pass therefore records, per particle, the
+// candidates with r2 <= tCut IN VISIT ORDER (self excluded: its terms are exactly zero); later
+// sweeps walk that list.  Order is preserved, so every accumulated bit is.
+//
+// Layout: wave-interleaved rows — entry k of particle i lives at ((i>>6)*cap + k)*64 + (i&63), so
+// the 64 lanes of a wave read 256 contiguous bytes per k.  Bit 31 marks a boundary particle.
+// count > cap means the list overflowed: that lane falls back to the direct 27-cell walk.
+struct SweepCtx {
+    GridDesc g; KernelConsts k;
+    const int* csF; const float4* posm;     // fluid cell starts, packed (x,y,z,mass)
+    const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass)
+    const unsigned int* nbr; const int* nbrCount; int cap;   // nbr == nullptr: direct sweeps only
+};
+constexpr unsigned int kBoundaryBit = 0x80000000u;
+
+// direct walk in reference order, Body::pair(idx, isBoundary, d, r2, mass_j)
+template <bool WANT_BOUNDARY, class Body>
+__device__ __forceinline__ void sweep_direct(const SweepCtx& c, const float3 pi, Body& body)
+{
+    const int3 c0 = cell_of(pi, c.g.cellLength);
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int X = c0.x + dx;
+        if (X < 0 || X >= c.g.gx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int Y = c0.y + dy;
+            if (Y < 0 || Y >= c.g.gy) continue;
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int Z = c0.z + dz;
+                if (Z < 0 || Z >= c.g.gz) continue;
+                const int cell = (X * c.g.gy + Y) * c.g.gz + Z;
+                {
+                    const int e = c.csF[cell + 1];
+                    for (int j = c.csF[cell]; j < e; ++j) {
+                        const float4 pj = c.posm[j];
+                        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                        const float r2 = dot3(d, d);
+                        if (r2 > c.k.tCut) continue;
+                        body.pair(j, false, d, r2, pj.w);
+                    }
+                }
+                if (WANT_BOUNDARY) {
+                    const int e = c.csB[cell + 1];
+                    for (int j = c.csB[cell]; j < e; ++j) {
+                        const float4 pj = c.bposm[j];
+                        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                        const float r2 = dot3(d, d);
+                        if (r2 > c.k.tCut) continue;
+                        body.pair(j, true, d, r2, pj.w);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool WANT_BOUNDARY, class Body>
+__device__ __forceinline__ void sweep(const SweepCtx& c, const int i, const float3 pi, Body& body)
+{
+    if (c.nbr) {
+        const int cnt = c.nbrCount[i];
+        if (cnt <= c.cap) {
+            const unsigned int* row = c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
+            for (int t = 0; t < cnt; ++t) {
+                const unsigned int e = row[(size_t)t * 64u];
+                const bool isB = (e & kBoundaryBit) != 0u;
+                if (!WANT_BOUNDARY && isB) continue;
+                const int idx = (int)(e & ~kBoundaryBit);
+                const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
+                const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                body.pair(idx, isB, d, dot3(d, d), pj.w);
+            }
+            return;
+        }
+    }
+    sweep_direct<WANT_BOUNDARY>(c, pi, body);
+}
+
+// list construction: same walk; z-adjacent cells are contiguous in memory (z is the fastest cell
+// axis), so when the three cells of a (dx,dy) column hold no boundary particles the fluid ranges
+// are visited as one run (identical order).
+__device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, unsigned int* nbr, int* nbrCount, const int i)
+{
+    const float4 self = c.posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    unsigned int* row = nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
+    int cnt = 0;
+    const int3 c0 = cell_of(pi, c.g.cellLength);
+    const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int X = c0.x + dx;
+        if (X < 0 || X >= c.g.gx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int Y = c0.y + dy;
+            if (Y < 0 || Y >= c.g.gy || zlo > zhi) continue;
+            const int base = (X * c.g.gy + Y) * c.g.gz;
+            const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
+            const int step = noWall ? (zhi - zlo + 1) : 1;
+            for (int z = zlo; z <= zhi; z += step) {
+                const int cell = base + z;
+                const int e = c.csF[cell + step];
+                for (int j = c.csF[cell]; j < e; ++j) {
+                    const float4 pj = c.posm[j];
+                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                    if (dot3(d, d) > c.k.tCut || j == i) continue;
+                    if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)j;
+                    ++cnt;
+                }
+                if (!noWall) {
+                    const int eb = c.csB[cell + 1];
+                    for (int j = c.csB[cell]; j < eb; ++j) {
+                        const float4 pj = c.bposm[j];
+                        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                        if (dot3(d, d) > c.k.tCut) continue;
+                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)j | kBoundaryBit;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    nbrCount[i] = cnt;
+}
+
 __device__ __forceinline__ float3 ld3(const float3* __restrict__ p, int i) { return p[i]; }
 __device__ __forceinline__ float3 xyz(const float4 v) { return v3(v.x, v.y, v.z); }
 

@@ -1,10 +1,14 @@
 // sweep_ops.hpp — the per-particle neighbour-sweep operators of all three solvers, plus the small
 // element-wise passes, as device functors launched one lane per fluid particle.
 //
-// Each operator cites the reference kernel whose arithmetic it restates (association order kept,
-// see sph_device.hpp).  Quantities that depend only on particle i are hoisted out of the pair loop
-// and quantities that depend only on particle j are read from per-particle arrays (e.g. `pterm`);
-// both are pure-function hoists and change no bit.
+// Each operator cites the reference kernel(s) whose arithmetic it restates (association order kept,
+// see sph_device.hpp).  Three kinds of rewrites are used, none of which changes a bit:
+//   * hoisting: sub-expressions depending only on particle i leave the pair loop; sub-expressions
+//     depending only on particle j are read from per-particle arrays (`pterm`);
+//   * fusion: sweeps that read the same frozen inputs run as one walk with independent
+//     accumulators (template flags select the reference's unfused building blocks);
+//   * boundary neighbours go through the fluid formula with the absent field set to +0
+//     (x - 0 == x, x + 0 == x), which is what the reference's separate boundary helpers compute.
 #pragma once
 
 #include "engine.hpp"
@@ -23,126 +27,114 @@ inline void launch_op(const Op& op, int n)
     if (n > 0) k_run_op<Op><<<blocks_for(n), 256, 0, stream()>>>(op, n);
 }
 
-// =================================================================================== WCSPH
-// viscosity_CUDA, BasicSPHSolver.cu:183-209
-struct OpViscosity {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const float3* vel; float3* deltaV;
-    float rho0, visc, dt;
+// wave-level sum of the fixed-point |error| terms, one atomic per wave
+__device__ __forceinline__ void accumulate_error(long long fixed, unsigned long long* accum)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fixed += __shfl_down(fixed, off, 64);
+    if ((threadIdx.x & 63) == 0 && fixed != 0) atomicAdd(accum, (unsigned long long)fixed);
+}
+
+// neighbour-list construction (sph_device.hpp::build_neighbor_row)
+struct OpBuildList {
+    SweepCtx c; unsigned int* nbr; int* nbrCount;
+    __device__ void operator()(int i) const { build_neighbor_row(c, nbr, nbrCount, i); }
+};
+
+// =================================================================================== shared sweeps
+// Per-particle properties that depend on positions (and the current velocities) only:
+//   VISC    viscosity_CUDA, BasicSPHSolver.cu:183-209            -> deltaV
+//   COLOR   computeColorGrad_CUDA, BasicSPHSolver.cu:277-318     -> colorGrad
+//   DENS    computeDensity_CUDA + computePressure_CUDA, :32-83, :103-111 -> density, pressure, pterm
+template <bool VISC, bool COLOR, bool DENS>
+struct OpFluidProps {
+    SweepCtx c;
+    const float3* vel; float3* deltaV; float3* colorGrad;
+    float* density; float* pressure; float* pterm;
+    float rho0, rhoB, visc, dt, stiff;
     struct Body {
-        const OpViscosity& o; float3 vi; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3, float r2, float mj)
+        const OpFluidProps& o; float3 vi; float3 a; float3 cg; float cden; float den;
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            a = add3(a, mul3s(smul3(mj, div3s(sub3(o.vel[j], vi), o.rho0)), kViscLap(sqrtf(r2), o.k)));
+            const float r = sqrtf(r2);
+            if (VISC && !isB)
+                a = add3(a, mul3s(smul3(mj, div3s(sub3(o.vel[idx], vi), o.rho0)), kViscLap(r, o.c.k)));
+            if (COLOR || DENS) {
+                const float q = q_of(r, o.c.k);
+                const float w = kW(q, o.c.k);
+                if (DENS) den += mj * w;
+                if (COLOR) {
+                    const float vol = mj / (isB ? o.rhoB : o.rho0);
+                    cg = add3(cg, smul3(vol, kGradW(d, q, o.c.k)));
+                    cden += vol * w;
+                }
+            }
         }
-        __device__ __forceinline__ void boundary(int, float3, float, float) {}
     };
     __device__ void operator()(int i) const
     {
-        Body b{*this, vel[i], v3(0, 0, 0)};
-        sweep27<true, false>(g, k, csF, posm, nullptr, nullptr, xyz(posm[i]), b);
-        deltaV[i] = mul3s(smul3(visc, b.a), dt);
-    }
-};
-
-// computeColorGrad_CUDA, BasicSPHSolver.cu:277-318
-struct OpColorGrad {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
-    float3* colorGrad;
-    float rho0, rhoB;
-    struct Body {
-        const OpColorGrad& o; float3 cg; float den;
-        __device__ __forceinline__ void term(float vol, float3 d, float r2)
-        {
-            const float q = q_of(sqrtf(r2), o.k);
-            cg = add3(cg, smul3(vol, kGradW(d, q, o.k)));
-            den += vol * kW(q, o.k);
+        Body b{*this, VISC ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f};
+        sweep<COLOR || DENS>(c, i, xyz(c.posm[i]), b);
+        if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
+        if (COLOR) colorGrad[i] = div3s(b.cg, max_eps(b.cden));
+        if (DENS) {
+            density[i] = b.den;
+            float p = stiff * (pow7(b.den / rho0) - 1.0f);
+            if (p < 0.0f) p = 0.0f;
+            pressure[i] = p;
+            pterm[i] = p / max_eps(b.den * b.den);
         }
-        __device__ __forceinline__ void fluid(int, float3 d, float r2, float mj) { term(mj / o.rho0, d, r2); }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj) { term(mj / o.rhoB, d, r2); }
-    };
-    __device__ void operator()(int i) const
-    {
-        Body b{*this, v3(0, 0, 0), 0.0f};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
-        colorGrad[i] = div3s(b.cg, max_eps(b.den));
     }
 };
 
-// surfaceTensionAndAirPressure_CUDA, BasicSPHSolver.cu:332-370
+// surfaceTensionAndAirPressure_CUDA, BasicSPHSolver.cu:332-370.  `velIn` is the velocity the
+// reference kernel would read for particle i (it only reads its own); when `addend` is given the
+// pending element-wise update vel += addend (BasicSPHSolver.cu:219-224) is applied first.
 struct OpSurface {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const float3* colorGrad; float3* vel;
+    SweepCtx c;
+    const float3* colorGrad; const float3* velIn; const float3* addend; float3* velOut;
     float rho0, tension, airPressure, dt;
     struct Body {
         const OpSurface& o; float dii, li, ml; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int idx, bool, float3 d, float r2, float mj)
         {
             const float r = sqrtf(r2);
-            const float q = q_of(r, o.k);
-            const float3 cgj = o.colorGrad[j];
-            a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad(d, r, o.k)));
-            a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW(d, q, o.k)), li), ml));
+            const float q = q_of(r, o.c.k);
+            const float3 cgj = o.colorGrad[idx];
+            a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad(d, r, o.c.k)));
+            a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW(d, q, o.c.k)), li), ml));
         }
-        __device__ __forceinline__ void boundary(int, float3, float, float) {}
     };
     __device__ void operator()(int i) const
     {
         const float3 cgi = colorGrad[i];
         const float li = len3(cgi);
         Body b{*this, dot3(cgi, cgi), li, max_eps(li), v3(0, 0, 0)};
-        sweep27<true, false>(g, k, csF, posm, nullptr, nullptr, xyz(posm[i]), b);
-        vel[i] = add3(vel[i], mul3s(b.a, dt));
-    }
-};
-
-// computeDensity_CUDA + computePressure_CUDA, BasicSPHSolver.cu:32-83, :103-111 (EOS fused into the
-// epilogue; also emits pterm = p / max(EPS, rho^2) for the pressure-force sweep)
-struct OpDensityPressure {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
-    float* density; float* pressure; float* pterm;
-    float rho0, stiff;
-    struct Body {
-        const OpDensityPressure& o; float den;
-        __device__ __forceinline__ void fluid(int, float3, float r2, float mj) { den += mj * kW(q_of(sqrtf(r2), o.k), o.k); }
-        __device__ __forceinline__ void boundary(int, float3, float r2, float mj) { den += mj * kW(q_of(sqrtf(r2), o.k), o.k); }
-    };
-    __device__ void operator()(int i) const
-    {
-        Body b{*this, 0.0f};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
-        density[i] = b.den;
-        float p = stiff * (pow7(b.den / rho0) - 1.0f);
-        if (p < 0.0f) p = 0.0f;
-        pressure[i] = p;
-        pterm[i] = p / max_eps(b.den * b.den);
+        sweep<false>(c, i, xyz(c.posm[i]), b);
+        float3 v = velIn[i];
+        if (addend) v = add3(v, addend[i]);
+        velOut[i] = add3(v, mul3s(b.a, dt));
     }
 };
 
 // pressureForce_CUDA, BasicSPHSolver.cu:113-165
 struct OpPressureForce {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
+    SweepCtx c;
     const float* pterm; float3* vel;
     float dt;
     struct Body {
         const OpPressureForce& o; int i; float pti; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            if (j == i) return;
-            a = add3(a, smul3(-mj * (pti + o.pterm[j]), kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
-        }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj)
-        {
-            a = add3(a, smul3(-mj * pti, kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
+            if (!isB && idx == i) return;
+            const float ptj = isB ? 0.0f : o.pterm[idx];
+            a = add3(a, smul3(-mj * (pti + ptj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
     __device__ void operator()(int i) const
     {
         Body b{*this, i, pterm[i], v3(0, 0, 0)};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
+        sweep<true>(c, i, xyz(c.posm[i]), b);
         float3 a = b.a;
         if (len3(a) > kMaxA) a = mul3s(mul3s(a, 1.0f / sqrtf(dot3(a, a))), kMaxA);
         vel[i] = add3(vel[i], mul3s(a, dt));
@@ -150,57 +142,82 @@ struct OpPressureForce {
 };
 
 // =================================================================================== DFSPH
-// computeDensityAlpha_CUDA, DFSPHSolver.cu:212-249
-struct OpDensityAlpha {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
-    float* density; float* alpha;
+// divergence / density error epilogue shared by the fused head and the stand-alone rate sweep:
+// computeDivergenceError_CUDA (DFSPHSolver.cu:296-304) and computeDensityError_CUDA (:111-114),
+// with the warm-stiffness bookkeeping of DFSPHSolver.cu:185,199-203 (WARM 0 none, 1 set, 2 add).
+struct RateOut {
+    float* error; float* kappa; float* warm; unsigned long long* accum;
+    float dt, rho0;
+};
+template <bool DENSITY_MODE, int WARM>
+__device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float e, float den, float alpha)
+{
+    float err;
+    if (DENSITY_MODE) {
+        err = max0(r.dt * e + den - r.rho0);
+    } else {
+        err = max0(e);
+        if (den + r.dt * err < r.rho0 && den <= r.rho0) err = 0.0f;
+    }
+    const float kap = err * alpha;
+    r.error[i] = err;
+    r.kappa[i] = kap;
+    if (WARM == 1) r.warm[i] = kap;
+    if (WARM == 2) r.warm[i] = r.warm[i] + kap;
+    return error_fixed(err);
+}
+
+// computeDensityAlpha_CUDA (DFSPHSolver.cu:212-249), optionally fused with the first
+// computeDivergenceError_CUDA (:261-306), whose inputs (density_i, alpha_i) are this lane's own.
+struct OpDfsphHead {
+    SweepCtx c;
+    const float3* vel; float* density; float* alpha;
+    RateOut out;
     struct Body {
-        const OpDensityAlpha& o; float den, sl; float3 gs;
-        __device__ __forceinline__ void fluid(int, float3 d, float r2, float mj)
+        const OpDfsphHead& o; float3 vi; float den, sl, e; float3 gs;
+        bool withRate;
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            const float q = q_of(sqrtf(r2), o.k);
-            den += mj * kW(q, o.k);
-            const float3 gr = smul3(mj, kGradW(d, q, o.k));
+            const float q = q_of(sqrtf(r2), o.c.k);
+            den += mj * kW(q, o.c.k);
+            const float3 gw = kGradW(d, q, o.c.k);
+            const float3 gr = smul3(mj, gw);
             gs = add3(gs, gr);
-            sl += dot3(gr, gr);
-        }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj)
-        {
-            const float q = q_of(sqrtf(r2), o.k);
-            den += mj * kW(q, o.k);
-            gs = add3(gs, smul3(mj, kGradW(d, q, o.k)));
+            if (!isB) sl += dot3(gr, gr);
+            if (withRate) {
+                const float3 vj = isB ? v3(0, 0, 0) : o.vel[idx];
+                e += mj * dot3(sub3(vi, vj), gw);
+            }
         }
     };
-    __device__ void operator()(int i) const
-    {
-        Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
-        density[i] = b.den;
-        alpha[i] = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
-    }
 };
+template <bool WITH_RATE>
+__global__ void __launch_bounds__(256) k_dfsph_head(const OpDfsphHead o, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    long long fixed = 0;
+    if (i < n) {
+        OpDfsphHead::Body b{o, WITH_RATE ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
+        sweep<true>(o.c, i, xyz(o.c.posm[i]), b);
+        const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
+        o.density[i] = b.den;
+        o.alpha[i] = al;
+        if (WITH_RATE) fixed = finish_rate<false, 0>(o.out, i, b.e, b.den, al);
+    }
+    if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
+}
 
-// computeDivergenceError_CUDA (DFSPHSolver.cu:261-306) and computeDensityError_CUDA (:74-116):
-// e = sum_f m_j (v_i - v_j).gradW + sum_b m_j v_i.gradW, then the mode-specific clamp.  The warm
-// stiffness bookkeeping of DFSPHSolver.cu:185,199-203 and the |error| reduction of :206,:360 are
-// fused into the epilogue (WARM: 0 none, 1 set, 2 accumulate).
+// stand-alone rate sweep: e = sum_f m_j (v_i - v_j).gradW + sum_b m_j v_i.gradW
 struct OpRate {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
+    SweepCtx c;
     const float3* vel; const float* density; const float* alpha;
-    float* error; float* kappa; float* warm;
-    unsigned long long* accum;   // fixed-point sum of |error| (nullptr: no reduction)
-    float dt, rho0;
+    RateOut out;
     struct Body {
         const OpRate& o; float3 vi; float e;
-        __device__ __forceinline__ void fluid(int j, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            e += mj * dot3(sub3(vi, o.vel[j]), kGradW(d, q_of(sqrtf(r2), o.k), o.k));
-        }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj)
-        {
-            e += mj * dot3(vi, kGradW(d, q_of(sqrtf(r2), o.k), o.k));
+            const float3 vj = isB ? v3(0, 0, 0) : o.vel[idx];
+            e += mj * dot3(sub3(vi, vj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k));
         }
     };
 };
@@ -211,51 +228,30 @@ __global__ void __launch_bounds__(256) k_rate(const OpRate o, int n)
     long long fixed = 0;
     if (i < n) {
         OpRate::Body b{o, o.vel[i], 0.0f};
-        sweep27<true, true>(o.g, o.k, o.csF, o.posm, o.csB, o.bposm, xyz(o.posm[i]), b);
-        float err;
-        const float den = o.density[i];
-        if (DENSITY_MODE) {
-            err = max0(o.dt * b.e + den - o.rho0);
-        } else {
-            err = max0(b.e);
-            if (den + o.dt * err < o.rho0 && den <= o.rho0) err = 0.0f;
-        }
-        const float kap = err * o.alpha[i];
-        o.error[i] = err;
-        o.kappa[i] = kap;
-        if (WARM == 1) o.warm[i] = kap;
-        if (WARM == 2) o.warm[i] = o.warm[i] + kap;
-        fixed = error_fixed(err);
+        sweep<true>(o.c, i, xyz(o.c.posm[i]), b);
+        fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     }
-    if (o.accum) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) fixed += __shfl_down(fixed, off, 64);
-        if ((threadIdx.x & 63) == 0 && fixed != 0) atomicAdd(o.accum, (unsigned long long)fixed);
-    }
+    if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 
 // correctDivergenceError_CUDA (DFSPHSolver.cu:308-329) / correctDensityError_CUDA (:138-158)
 template <bool DIVIDE_BY_DT>
 struct OpCorrect {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
+    SweepCtx c;
     const float* kappa; float3* vel;
     float dt;
     struct Body {
         const OpCorrect& o; float ki; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            a = add3(a, smul3(mj * (ki + o.kappa[j]), kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
-        }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj)
-        {
-            a = add3(a, smul3(mj * ki, kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
+            const float kj = isB ? 0.0f : o.kappa[idx];
+            a = add3(a, smul3(mj * (ki + kj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
     __device__ void operator()(int i) const
     {
         Body b{*this, kappa[i], v3(0, 0, 0)};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
+        sweep<true>(c, i, xyz(c.posm[i]), b);
         vel[i] = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
     }
 };
@@ -264,28 +260,25 @@ struct OpCorrect {
 // computeDensityLambda_CUDA, PBDSolver.cu:127-168.  `rb` is (float)(bool)rho0;
 // dividing by 1.0f is the identity, so the division is only performed when rb != 1.
 struct OpLambda {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
+    SweepCtx c;
     float* density; float* lambda;
     float rho0, rb, relaxation;
     struct Body {
         const OpLambda& o; float den, sl; float3 gs;
-        __device__ __forceinline__ void term(float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int, bool, float3 d, float r2, float mj)
         {
-            const float q = q_of(sqrtf(r2), o.k);
-            den += mj * kW(q, o.k);
-            float3 gr = smul3(-mj, kGradW(d, q, o.k));
+            const float q = q_of(sqrtf(r2), o.c.k);
+            den += mj * kW(q, o.c.k);
+            float3 gr = smul3(-mj, kGradW(d, q, o.c.k));
             if (o.rb != 1.0f) gr = div3s(gr, o.rb);
             gs = sub3(gs, gr);
             sl += dot3(gr, gr);
         }
-        __device__ __forceinline__ void fluid(int, float3 d, float r2, float mj) { term(d, r2, mj); }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj) { term(d, r2, mj); }
     };
     __device__ void operator()(int i) const
     {
         Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
+        sweep<true>(c, i, xyz(c.posm[i]), b);
         density[i] = b.den;
         float lam = (b.den > rho0) ? (-(b.den / rho0 - 1.0f) / (dot3(b.gs, b.gs) + b.sl + kEps)) : 0.0f;
         lam *= relaxation;
@@ -295,47 +288,52 @@ struct OpLambda {
 
 // computeDeltaPos_CUDA, PBDSolver.cu:170-210
 struct OpDeltaPos {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const int* csB; const float4* bposm;
+    SweepCtx c;
     const float* lambda; float3* deltaPos;
     float rho0;
     struct Body {
         const OpDeltaPos& o; float li; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            a = add3(a, smul3(mj * (li + o.lambda[j]), kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
-        }
-        __device__ __forceinline__ void boundary(int, float3 d, float r2, float mj)
-        {
-            a = add3(a, smul3(mj * li, kGradW(d, q_of(sqrtf(r2), o.k), o.k)));
+            const float lj = isB ? 0.0f : o.lambda[idx];
+            a = add3(a, smul3(mj * (li + lj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
     __device__ void operator()(int i) const
     {
         Body b{*this, lambda[i], v3(0, 0, 0)};
-        sweep27<true, true>(g, k, csF, posm, csB, bposm, xyz(posm[i]), b);
+        sweep<true>(c, i, xyz(c.posm[i]), b);
         deltaPos[i] = div3s(b.a, rho0);
     }
 };
 
-// XSPHViscosity_CUDA, PBDSolver.cu:89-115, Jacobi form: reads vel, writes velOut
+// XSPHViscosity_CUDA (PBDSolver.cu:89-115), Jacobi form (reads vel, writes velOut),
+// optionally fused with the colour gradient (BasicSPHSolver.cu:277-318).
+template <bool COLOR>
 struct OpXsph {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm; const float3* vel; float3* velOut;
-    float c, rho0;
+    SweepCtx c;
+    const float3* vel; float3* velOut; float3* colorGrad;
+    float xsphC, rho0, rhoB;
     struct Body {
-        const OpXsph& o; float3 vi; float3 a;
-        __device__ __forceinline__ void fluid(int j, float3, float r2, float mj)
+        const OpXsph& o; float3 vi; float3 a; float3 cg; float cden;
+        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
         {
-            a = add3(a, mul3s(smul3(mj, sub3(o.vel[j], vi)), kW(q_of(sqrtf(r2), o.k), o.k)));
+            const float q = q_of(sqrtf(r2), o.c.k);
+            const float w = kW(q, o.c.k);
+            if (!isB) a = add3(a, mul3s(smul3(mj, sub3(o.vel[idx], vi)), w));
+            if (COLOR) {
+                const float vol = mj / (isB ? o.rhoB : o.rho0);
+                cg = add3(cg, smul3(vol, kGradW(d, q, o.c.k)));
+                cden += vol * w;
+            }
         }
-        __device__ __forceinline__ void boundary(int, float3, float, float) {}
     };
     __device__ void operator()(int i) const
     {
-        Body b{*this, vel[i], v3(0, 0, 0)};
-        sweep27<true, false>(g, k, csF, posm, nullptr, nullptr, xyz(posm[i]), b);
-        velOut[i] = add3(b.vi, div3s(smul3(c, b.a), rho0));
+        Body b{*this, vel[i], v3(0, 0, 0), v3(0, 0, 0), 0.0f};
+        sweep<COLOR>(c, i, xyz(c.posm[i]), b);
+        velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));
+        if (COLOR) colorGrad[i] = div3s(b.cg, max_eps(b.cden));
     }
 };
 
@@ -350,6 +348,16 @@ static __global__ void k_add3(float3* __restrict__ v, const float3* __restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = add3(v[i], w[i]);
 }
+// pack (x,y,z,mass) and apply the gravity kick vel += dv in the same pass (BasicSPHSolver.cu:227-235)
+static __global__ void k_pack_kick(float4* __restrict__ posm, const float3* __restrict__ pos, const float* __restrict__ mass,
+                                   float3* __restrict__ vel, float3 dv, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 p = pos[i];
+    posm[i] = make_float4(p.x, p.y, p.z, mass[i]);
+    vel[i] = add3(vel[i], dv);
+}
 // Particles::advect + enforceBoundary_CUDA(pos, vel): Particles.cu:28-36, BasicSPHSolver.cu:85-101
 static __global__ void k_advect_clamp(float3* __restrict__ pos, float3* __restrict__ vel, float dt, float3 space, int n)
 {
@@ -357,6 +365,20 @@ static __global__ void k_advect_clamp(float3* __restrict__ pos, float3* __restri
     if (i >= n) return;
     float3 v = vel[i];
     float3 p = add3(pos[i], smul3(dt, v));
+    clamp_box<true>(p, v, space);
+    pos[i] = p;
+    vel[i] = v;
+}
+// PBD tail: vel += dv (gravity), posLast = pos, then advect + clamp (PBDSolver.cu:69-79)
+static __global__ void k_kick_remember_advect(float3* __restrict__ pos, float3* __restrict__ vel, float3* __restrict__ posLast,
+                                              float3 dv, float dt, float3 space, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float3 v = add3(vel[i], dv);
+    const float3 p0 = pos[i];
+    posLast[i] = p0;
+    float3 p = add3(p0, smul3(dt, v));
     clamp_box<true>(p, v, space);
     pos[i] = p;
     vel[i] = v;
@@ -389,9 +411,17 @@ inline void launch_add3(float3* v, const float3* w, int n)
 {
     if (n > 0) k_add3<<<blocks_for(n), 256, 0, stream()>>>(v, w, n);
 }
+inline void launch_pack_kick(float4* posm, const float3* pos, const float* mass, float3* vel, float3 dv, int n)
+{
+    if (n > 0) k_pack_kick<<<blocks_for(n), 256, 0, stream()>>>(posm, pos, mass, vel, dv, n);
+}
 inline void launch_advect_clamp(float3* pos, float3* vel, float dt, float3 space, int n)
 {
     if (n > 0) k_advect_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, dt, space, n);
+}
+inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLast, float3 dv, float dt, float3 space, int n)
+{
+    if (n > 0) k_kick_remember_advect<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, posLast, dv, dt, space, n);
 }
 inline void launch_apply_delta_clamp(float3* pos, float4* posm, const float3* dpos, float3 space, int n)
 {

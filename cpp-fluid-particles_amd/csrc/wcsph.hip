@@ -1,8 +1,17 @@
 // wcsph.hip — BasicSPHSolver (weakly compressible SPH) as hand-written HIP kernels for gfx950.
 //
-// One lane per fluid particle; each lane walks its 27-cell neighbourhood in the reference order
-// and accumulates into registers (see sph_device.hpp::sweep27).  Reference behaviour restated from
-// src/BasicSPHSolver.cu:32-381 (kernel-by-kernel citations below); no code is shared with it.
+// One lane per fluid particle walks its compact neighbour row (built once per step, see
+// sph_device.hpp) and accumulates into registers in the reference's order.  Reference behaviour
+// restated from src/BasicSPHSolver.cu:32-381 (kernel-by-kernel citations in sweep_ops.hpp).
+//
+// step() has two equivalent schedules:
+//   fused    gravity folded into the pack pass; ONE sweep for viscosity + colour gradient +
+//            density/pressure; the surface sweep also applies vel += deltaV; pressure force;
+//            advect+clamp.  3 sweeps instead of 5.
+//   unfused  the reference's sequence of protected building blocks (force, diffuse, handleSurface,
+//            project, advect), used when a subclass overrides any of them or when asked for.
+#include <typeinfo>
+
 #include "BasicSPHSolver.h"
 #include "engine.hpp"
 #include "sweep_ops.hpp"
@@ -12,7 +21,8 @@ using namespace sphx;
 BasicSPHSolver::BasicSPHSolver(int num) : bufferFloat3((unsigned)num), _cache(new SweepCache(num)) {}
 BasicSPHSolver::~BasicSPHSolver() noexcept {}
 
-void BasicSPHSolver::invalidatePositions() { _cache->fluidValid = false; }
+void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
+void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)
@@ -41,9 +51,12 @@ void BasicSPHSolver::diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     const int n = (int)fluids->size();
+    // fluid-only sweep: walk the cells directly unless a list for these positions already exists
+    SweepCtx ctx = c.ctx(cellStartFluid, cellStartFluid);
     {
         ScopedKernel t("viscosity");
-        OpViscosity op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), fluids->getVelPtr(), bufferFloat3.addr(), rho0, visc, dt};
+        OpFluidProps<true, false, false> op{ctx, fluids->getVelPtr(), bufferFloat3.addr(), nullptr, nullptr, nullptr, nullptr,
+                                            rho0, 0.0f, visc, dt, 0.0f};
         launch_op(op, n);
     }
     {
@@ -63,16 +76,18 @@ void BasicSPHSolver::handleSurface(std::shared_ptr<SPHParticles>& fluids, const 
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     const int n = (int)fluids->size();
     {
         ScopedKernel t("color_grad");
-        OpColorGrad op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                       bufferFloat3.addr(), rho0, rhoB};
+        OpFluidProps<false, true, false> op{ctx, nullptr, nullptr, bufferFloat3.addr(), nullptr, nullptr, nullptr,
+                                            rho0, rhoB, 0.0f, dt, 0.0f};
         launch_op(op, n);
     }
     {
         ScopedKernel t("surface_tension");
-        OpSurface op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), bufferFloat3.addr(), fluids->getVelPtr(), rho0,
+        OpSurface op{ctx, bufferFloat3.addr(), fluids->getVelPtr(), nullptr, fluids->getVelPtr(), rho0,
                      surfaceTensionIntensity, airPressure, dt};
         launch_op(op, n);
     }
@@ -87,17 +102,18 @@ void BasicSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::s
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     const int n = (int)fluids->size();
     {
         ScopedKernel t("density_pressure");
-        OpDensityPressure op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                             fluids->getDensityPtr(), fluids->getPressurePtr(), c.pterm.addr(), rho0, stiff};
+        OpFluidProps<false, false, true> op{ctx, nullptr, nullptr, nullptr, fluids->getDensityPtr(), fluids->getPressurePtr(),
+                                            c.pterm.addr(), rho0, 0.0f, 0.0f, dt, stiff};
         launch_op(op, n);
     }
     {
         ScopedKernel t("pressure_force");
-        OpPressureForce op{c.g, c.k, cellStartFluid.addr(), c.fluid4(), cellStartBoundary.addr(), c.boundary4(),
-                           c.pterm.addr(), fluids->getVelPtr(), dt};
+        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt};
         launch_op(op, n);
     }
 }
@@ -109,11 +125,50 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
                           float visc, float3 G, float surfaceTensionIntensity, float airPressure)
 {
     invalidatePositions();   // the caller has just re-sorted the particles
-    force(fluids, dt, G);
-    diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
-    if (surfaceTensionIntensity > EPSILON || airPressure > EPSILON)
-        handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius, dt,
-                      surfaceTensionIntensity, airPressure);
-    project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, stiff, cellSize, cellLength, radius, dt);
+    SweepCache& c = cache();
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
+    if (!c.fused() || typeid(*this) != typeid(BasicSPHSolver)) {
+        force(fluids, dt, G);
+        diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
+        if (surface)
+            handleSurface(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, rhoB, cellSize, cellLength, radius,
+                          dt, surfaceTensionIntensity, airPressure);
+        project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, stiff, cellSize, cellLength, radius, dt);
+        advect(fluids, dt, spaceSize);
+        return;
+    }
+    const int n = (int)fluids->size();
+    c.setup(cellSize, cellLength, radius);
+    c.packFluidKick(*fluids, make_float3(dt * G.x, dt * G.y, dt * G.z));
+    c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+    if (surface) {
+        {
+            ScopedKernel t("visc_color_density");
+            OpFluidProps<true, true, true> op{ctx, fluids->getVelPtr(), c.aux3.addr(), bufferFloat3.addr(),
+                                              fluids->getDensityPtr(), fluids->getPressurePtr(), c.pterm.addr(),
+                                              rho0, rhoB, visc, dt, stiff};
+            launch_op(op, n);
+        }
+        ScopedKernel t("surface_tension");
+        OpSurface op{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0,
+                     surfaceTensionIntensity, airPressure, dt};
+        launch_op(op, n);
+    } else {
+        {
+            ScopedKernel t("visc_density");
+            OpFluidProps<true, false, true> op{ctx, fluids->getVelPtr(), c.aux3.addr(), nullptr, fluids->getDensityPtr(),
+                                               fluids->getPressurePtr(), c.pterm.addr(), rho0, rhoB, visc, dt, stiff};
+            launch_op(op, n);
+        }
+        ScopedKernel t("add_delta_v");
+        launch_add3(fluids->getVelPtr(), c.aux3.addr(), n);
+    }
+    {
+        ScopedKernel t("pressure_force");
+        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt};
+        launch_op(op, n);
+    }
     advect(fluids, dt, spaceSize);
 }

@@ -28,8 +28,11 @@ public:
                       float surfaceTensionIntensity, float airPressure) override;
 
     bool graphSafe() const override { return true; }
-    // engine extension: viscosity delta-v during diffuse(), colour gradient after handleSurface()
+    // engine extensions: the colour gradient left by handleSurface(), and engine switches used by
+    // the tests (bit 0: run the reference-structure, unfused sequence of building blocks;
+    // bit 1: walk the 27 cells directly instead of the per-step neighbour list)
     const DArray<float3>& getColorGradient() const { return bufferFloat3; }
+    void setEngineFlags(int flags);
 
 protected:
     virtual void force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G) override final;
@@ -53,6 +56,7 @@ protected:
     sphx::SweepCache& cache() { return *_cache; }
     // marks the packed position view stale (call after anything that moves particles)
     void invalidatePositions();
+    DArray<float3>& colorGradientBuffer() { return bufferFloat3; }
 
 private:
     DArray<float3> bufferFloat3;   // viscosity delta-v, then the colour gradient

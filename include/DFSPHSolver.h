@@ -69,5 +69,6 @@ private:
     const float divergenceErrorThreshold;
     const int maxIter;
     int fixedDiv = -1, fixedDen = -1;
+    bool headDidFirstError = false;   // the fused head sweep already produced the first divergence error
     int lastDiv = 0, lastDen = 0;
 };

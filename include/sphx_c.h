@@ -61,7 +61,8 @@ typedef struct sphx_params {
     float pbd_relaxation;      /* PBDSolver ctor: defaultRelaxation (0.75) */
     int   pow7_mode;           /* must be 0 (fp64 multiply chain for the Tait exponent) */
     int   xsph_mode;           /* must be 0 (Jacobi XSPH) */
-    int   reserved[4];
+    int   reserved[4];         /* reserved[0]: engine switches for tests (bit0 unfused schedule,
+                                  bit1 direct 27-cell walks instead of the neighbour list) */
 } sphx_params;
 
 /* device-resident fields readable through sphx_get (host copy) / sphx_device_ptr (raw pointer) */

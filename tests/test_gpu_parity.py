@@ -125,6 +125,29 @@ def test_trajectory_bit_exact_disordered(sphx, oracle, solver):
             assert gs.iters() == os_.iters()
 
 
+@pytest.mark.parametrize("solver", [0, 1, 2])
+@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (3, None), (0, "8"), (1, "20")])
+def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
+    """the fused/unfused schedules, the neighbour-list and direct 27-cell walks, and the per-lane
+    overflow fallback of the list (tiny capacity) all produce the oracle's bits."""
+    if cap:
+        monkeypatch.setenv("SPHX_NBR_CAP", cap)
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = solver; P.pbd_iters = 3; P.dt = 0.001
+    n = len(fluid)
+    pos, vel = _splash_state(n, P, 40 + solver)
+    Po = same_params(oracle.Params(), P)
+    P.reserved[0] = flags
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    ids = gs.get(sphx.F_ID)
+    gs.set(sphx.F_VEL, vel[ids]); os_.set(oracle.F_VEL, vel[ids])
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else []) + (FIELDS_PBD if solver == 2 else [])
+    for s in range(4):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, names, "flags %d cap %s solver %d step %d" % (flags, cap, solver, s + 1))
+
+
 def test_dfsph_fixed_iterations_and_graph_replay(sphx, oracle):
     """fixed (v=1, d=4) mode: step_n replays a captured hipGraph; results equal eager stepping."""
     def tweak(P):
