@@ -327,6 +327,37 @@ int sphx_profile_step(sphx_system* h, int cap, char (*names)[48], float* ms, int
     return SPHX_OK;
 }
 
+// live kernel timing for bench.py: hipEvents on the engine stream around every launch whose span
+// name equals `filter` (empty: all); while enabled, sphx_step_n launches eagerly (no graph).
+int sphx_kernel_timer(int enable, const char* filter)
+{
+    KernelTimer::reset();
+    KernelTimer::filter = (filter && enable) ? filter : "";
+    KernelTimer::enabled = enable != 0;
+    return SPHX_OK;
+}
+
+int sphx_kernel_timer_collect(int cap, char (*names)[48], float* total_ms, int* launches, int* count)
+{
+    if (!names || !total_ms || !launches || !count) return fail(SPHX_ERR_INVALID, "sphx_kernel_timer_collect: bad argument");
+    std::vector<std::string> nm; std::vector<float> t;
+    KernelTimer::collect(nm, t);
+    std::vector<std::string> un; std::vector<float> ut; std::vector<int> uc;
+    for (size_t i = 0; i < nm.size(); ++i) {
+        size_t k = 0;
+        while (k < un.size() && un[k] != nm[i]) ++k;
+        if (k == un.size()) { un.push_back(nm[i]); ut.push_back(0.0f); uc.push_back(0); }
+        ut[k] += t[i]; uc[k] += 1;
+    }
+    *count = (int)std::min((size_t)cap, un.size());
+    for (int i = 0; i < *count; ++i) {
+        std::strncpy(names[i], un[i].c_str(), 47); names[i][47] = 0;
+        total_ms[i] = ut[i]; launches[i] = uc[i];
+    }
+    KernelTimer::reset();
+    return SPHX_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------ probes

@@ -40,7 +40,7 @@ void launch_rate(const OpRate& op, int n, bool reduce)
     OpRate o = op;
     if (!reduce) o.out.accum = nullptr;
     else HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long), sphx::stream()));
-    k_rate<DENSITY_MODE, WARM><<<blocks_for(n), 256, 0, sphx::stream()>>>(o, n);
+    launch_rate_kernel<DENSITY_MODE, WARM>(o, n);
 }
 }  // namespace
 
@@ -58,7 +58,7 @@ void DFSPHSolver::computeDensityAlpha(std::shared_ptr<SPHParticles>& fluids, con
     if (num <= 0) return;
     ScopedKernel t("density_alpha");
     OpDfsphHead op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{}};
-    k_dfsph_head<false><<<blocks_for(num), 256, 0, sphx::stream()>>>(op, num);
+    launch_dfsph_head<false>(op, num);
 }
 
 // correctDivergenceError, DFSPHSolver.cu:331-363.  `firstErrorDone`: the fused head sweep has
@@ -188,7 +188,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         ScopedKernel t("density_alpha_diverr");
         OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                        RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0}};
-        k_dfsph_head<true><<<blocks_for(num), 256, 0, sphx::stream()>>>(op, num);
+        launch_dfsph_head<true>(op, num);
     }
     headDidFirstError = true;
     lastDiv = correctDivergenceError(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength,

@@ -25,7 +25,9 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength);
 //   nbr/nbrCount : wave-interleaved compact neighbour rows (sph_device.hpp), `cap` entries/particle
 //   aux3         : second float3 scratch (viscosity delta-v while bufferFloat3 holds the colour
 //                  gradient in the fused sweeps)
-enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2 };
+// kFlagTiles: stage neighbour ranges in LDS per 64-particle tile (tested, currently slower than
+// global gathers at one wave per 40 KB of LDS; off by default)
+enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4 };
 
 struct SweepCache {
     explicit SweepCache(int num);
@@ -33,7 +35,10 @@ struct SweepCache {
     DArray<float> posm;                      // 4 floats per fluid particle
     DArray<float> pterm;
     DArray<float3> aux3;
+    DArray<float> vel4;                      // float4 mirror of vel, kept in step by every velocity writer
+    DArray<float> cg4;                       // float4 mirror of the colour gradient
     DArray<int> nbrCount;
+    DArray<int> tileFmt;                     // per 64-particle tile: 1 = rows hold LDS slots
     std::unique_ptr<DArray<int>> nbr;        // allocated on first use
     std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
     int nb = 0;
@@ -42,6 +47,9 @@ struct SweepCache {
     bool fluidValid = false;
     bool boundaryValid = false;
     bool listValid = false;
+    bool allowTiles = true;                  // false when sweeps run on positions that were not binned (PBD)
+    const int* listCsF = nullptr;            // cell tables the current rows were built from
+    const int* listCsB = nullptr;
     const void* boundaryKey = nullptr;       // boundary pos pointer the packed copy was made from
     KernelConsts k{};
     GridDesc g{};
@@ -60,6 +68,8 @@ struct SweepCache {
     bool fused() const { return (flags & kFlagUnfused) == 0; }
     const float4* fluid4() const { return reinterpret_cast<const float4*>(posm.addr()); }
     float4* fluid4w() { return reinterpret_cast<float4*>(posm.addr()); }
+    float4* vel4w() const { return reinterpret_cast<float4*>(vel4.addr()); }
+    float4* cg4w() const { return reinterpret_cast<float4*>(cg4.addr()); }
     const float4* boundary4() const { return reinterpret_cast<const float4*>(bposm->addr()); }
 };
 
@@ -69,14 +79,20 @@ inline unsigned int blocks_for(int n, int block = 256) { return n > 0 ? (unsigne
 // kernel with hipEvents on sphx::stream().
 struct KernelTimer {
     static bool enabled;
+    static std::string filter;   // when non-empty only spans with exactly this name are recorded
     static void begin(const char* name);
     static void end();
     static void collect(std::vector<std::string>& names, std::vector<float>& ms);
     static void reset();
 };
 struct ScopedKernel {
-    explicit ScopedKernel(const char* name) { if (KernelTimer::enabled) KernelTimer::begin(name); }
-    ~ScopedKernel() { if (KernelTimer::enabled) KernelTimer::end(); }
+    explicit ScopedKernel(const char* name)
+        : on(KernelTimer::enabled && (KernelTimer::filter.empty() || KernelTimer::filter == name))
+    {
+        if (on) KernelTimer::begin(name);
+    }
+    ~ScopedKernel() { if (on) KernelTimer::end(); }
+    bool on;
 };
 
 // generic element-wise device helpers implemented in elementwise.hip

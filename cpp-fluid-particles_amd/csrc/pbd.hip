@@ -54,7 +54,7 @@ void PBDSolver::diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray<int>
     ScopedKernel t("xsph");
     OpXsph<false> op{c.ctx(cellStartFluid, cellStartFluid), fluids->getVelPtr(), bufferFloat3.addr(), nullptr, visc, rho0, 0.0f};
     launch_op(op, num);
-    ew_copy(fluids->getVelPtr(), bufferFloat3.addr(), sizeof(float3) * num);
+    launch_copy3_mirror(fluids->getVelPtr(), c.vel4w(), bufferFloat3.addr(), num);
 }
 
 // PBDSolver::project, PBDSolver.cu:225-258.  Positions move every iteration while the cell table
@@ -113,13 +113,14 @@ void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_pt
     }
     invalidatePositions();
     SweepCache& c = cache();
+    c.allowTiles = false;   // PBD sweeps run on positions that moved after binning
     const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
     const int num = (int)fluids->size();
     updateNeighborhood(fluids);
     project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, spaceSize, cellLength, radius, maxIter);
     {
         ScopedKernel t("pbd_velocity");
-        launch_velocity_from_displacement(fluids->getVelPtr(), fluids->getPosPtr(), fluidPosLast.addr(), dt, num);
+        launch_velocity_from_displacement(fluids->getVelPtr(), cache().vel4w(), fluids->getPosPtr(), fluidPosLast.addr(), dt, num);
     }
     if (!c.fused()) {
         diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, xSPH_c);

@@ -107,6 +107,15 @@ __global__ void k_pack4(float4* __restrict__ dst, const float3* __restrict__ pos
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) { const float3 p = pos[q]; dst[q] = make_float4(p.x, p.y, p.z, w[q]); }
 }
+__global__ void k_pack_fluid(float4* __restrict__ posm, float4* __restrict__ vel4, const float3* __restrict__ pos,
+                             const float* __restrict__ mass, const float3* __restrict__ vel, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float3 p = pos[q], v = vel[q];
+    posm[q] = make_float4(p.x, p.y, p.z, mass[q]);
+    vel4[q] = make_float4(v.x, v.y, v.z, 0.0f);
+}
 
 void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n)
 {
@@ -142,23 +151,51 @@ void ew_iota(int* dst, int n)
 }
 
 // ------------------------------------------------------------------------------ SweepCache
-__global__ void k_pack_kick_rt(float4* __restrict__ posm, const float3* __restrict__ pos, const float* __restrict__ mass,
-                               float3* __restrict__ vel, float3 dv, int n)
+__global__ void k_pack_kick_rt(float4* __restrict__ posm, float4* __restrict__ vel4, const float3* __restrict__ pos,
+                               const float* __restrict__ mass, float3* __restrict__ vel, float3 dv, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float3 p = pos[i];
     posm[i] = make_float4(p.x, p.y, p.z, mass[i]);
-    vel[i] = add3(vel[i], dv);
+    const float3 v = add3(vel[i], dv);
+    vel[i] = v;
+    vel4[i] = make_float4(v.x, v.y, v.z, 0.0f);
 }
-__global__ void __launch_bounds__(256) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int n)
+// tiled build: one wave per 64-particle tile decides whether the tile is staged, stages positions,
+// builds the rows with LDS slots as entries
+__global__ void __launch_bounds__(kTile) k_build_list_tiled(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) build_neighbor_row(c, nbr, nbrCount, i);
+    __shared__ float4 pos[kTileSlots];
+    __shared__ TileTable tab;
+    const int lane = threadIdx.x;
+    const int tile = logical_block();
+    if (tile * kTile >= c.n) return;
+    const int i = tile * kTile + lane;
+    const bool tiled = tile_table(c, tile * kTile, tab);
+    if (tiled) {
+#pragma unroll 1
+        for (int r = 0; r < 18; ++r) {
+            const int s0 = tab.start[r], o = tab.off[r], len = tab.off[r + 1] - o;
+            const float4* src = r < 9 ? c.posm : c.bposm;
+            for (int t = lane; t < len; t += kTile) pos[o + t] = src[s0 + t];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) tileFmt[tile] = tiled ? 1 : 0;
+    if (i < c.n) build_neighbor_row(c, tiled ? pos : nullptr, &tab, nbr, nbrCount, i);
+}
+// plain build: rows hold global indices
+__global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount)
+{
+    const int i = logical_block() * kWideBlock + threadIdx.x;
+    if (i < c.n) build_neighbor_row(c, nullptr, nullptr, nbr, nbrCount, i);
 }
 
 SweepCache::SweepCache(int num)
-    : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), nbrCount((unsigned)num)
+    : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
+      cg4(4u * (unsigned)num), nbrCount((unsigned)num),
+      tileFmt((unsigned)(num / kTile + 1))
 {
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
@@ -177,7 +214,8 @@ void SweepCache::packFluid(const SPHParticles& fluids)
 {
     if (fluidValid) return;
     ScopedKernel t("pack_fluid");
-    if (n > 0) k_pack4<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), n);
+    if (n > 0)
+        k_pack_fluid<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), n);
     fluidValid = true;
     listValid = false;
 }
@@ -186,7 +224,7 @@ void SweepCache::packFluidKick(const SPHParticles& fluids, float3 dv)
 {
     ScopedKernel t("pack_kick");
     if (n > 0)
-        k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), dv, n);
+        k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), dv, n);
     fluidValid = true;
     listValid = false;
 }
@@ -213,9 +251,14 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.csF = csF.addr(); c.posm = fluid4();
     c.csB = csB.addr(); c.bposm = bposm ? boundary4() : nullptr;
     const bool use = listValid && nbr && !(flags & kFlagNoList);
+    if (use) { c.csF = listCsF; c.csB = listCsB; }   // rows (and tile tables) are tied to these tables
     c.nbr = use ? reinterpret_cast<const unsigned int*>(nbr->addr()) : nullptr;
     c.nbrCount = nbrCount.addr();
     c.cap = cap;
+    c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
+    c.n = n;
+    c.vel4 = vel4w();
+    c.cg4 = cg4w();
     return c;
 }
 
@@ -227,13 +270,19 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     if (!nbr) nbr.reset(new DArray<int>((unsigned)entries));
     SweepCtx c = ctx(csF, csB);
     c.nbr = nullptr;
+    listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");
-    k_build_list<<<blocks_for(n), 256, 0, stream()>>>(c, reinterpret_cast<unsigned int*>(nbr->addr()), nbrCount.addr(), n);
+    unsigned int* rows = reinterpret_cast<unsigned int*>(nbr->addr());
+    if (allowTiles && (flags & kFlagTiles))
+        k_build_list_tiled<<<xcd_grid(n, kTile), kTile, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
+    else
+        k_build_list<<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr());
     listValid = true;
 }
 
 // ------------------------------------------------------------------------------ KernelTimer
 bool KernelTimer::enabled = false;
+std::string KernelTimer::filter;
 namespace {
 struct TimedSpan { std::string name; hipEvent_t a, b; };
 std::vector<TimedSpan> g_spans;

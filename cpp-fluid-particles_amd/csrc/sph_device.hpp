@@ -43,6 +43,7 @@ __device__ __forceinline__ float3 div3s(float3 a, float s) { return v3(a.x / s, 
 __device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float len3(float3 a) { return sqrtf(dot3(a, a)); }
 __device__ __forceinline__ float cube(float x) { return x * x * x; }
+__device__ __forceinline__ float3 xyz4(const float4 v) { return make_float3(v.x, v.y, v.z); }
 
 // fmaxf/fminf with explicit compares (identical to the oracle's helpers; see oracle header)
 __device__ __forceinline__ float max_eps(float x) { return (x > kEps) ? x : kEps; }
@@ -159,27 +160,87 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
     }
 }
 
-// ---- per-step compact neighbour list ---------------------------------------------------------------
+// ---- per-step compact neighbour list + LDS-staged tiles ---------------------------------------------
 // While positions are frozen (all sweeps of a WCSPH/DFSPH step; the two sweeps of one PBD
 // iteration) every sweep of particle i meets the same candidates and rejects the same ones, and a
 // rejected candidate contributes exactly +0.  The first pass therefore records, per particle, the
 // candidates with r2 <= tCut IN VISIT ORDER (self excluded: its terms are exactly zero); later
 // sweeps walk that list.  Order is preserved, so every accumulated bit is.
 //
-// Layout: wave-interleaved rows — entry k of particle i lives at ((i>>6)*cap + k)*64 + (i&63), so
+// Row layout: wave-interleaved — entry k of particle i lives at ((i>>6)*cap + k)*64 + (i&63), so
 // the 64 lanes of a wave read 256 contiguous bytes per k.  Bit 31 marks a boundary particle.
-// count > cap means the list overflowed: that lane falls back to the direct 27-cell walk.
+// count > cap means the row overflowed: that lane falls back to the direct 27-cell walk.
+//
+// Tiles: a tile is 64 consecutive (cell-sorted) particles = one wave = one workgroup.  Because the
+// linear cell id runs z fastest, the 27-cell neighbourhoods of a tile are covered by 9 contiguous
+// cell-id ranges [first+off-1, last+off+1], off = (dx*gy+dy)*gz, i.e. 9 contiguous particle ranges
+// of the fluid array and 9 of the boundary array.  A tiled sweep copies those ranges (position+mass
+// and the one per-particle field the sweep reads from neighbours) into LDS with coalesced loads and
+// then gathers from LDS; row entries of a tiled tile are LDS slots instead of global indices.
+// Divergent global gathers cost ~64 cycles per wave-instruction on a CU's single texture-address
+// pipe and bound the un-tiled sweeps; LDS gathers cost ~10.  Tiles whose ranges exceed kTileSlots,
+// that touch the out-of-grid sentinel, or whose positions are not the binned ones (PBD) keep
+// global indices (tileFmt = 0).
+constexpr int kTile = 64;
+constexpr int kWideBlock = 256;     // threads per block of the un-tiled kernels (4 adjacent tiles share a CU's L1)
+constexpr int kTileSlots = 1280;
+constexpr unsigned int kBoundaryBit = 0x80000000u;
+
 struct SweepCtx {
     GridDesc g; KernelConsts k;
     const int* csF; const float4* posm;     // fluid cell starts, packed (x,y,z,mass)
     const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass)
     const unsigned int* nbr; const int* nbrCount; int cap;   // nbr == nullptr: direct sweeps only
+    const int* tileFmt;                     // per tile: 1 = row entries are LDS slots (nullptr: never)
+    float4* vel4;                           // 16-byte aligned mirror of the fluid velocities (one gather)
+    float4* cg4;                            // 16-byte aligned mirror of the colour gradient
+    int n;
 };
-constexpr unsigned int kBoundaryBit = 0x80000000u;
 
-// direct walk in reference order, Body::pair(idx, isBoundary, d, r2, mass_j)
-template <bool WANT_BOUNDARY, class Body>
-__device__ __forceinline__ void sweep_direct(const SweepCtx& c, const float3 pi, Body& body)
+// XCD-aware block order: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each XCD
+// has its own L2.  Logical block = (b % 8) * chunk + b / 8 gives every XCD one contiguous run of
+// logical blocks = one spatial slab of the cell-sorted particles, so the neighbour data an XCD
+// re-reads stays in ITS L2 instead of being fetched into all eight.  Grids are launched with
+// 8 * chunk blocks; logical blocks past the end exit.  (Speed only: any placement is correct.)
+__device__ __forceinline__ int logical_block() { return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3); }
+inline unsigned int xcd_grid(int n, int block) { const int nb = n > 0 ? (n - 1) / block + 1 : 1; return (unsigned int)(((nb + 7) / 8) * 8); }
+
+struct TileTable { int start[18]; int off[19]; };   // ranges 0..8 fluid (dx,dy), 9..17 boundary
+
+// All 64 lanes call this.  Returns true when the tile can be staged.
+__device__ __forceinline__ bool tile_table(const SweepCtx& c, const int i0, TileTable& tab)
+{
+    const int lane = threadIdx.x;
+    const int i1 = min(i0 + kTile, c.n);
+    const int3 cf = cell_of(xyz4(c.posm[i0]), c.g.cellLength);
+    const int3 cl = cell_of(xyz4(c.posm[i1 - 1]), c.g.cellLength);
+    const int idF = cell_id(cf.x, cf.y, cf.z, c.g), idL = cell_id(cl.x, cl.y, cl.z, c.g);
+    const bool ok = idF < c.g.C && idL < c.g.C && idF <= idL;
+    int len = 0;
+    if (lane < 18) {
+        const int r = lane % 9;
+        const int off = ((r / 3 - 1) * c.g.gy + (r % 3 - 1)) * c.g.gz;
+        const int lo = max(idF + off - 1, 0), hi = min(idL + off + 1, c.g.C - 1);
+        const int* cs = lane < 9 ? c.csF : c.csB;
+        int s0 = 0;
+        if (ok && lo <= hi) { s0 = cs[lo]; len = cs[hi + 1] - s0; }
+        tab.start[lane] = s0;
+    }
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane < 18) tab.off[lane] = incl - len;
+    if (lane == 17) tab.off[18] = incl;
+    __syncthreads();
+    return ok && tab.off[18] <= kTileSlots;
+}
+
+// direct walk in reference order; `visit(j, isBoundary, d, r2, mass_j)`
+template <bool WANT_BOUNDARY, class Visit>
+__device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, Visit&& visit)
 {
     const int3 c0 = cell_of(pi, c.g.cellLength);
     for (int dx = -1; dx <= 1; ++dx) {
@@ -199,7 +260,7 @@ __device__ __forceinline__ void sweep_direct(const SweepCtx& c, const float3 pi,
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                         const float r2 = dot3(d, d);
                         if (r2 > c.k.tCut) continue;
-                        body.pair(j, false, d, r2, pj.w);
+                        visit(j, false, d, r2, pj.w);
                     }
                 }
                 if (WANT_BOUNDARY) {
@@ -209,7 +270,7 @@ __device__ __forceinline__ void sweep_direct(const SweepCtx& c, const float3 pi,
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                         const float r2 = dot3(d, d);
                         if (r2 > c.k.tCut) continue;
-                        body.pair(j, true, d, r2, pj.w);
+                        visit(j, true, d, r2, pj.w);
                     }
                 }
             }
@@ -217,32 +278,52 @@ __device__ __forceinline__ void sweep_direct(const SweepCtx& c, const float3 pi,
     }
 }
 
-template <bool WANT_BOUNDARY, class Body>
-__device__ __forceinline__ void sweep(const SweepCtx& c, const int i, const float3 pi, Body& body)
+// The sweep of one particle.  Op supplies `Field` (the per-neighbour value its pair term reads) and
+// `stage(isBoundary, j)` (its global load; boundaries yield zeros); Body::pair(field, isBoundary,
+// d, r2, mass_j, j_or_-1) accumulates.  ldsPos/ldsField are the staged tile (nullptr: global).
+template <bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, const float4* ldsPos,
+                                      const typename Op::Field* ldsField, const int i, const float3 pi, Body& body)
 {
     if (c.nbr) {
         const int cnt = c.nbrCount[i];
         if (cnt <= c.cap) {
             const unsigned int* row = c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
-            for (int t = 0; t < cnt; ++t) {
-                const unsigned int e = row[(size_t)t * 64u];
-                const bool isB = (e & kBoundaryBit) != 0u;
-                if (!WANT_BOUNDARY && isB) continue;
-                const int idx = (int)(e & ~kBoundaryBit);
-                const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
-                const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                body.pair(idx, isB, d, dot3(d, d), pj.w);
+            if (ldsPos) {
+                for (int t = 0; t < cnt; ++t) {
+                    const unsigned int e = row[(size_t)t * 64u];
+                    const bool isB = (e & kBoundaryBit) != 0u;
+                    if (!WANT_BOUNDARY && isB) continue;
+                    const int slot = (int)(e & ~kBoundaryBit);
+                    const float4 pj = ldsPos[slot];
+                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                    body.pair(ldsField[slot], isB, d, dot3(d, d), pj.w, -1);
+                }
+            } else {
+                for (int t = 0; t < cnt; ++t) {
+                    const unsigned int e = row[(size_t)t * 64u];
+                    const bool isB = (e & kBoundaryBit) != 0u;
+                    if (!WANT_BOUNDARY && isB) continue;
+                    const int idx = (int)(e & ~kBoundaryBit);
+                    const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
+                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                    body.pair(op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
+                }
             }
             return;
         }
     }
-    sweep_direct<WANT_BOUNDARY>(c, pi, body);
+    walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+        body.pair(op.stage(isB, j), isB, d, r2, mj, j);
+    });
 }
 
-// list construction: same walk; z-adjacent cells are contiguous in memory (z is the fastest cell
-// axis), so when the three cells of a (dx,dy) column hold no boundary particles the fluid ranges
-// are visited as one run (identical order).
-__device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, unsigned int* nbr, int* nbrCount, const int i)
+// Row construction for particle i: the same walk; the three z-adjacent cells of a (dx,dy) column
+// are contiguous in memory, so when they hold no boundary particles the fluid ranges are visited
+// as one run (identical order).  With a staged tile candidates are read from LDS and entries are
+// LDS slots: slot = tab.off[r] + (j - tab.start[r]), r = (dx+1)*3 + (dy+1) (+9 for boundaries).
+__device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, const float4* ldsPos, const TileTable* tab,
+                                                   unsigned int* nbr, int* nbrCount, const int i)
 {
     const float4 self = c.posm[i];
     const float3 pi = v3(self.x, self.y, self.z);
@@ -257,25 +338,28 @@ __device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, unsigned i
             const int Y = c0.y + dy;
             if (Y < 0 || Y >= c.g.gy || zlo > zhi) continue;
             const int base = (X * c.g.gy + Y) * c.g.gz;
+            const int r = (dx + 1) * 3 + (dy + 1);
+            const int fShift = ldsPos ? tab->off[r] - tab->start[r] : 0;       // slot = j + shift
+            const int bShift = ldsPos ? tab->off[r + 9] - tab->start[r + 9] : 0;
             const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
             const int step = noWall ? (zhi - zlo + 1) : 1;
             for (int z = zlo; z <= zhi; z += step) {
                 const int cell = base + z;
                 const int e = c.csF[cell + step];
                 for (int j = c.csF[cell]; j < e; ++j) {
-                    const float4 pj = c.posm[j];
+                    const float4 pj = ldsPos ? ldsPos[j + fShift] : c.posm[j];
                     const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                     if (dot3(d, d) > c.k.tCut || j == i) continue;
-                    if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)j;
+                    if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift);
                     ++cnt;
                 }
                 if (!noWall) {
                     const int eb = c.csB[cell + 1];
                     for (int j = c.csB[cell]; j < eb; ++j) {
-                        const float4 pj = c.bposm[j];
+                        const float4 pj = ldsPos ? ldsPos[j + bShift] : c.bposm[j];
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                         if (dot3(d, d) > c.k.tCut) continue;
-                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)j | kBoundaryBit;
+                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | kBoundaryBit;
                         ++cnt;
                     }
                 }

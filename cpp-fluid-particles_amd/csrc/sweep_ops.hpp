@@ -15,16 +15,50 @@
 
 namespace sphx {
 
-template <class Op>
-__global__ void __launch_bounds__(256) k_run_op(const Op op, int n)
+// ---- tile staging + launch ------------------------------------------------------------------------
+template <class Op, bool TILED>
+struct TileLds {
+    float4 pos[TILED ? kTileSlots : 1];
+    typename Op::Field field[TILED ? kTileSlots : 1];
+    TileTable tab;
+};
+
+// copies the tile's 18 ranges into LDS (coalesced); returns false when this tile is not staged
+template <class Op, bool TILED>
+__device__ __forceinline__ bool stage_tile(const Op& op, const SweepCtx& c, TileLds<Op, TILED>& lds)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) op(i);
+    const int tile = logical_block();
+    if (!TILED || !c.nbr || !c.tileFmt || tile * kTile >= c.n || !c.tileFmt[tile]) return false;
+    tile_table(c, tile * kTile, lds.tab);
+    const int lane = threadIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < 18; ++r) {
+        const int s0 = lds.tab.start[r], o = lds.tab.off[r], len = lds.tab.off[r + 1] - o;
+        const float4* src = r < 9 ? c.posm : c.bposm;
+        for (int t = lane; t < len; t += kTile) {
+            lds.pos[o + t] = src[s0 + t];
+            lds.field[o + t] = op.stage(r >= 9, s0 + t);
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// TILED: one wave per 64-particle tile with LDS staging; otherwise 256-thread blocks, global gathers
+template <class Op, bool TILED>
+__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_run_op(const Op op, int n)
+{
+    __shared__ TileLds<Op, TILED> lds;
+    const bool tiled = stage_tile<Op, TILED>(op, op.c, lds);
+    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
+    if (i < n) op(i, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr);
 }
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
-    if (n > 0) k_run_op<Op><<<blocks_for(n), 256, 0, stream()>>>(op, n);
+    if (n <= 0) return;
+    if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(op, n);
+    else k_run_op<Op, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(op, n);
 }
 
 // wave-level sum of the fixed-point |error| terms, one atomic per wave
@@ -35,11 +69,8 @@ __device__ __forceinline__ void accumulate_error(long long fixed, unsigned long 
     if ((threadIdx.x & 63) == 0 && fixed != 0) atomicAdd(accum, (unsigned long long)fixed);
 }
 
-// neighbour-list construction (sph_device.hpp::build_neighbor_row)
-struct OpBuildList {
-    SweepCtx c; unsigned int* nbr; int* nbrCount;
-    __device__ void operator()(int i) const { build_neighbor_row(c, nbr, nbrCount, i); }
-};
+__device__ __forceinline__ float4 f4(const float3 v) { return make_float4(v.x, v.y, v.z, 0.0f); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 
 // =================================================================================== shared sweeps
 // Per-particle properties that depend on positions (and the current velocities) only:
@@ -52,13 +83,15 @@ struct OpFluidProps {
     const float3* vel; float3* deltaV; float3* colorGrad;
     float* density; float* pressure; float* pterm;
     float rho0, rhoB, visc, dt, stiff;
+    using Field = float4;   // neighbour velocity
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return (VISC && !isB) ? c.vel4[j] : f4zero(); }
     struct Body {
         const OpFluidProps& o; float3 vi; float3 a; float3 cg; float cden; float den;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float r = sqrtf(r2);
             if (VISC && !isB)
-                a = add3(a, mul3s(smul3(mj, div3s(sub3(o.vel[idx], vi), o.rho0)), kViscLap(r, o.c.k)));
+                a = add3(a, mul3s(smul3(mj, div3s(sub3(xyz(vj), vi), o.rho0)), kViscLap(r, o.c.k)));
             if (COLOR || DENS) {
                 const float q = q_of(r, o.c.k);
                 const float w = kW(q, o.c.k);
@@ -71,12 +104,12 @@ struct OpFluidProps {
             }
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, VISC ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f};
-        sweep<COLOR || DENS>(c, i, xyz(c.posm[i]), b);
+        sweep<COLOR || DENS>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
         if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
-        if (COLOR) colorGrad[i] = div3s(b.cg, max_eps(b.cden));
+        if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
         if (DENS) {
             density[i] = b.den;
             float p = stiff * (pow7(b.den / rho0) - 1.0f);
@@ -94,26 +127,30 @@ struct OpSurface {
     SweepCtx c;
     const float3* colorGrad; const float3* velIn; const float3* addend; float3* velOut;
     float rho0, tension, airPressure, dt;
+    using Field = float4;   // neighbour colour gradient
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.cg4[j]; }
     struct Body {
         const OpSurface& o; float dii, li, ml; float3 a;
-        __device__ __forceinline__ void pair(int idx, bool, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field cg4, bool, float3 d, float r2, float mj, int)
         {
             const float r = sqrtf(r2);
             const float q = q_of(r, o.c.k);
-            const float3 cgj = o.colorGrad[idx];
+            const float3 cgj = xyz(cg4);
             a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad(d, r, o.c.k)));
             a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW(d, q, o.c.k)), li), ml));
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         const float3 cgi = colorGrad[i];
         const float li = len3(cgi);
         Body b{*this, dot3(cgi, cgi), li, max_eps(li), v3(0, 0, 0)};
-        sweep<false>(c, i, xyz(c.posm[i]), b);
+        sweep<false>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
-        velOut[i] = add3(v, mul3s(b.a, dt));
+        const float3 vn = add3(v, mul3s(b.a, dt));
+        velOut[i] = vn;
+        c.vel4[i] = f4(vn);
     }
 };
 
@@ -122,19 +159,20 @@ struct OpPressureForce {
     SweepCtx c;
     const float* pterm; float3* vel;
     float dt;
+    using Field = float;    // neighbour p_j / max(EPS, rho_j^2)
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : pterm[j]; }
     struct Body {
         const OpPressureForce& o; int i; float pti; float3 a;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field ptj, bool isB, float3 d, float r2, float mj, int idx)
         {
             if (!isB && idx == i) return;
-            const float ptj = isB ? 0.0f : o.pterm[idx];
             a = add3(a, smul3(-mj * (pti + ptj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, i, pterm[i], v3(0, 0, 0)};
-        sweep<true>(c, i, xyz(c.posm[i]), b);
+        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
         float3 a = b.a;
         if (len3(a) > kMaxA) a = mul3s(mul3s(a, 1.0f / sqrtf(dot3(a, a))), kMaxA);
         vel[i] = add3(vel[i], mul3s(a, dt));
@@ -173,10 +211,12 @@ struct OpDfsphHead {
     SweepCtx c;
     const float3* vel; float* density; float* alpha;
     RateOut out;
+    using Field = float4;   // neighbour velocity
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return (vel && !isB) ? c.vel4[j] : f4zero(); }
     struct Body {
         const OpDfsphHead& o; float3 vi; float den, sl, e; float3 gs;
         bool withRate;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float q = q_of(sqrtf(r2), o.c.k);
             den += mj * kW(q, o.c.k);
@@ -184,21 +224,20 @@ struct OpDfsphHead {
             const float3 gr = smul3(mj, gw);
             gs = add3(gs, gr);
             if (!isB) sl += dot3(gr, gr);
-            if (withRate) {
-                const float3 vj = isB ? v3(0, 0, 0) : o.vel[idx];
-                e += mj * dot3(sub3(vi, vj), gw);
-            }
+            if (withRate) e += mj * dot3(sub3(vi, xyz(vj)), gw);
         }
     };
 };
-template <bool WITH_RATE>
-__global__ void __launch_bounds__(256) k_dfsph_head(const OpDfsphHead o, int n)
+template <bool WITH_RATE, bool TILED>
+__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_dfsph_head(const OpDfsphHead o, int n)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ TileLds<OpDfsphHead, TILED> lds;
+    const bool tiled = stage_tile<OpDfsphHead, TILED>(o, o.c, lds);
+    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
     long long fixed = 0;
     if (i < n) {
         OpDfsphHead::Body b{o, WITH_RATE ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
-        sweep<true>(o.c, i, xyz(o.c.posm[i]), b);
+        sweep<true>(o, o.c, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr, i, xyz(o.c.posm[i]), b);
         const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
         o.density[i] = b.den;
         o.alpha[i] = al;
@@ -206,53 +245,75 @@ __global__ void __launch_bounds__(256) k_dfsph_head(const OpDfsphHead o, int n)
     }
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
+template <bool WITH_RATE>
+inline void launch_dfsph_head(const OpDfsphHead& o, int n)
+{
+    if (n <= 0) return;
+    if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(o, n);
+    else k_dfsph_head<WITH_RATE, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
+}
 
 // stand-alone rate sweep: e = sum_f m_j (v_i - v_j).gradW + sum_b m_j v_i.gradW
+// (boundaries are staged with v_j = +0: v_i - 0 == v_i)
 struct OpRate {
     SweepCtx c;
     const float3* vel; const float* density; const float* alpha;
     RateOut out;
+    using Field = float4;   // neighbour velocity
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
     struct Body {
         const OpRate& o; float3 vi; float e;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field vj, bool, float3 d, float r2, float mj, int)
         {
-            const float3 vj = isB ? v3(0, 0, 0) : o.vel[idx];
-            e += mj * dot3(sub3(vi, vj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k));
+            e += mj * dot3(sub3(vi, xyz(vj)), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k));
         }
     };
 };
-template <bool DENSITY_MODE, int WARM>
-__global__ void __launch_bounds__(256) k_rate(const OpRate o, int n)
+template <bool DENSITY_MODE, int WARM, bool TILED>
+__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_rate(const OpRate o, int n)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ TileLds<OpRate, TILED> lds;
+    const bool tiled = stage_tile<OpRate, TILED>(o, o.c, lds);
+    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
     long long fixed = 0;
     if (i < n) {
         OpRate::Body b{o, o.vel[i], 0.0f};
-        sweep<true>(o.c, i, xyz(o.c.posm[i]), b);
+        sweep<true>(o, o.c, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr, i, xyz(o.c.posm[i]), b);
         fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     }
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
+template <bool DENSITY_MODE, int WARM>
+inline void launch_rate_kernel(const OpRate& o, int n)
+{
+    if (n <= 0) return;
+    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(o, n);
+    else k_rate<DENSITY_MODE, WARM, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
+}
 
 // correctDivergenceError_CUDA (DFSPHSolver.cu:308-329) / correctDensityError_CUDA (:138-158)
+// (boundaries are staged with kappa_j = +0: kappa_i + 0 == kappa_i)
 template <bool DIVIDE_BY_DT>
 struct OpCorrect {
     SweepCtx c;
     const float* kappa; float3* vel;
     float dt;
+    using Field = float;    // neighbour stiffness
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : kappa[j]; }
     struct Body {
         const OpCorrect& o; float ki; float3 a;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field kj, bool, float3 d, float r2, float mj, int)
         {
-            const float kj = isB ? 0.0f : o.kappa[idx];
             a = add3(a, smul3(mj * (ki + kj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, kappa[i], v3(0, 0, 0)};
-        sweep<true>(c, i, xyz(c.posm[i]), b);
-        vel[i] = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
+        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        const float3 vn = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
+        vel[i] = vn;
+        c.vel4[i] = f4(vn);
     }
 };
 
@@ -263,9 +324,11 @@ struct OpLambda {
     SweepCtx c;
     float* density; float* lambda;
     float rho0, rb, relaxation;
+    using Field = float;    // unused
+    __device__ __forceinline__ Field stage(bool, int) const { return 0.0f; }
     struct Body {
         const OpLambda& o; float den, sl; float3 gs;
-        __device__ __forceinline__ void pair(int, bool, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field, bool, float3 d, float r2, float mj, int)
         {
             const float q = q_of(sqrtf(r2), o.c.k);
             den += mj * kW(q, o.c.k);
@@ -275,10 +338,10 @@ struct OpLambda {
             sl += dot3(gr, gr);
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
-        sweep<true>(c, i, xyz(c.posm[i]), b);
+        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
         density[i] = b.den;
         float lam = (b.den > rho0) ? (-(b.den / rho0 - 1.0f) / (dot3(b.gs, b.gs) + b.sl + kEps)) : 0.0f;
         lam *= relaxation;
@@ -286,23 +349,24 @@ struct OpLambda {
     }
 };
 
-// computeDeltaPos_CUDA, PBDSolver.cu:170-210
+// computeDeltaPos_CUDA, PBDSolver.cu:170-210 (boundaries: lambda_j = +0)
 struct OpDeltaPos {
     SweepCtx c;
     const float* lambda; float3* deltaPos;
     float rho0;
+    using Field = float;    // neighbour lambda
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : lambda[j]; }
     struct Body {
         const OpDeltaPos& o; float li; float3 a;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field lj, bool, float3 d, float r2, float mj, int)
         {
-            const float lj = isB ? 0.0f : o.lambda[idx];
             a = add3(a, smul3(mj * (li + lj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, lambda[i], v3(0, 0, 0)};
-        sweep<true>(c, i, xyz(c.posm[i]), b);
+        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
         deltaPos[i] = div3s(b.a, rho0);
     }
 };
@@ -314,13 +378,15 @@ struct OpXsph {
     SweepCtx c;
     const float3* vel; float3* velOut; float3* colorGrad;
     float xsphC, rho0, rhoB;
+    using Field = float4;   // neighbour velocity
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
     struct Body {
         const OpXsph& o; float3 vi; float3 a; float3 cg; float cden;
-        __device__ __forceinline__ void pair(int idx, bool isB, float3 d, float r2, float mj)
+        __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float q = q_of(sqrtf(r2), o.c.k);
             const float w = kW(q, o.c.k);
-            if (!isB) a = add3(a, mul3s(smul3(mj, sub3(o.vel[idx], vi)), w));
+            if (!isB) a = add3(a, mul3s(smul3(mj, sub3(xyz(vj), vi)), w));
             if (COLOR) {
                 const float vol = mj / (isB ? o.rhoB : o.rho0);
                 cg = add3(cg, smul3(vol, kGradW(d, q, o.c.k)));
@@ -328,25 +394,40 @@ struct OpXsph {
             }
         }
     };
-    __device__ void operator()(int i) const
+    __device__ void operator()(int i, const float4* lp, const Field* lf) const
     {
         Body b{*this, vel[i], v3(0, 0, 0), v3(0, 0, 0), 0.0f};
-        sweep<COLOR>(c, i, xyz(c.posm[i]), b);
-        velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));
-        if (COLOR) colorGrad[i] = div3s(b.cg, max_eps(b.cden));
+        sweep<COLOR>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));   // not the live velocity yet: vel4 untouched
+        if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
     }
 };
 
 // =================================================================================== element-wise
-static __global__ void k_add_const3(float3* __restrict__ v, float3 c, int n)
+// velocity writers also refresh the aligned mirror vel4 (may be nullptr for non-velocity arrays)
+static __global__ void k_add_const3(float3* __restrict__ v, float4* __restrict__ v4, float3 c, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = add3(v[i], c);
+    if (i >= n) return;
+    const float3 r = add3(v[i], c);
+    v[i] = r;
+    if (v4) v4[i] = make_float4(r.x, r.y, r.z, 0.0f);
 }
-static __global__ void k_add3(float3* __restrict__ v, const float3* __restrict__ w, int n)
+static __global__ void k_add3(float3* __restrict__ v, float4* __restrict__ v4, const float3* __restrict__ w, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = add3(v[i], w[i]);
+    if (i >= n) return;
+    const float3 r = add3(v[i], w[i]);
+    v[i] = r;
+    if (v4) v4[i] = make_float4(r.x, r.y, r.z, 0.0f);
+}
+static __global__ void k_copy3_mirror(float3* __restrict__ v, float4* __restrict__ v4, const float3* __restrict__ src, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 r = src[i];
+    v[i] = r;
+    v4[i] = make_float4(r.x, r.y, r.z, 0.0f);
 }
 // pack (x,y,z,mass) and apply the gravity kick vel += dv in the same pass (BasicSPHSolver.cu:227-235)
 static __global__ void k_pack_kick(float4* __restrict__ posm, const float3* __restrict__ pos, const float* __restrict__ mass,
@@ -396,20 +477,28 @@ static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __r
     posm[i] = make_float4(p.x, p.y, p.z, posm[i].w);
 }
 // vel = (pos - posLast) / dt, PBDSolver.cu:55-60
-static __global__ void k_velocity_from_displacement(float3* __restrict__ vel, const float3* __restrict__ pos,
-                                                    const float3* __restrict__ posLast, float dt, int n)
+static __global__ void k_velocity_from_displacement(float3* __restrict__ vel, float4* __restrict__ vel4,
+                                                    const float3* __restrict__ pos, const float3* __restrict__ posLast,
+                                                    float dt, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) vel[i] = div3s(sub3(pos[i], posLast[i]), dt);
+    if (i >= n) return;
+    const float3 r = div3s(sub3(pos[i], posLast[i]), dt);
+    vel[i] = r;
+    vel4[i] = make_float4(r.x, r.y, r.z, 0.0f);
 }
 
-inline void launch_add_const3(float3* v, float3 c, int n)
+inline void launch_add_const3(float3* v, float4* v4, float3 c, int n)
 {
-    if (n > 0) k_add_const3<<<blocks_for(n), 256, 0, stream()>>>(v, c, n);
+    if (n > 0) k_add_const3<<<blocks_for(n), 256, 0, stream()>>>(v, v4, c, n);
 }
-inline void launch_add3(float3* v, const float3* w, int n)
+inline void launch_add3(float3* v, float4* v4, const float3* w, int n)
 {
-    if (n > 0) k_add3<<<blocks_for(n), 256, 0, stream()>>>(v, w, n);
+    if (n > 0) k_add3<<<blocks_for(n), 256, 0, stream()>>>(v, v4, w, n);
+}
+inline void launch_copy3_mirror(float3* v, float4* v4, const float3* src, int n)
+{
+    if (n > 0) k_copy3_mirror<<<blocks_for(n), 256, 0, stream()>>>(v, v4, src, n);
 }
 inline void launch_pack_kick(float4* posm, const float3* pos, const float* mass, float3* vel, float3 dv, int n)
 {
@@ -427,9 +516,9 @@ inline void launch_apply_delta_clamp(float3* pos, float4* posm, const float3* dp
 {
     if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, dpos, space, n);
 }
-inline void launch_velocity_from_displacement(float3* vel, const float3* pos, const float3* posLast, float dt, int n)
+inline void launch_velocity_from_displacement(float3* vel, float4* vel4, const float3* pos, const float3* posLast, float dt, int n)
 {
-    if (n > 0) k_velocity_from_displacement<<<blocks_for(n), 256, 0, stream()>>>(vel, pos, posLast, dt, n);
+    if (n > 0) k_velocity_from_displacement<<<blocks_for(n), 256, 0, stream()>>>(vel, vel4, pos, posLast, dt, n);
 }
 
 }  // namespace sphx

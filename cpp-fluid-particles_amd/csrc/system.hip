@@ -5,6 +5,7 @@
 // Reference behaviour restated (never copied): src/Particles.h:22-25, src/Particles.cu:28-36,
 // src/SPHParticles.h:22-29, src/SPHSystem.cu:33-158, src/CUDAFunctions.cuh:56-78.
 #include <algorithm>
+#include <cstdlib>
 #include <iostream>
 
 #include "SPHSystem.h"
@@ -345,7 +346,7 @@ float SPHSystem::stepN(int n)
     hipStream_t st = sphx::stream();
     float extra = 0.0f;
     if (_graph->stepsRun == 0) { extra = step(); --n; if (n == 0) return extra; }
-    const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled;
+    const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
     if (wantGraph && !_graph->exec && !_graph->tried) {
         _graph->tried = true;
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;

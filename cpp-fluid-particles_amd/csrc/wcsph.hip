@@ -30,7 +30,7 @@ void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, floa
     const int n = (int)fluids->size();
     const float3 dv = make_float3(dt * G.x, dt * G.y, dt * G.z);
     ScopedKernel t("force");
-    launch_add_const3(fluids->getVelPtr(), dv, n);
+    launch_add_const3(fluids->getVelPtr(), cache().vel4w(), dv, n);
 }
 
 // BasicSPHSolver::advect, BasicSPHSolver.cu:98-101 (+ Particles::advect): pos += dt*vel, then the
@@ -61,7 +61,7 @@ void BasicSPHSolver::diffuse(std::shared_ptr<SPHParticles>& fluids, const DArray
     }
     {
         ScopedKernel t("add_delta_v");
-        launch_add3(fluids->getVelPtr(), bufferFloat3.addr(), n);
+        launch_add3(fluids->getVelPtr(), c.vel4w(), bufferFloat3.addr(), n);
     }
 }
 
@@ -163,7 +163,7 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
             launch_op(op, n);
         }
         ScopedKernel t("add_delta_v");
-        launch_add3(fluids->getVelPtr(), c.aux3.addr(), n);
+        launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), n);
     }
     {
         ScopedKernel t("pressure_force");

@@ -26,7 +26,7 @@ EXPORTS = [
     "sphx_scene_params", "sphx_scene_counts", "sphx_scene_fill", "sphx_create", "sphx_destroy",
     "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
-    "sphx_generate_dots",
+    "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
         L.sphx_eval_kernels.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         L.sphx_ieee_probe.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
         L.sphx_generate_dots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
+        L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.sphx_sizeof_params() != C.sizeof(Params):
             raise SphxError("sphx_params layout mismatch between sphx.py and libsphx.so")
         _lib = L
@@ -185,6 +187,20 @@ class System:
             self.close()
         except Exception:
             pass
+
+
+def kernel_timer(enable, name_filter=""):
+    _check(lib().sphx_kernel_timer(int(enable), name_filter.encode()))
+
+
+def kernel_timer_collect(cap=64):
+    """{span name: (total_ms, launches)} since kernel_timer(True, ...)"""
+    names = (C.c_char * 48 * cap)()
+    ms = (C.c_float * cap)()
+    cnt = (C.c_int * cap)()
+    k = C.c_int()
+    _check(lib().sphx_kernel_timer_collect(cap, names, ms, cnt, C.byref(k)))
+    return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(k.value)}
 
 
 def eval_kernels(r3, radius):

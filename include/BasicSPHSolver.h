@@ -30,7 +30,8 @@ public:
     bool graphSafe() const override { return true; }
     // engine extensions: the colour gradient left by handleSurface(), and engine switches used by
     // the tests (bit 0: run the reference-structure, unfused sequence of building blocks;
-    // bit 1: walk the 27 cells directly instead of the per-step neighbour list)
+    // bit 1: walk the 27 cells directly instead of the per-step neighbour list;
+    // bit 2: stage neighbour ranges in LDS per 64-particle tile)
     const DArray<float3>& getColorGradient() const { return bufferFloat3; }
     void setEngineFlags(int flags);
 

@@ -62,7 +62,8 @@ typedef struct sphx_params {
     int   pow7_mode;           /* must be 0 (fp64 multiply chain for the Tait exponent) */
     int   xsph_mode;           /* must be 0 (Jacobi XSPH) */
     int   reserved[4];         /* reserved[0]: engine switches for tests (bit0 unfused schedule,
-                                  bit1 direct 27-cell walks instead of the neighbour list) */
+                                  bit1 direct 27-cell walks instead of the neighbour list,
+                                  bit2 LDS-staged 64-particle tiles) */
 } sphx_params;
 
 /* device-resident fields readable through sphx_get (host copy) / sphx_device_ptr (raw pointer) */
@@ -129,6 +130,12 @@ int  sphx_device_ptr(const sphx_system *sys, int field, void **device_ptr);
 
 /* per-kernel timing of the last sphx_profile_step: names/ms arrays of up to cap entries */
 int  sphx_profile_step(sphx_system *sys, int cap, char (*names)[48], float *ms, int *count);
+
+/* live per-kernel timing (bench.py roofline leg): hipEvents on the engine stream around each
+ * launch whose span name equals `filter` (NULL/"" = all).  While enabled sphx_step_n launches
+ * eagerly.  collect() synchronises and returns, per span name, total ms and launch count.       */
+int  sphx_kernel_timer(int enable, const char *filter);
+int  sphx_kernel_timer_collect(int cap, char (*names)[48], float *total_ms, int *launches, int *count);
 
 /* pointwise evaluation of the four smoothing kernels of CUDAFunctions.cuh:23-98 on the device
  * (device-function parity test): r3 = n displacement vectors, outputs W[n], gradW[3n],

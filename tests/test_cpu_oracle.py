@@ -1,0 +1,158 @@
+"""CPU tests (no GPU): the oracle against the known answers SURVEY.md §8(c) recorded from the
+reference's own sources, against the committed golden fixture, and basic kernel identities."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+
+def _stats(s, O):
+    d = s.get(O.F_DENSITY); p = s.get(O.F_POS); v = s.get(O.F_VEL)
+    return (d.mean(dtype=np.float64), d.min(), d.max(), p[:, 1].mean(dtype=np.float64),
+            np.sqrt((v.astype(np.float64) ** 2).sum(1)).max())
+
+
+def test_scene_is_the_reference_scene(oracle):
+    P, fluid, boundary = oracle.scene(24)
+    assert list(P.cells) == [25, 25, 25]
+    assert len(fluid) == 20736 and len(boundary) == 14408      # main.cpp:76-116
+    assert np.float32(P.cell_length) == np.float32(1.01) * (np.float32(2.0) * np.float32(0.02))
+    # first/last fluid particle of main.cpp:76-85 (i outer = y, j = x, k inner = z)
+    assert_bit_equal(fluid[0], np.array([0.27, 0.10, 0.27], np.float32), "first particle")
+    want_last = np.array([np.float32(0.27) + np.float32(0.02) * np.float32(23),
+                          np.float32(0.10) + np.float32(0.02) * np.float32(35),
+                          np.float32(0.27) + np.float32(0.02) * np.float32(23)], np.float32)
+    assert_bit_equal(fluid[-1], want_last, "last particle")
+    assert boundary.min() >= 0.005 - 1e-7 and boundary.max() <= 0.995 + 1e-7
+
+
+def test_known_answers_boundary_mass_and_wcsph(oracle):
+    """boundary mass mean/min/max; WCSPH(dt=0.001) after the ctor step and at step 50."""
+    P, fluid, boundary = oracle.scene(24)
+    P.solver = oracle.WCSPH; P.dt = 0.001
+    for mode in (0, 1):            # fp64-chain x^7 (engine contract) and libm powf (literal CPU build)
+        P.pow7_mode = mode
+        s = oracle.System(P, fluid, boundary)
+        bm = s.get(oracle.F_BMASS)
+        assert abs(bm.mean(dtype=np.float64) - 2.426257e-4) < 5e-10
+        assert abs(bm.min() - 2.231831e-4) < 5e-10 and abs(bm.max() - 3.246067e-4) < 5e-10
+        mean, lo, hi, my, _ = _stats(s, oracle)
+        assert abs(mean - 0.776389) < 1e-6 and abs(lo - 0.3450) < 1e-4 and abs(hi - 0.8158) < 1e-4
+        assert abs(my - 0.449990) < 1e-6
+        for _ in range(50):
+            s.step()
+        mean, lo, hi, my, vmax = _stats(s, oracle)
+        assert abs(mean - 0.778598) < 1e-6 and abs(my - 0.437005) < 1e-6 and abs(vmax - 0.5244) < 1e-4
+
+
+def test_known_answers_dfsph(oracle):
+    """DFSPH(dt=0.002) step 50: rho mean 0.784005, mean y 0.398021, |v|max 1.0354, (1,2)."""
+    P, fluid, boundary = oracle.scene(24)
+    P.solver = oracle.DFSPH
+    s = oracle.System(P, fluid, boundary)
+    for _ in range(50):
+        s.step()
+    mean, _, _, my, vmax = _stats(s, oracle)
+    assert abs(mean - 0.784005) < 1e-6 and abs(my - 0.398021) < 1e-6 and abs(vmax - 1.0354) < 1e-4
+    assert s.iters() == (1, 2)
+
+
+def test_known_answers_pbd(oracle):
+    """PBD(k=20) density all 0 after the ctor; step 20: rho mean 0.777972 ..."""
+    P, fluid, boundary = oracle.scene(24)
+    P.solver = oracle.PBD
+    for xs in (0, 1):              # Jacobi XSPH (engine contract) and serial in-place order
+        P.xsph_mode = xs
+        s = oracle.System(P, fluid, boundary)
+        assert not s.get(oracle.F_DENSITY).any()
+        for _ in range(20):
+            s.step()
+        mean, _, _, my, vmax = _stats(s, oracle)
+        assert abs(mean - 0.777972) < 1e-6 and abs(my - 0.441767) < 1e-6 and abs(vmax - 0.4146) < 1e-4
+
+
+def test_oracle_reproduces_golden_fixture(oracle):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dambreak_nx8.npz"))
+    for key, solver in (("wcsph", oracle.WCSPH), ("dfsph", oracle.DFSPH), ("pbd", oracle.PBD)):
+        P, fluid, boundary = oracle.scene(8)
+        P.solver = solver; P.pbd_iters = 4
+        s = oracle.System(P, fluid, boundary)
+        for _ in range(int(g["steps"])):
+            s.step()
+        assert_bit_equal(s.get(oracle.F_POS), g[key + "_pos"], key + " pos")
+        assert_bit_equal(s.get(oracle.F_DENSITY), g[key + "_density"], key + " density")
+        assert np.array_equal(s.get(oracle.F_CELL), g[key + "_cell"])
+        assert tuple(g[key + "_iters"]) == s.iters()
+
+
+def test_oracle_is_thread_count_invariant(oracle):
+    P, fluid, boundary = oracle.scene(8)
+    P.solver = oracle.DFSPH
+    out = []
+    for threads in (1, 4):
+        s = oracle.System(P, fluid, boundary, threads=threads)
+        for _ in range(5):
+            s.step()
+        out.append((s.get(oracle.F_POS), s.get(oracle.F_VEL), s.get(oracle.F_DENSITY)))
+    for a, b in zip(*out):
+        assert_bit_equal(a, b, "1 vs 4 threads")
+
+
+def test_grid_invariants(oracle):
+    """cell ids bit-exact rules: true division + truncation, x slowest, sentinel = C."""
+    P, fluid, boundary = oracle.scene(8)
+    P.solver = oracle.WCSPH
+    pos = fluid.copy()
+    pos[3] = [9.0, 0.1, 0.1]          # out of grid -> sentinel
+    s = oracle.System(P, pos, boundary, ctor_step=False)
+    C = P.cells[0] * P.cells[1] * P.cells[2]
+    sp = s.get(oracle.F_POS); cs = s.get(oracle.F_CELLSTART_F); ids = s.get(oracle.F_ID)
+    cl = np.float32(P.cell_length)
+    c3 = (sp / cl).astype(np.int32)
+    inside = ((c3 >= 0) & (c3 < np.array(P.cells[:], np.int32))).all(1)
+    want = np.where(inside, (c3[:, 0] * P.cells[1] + c3[:, 1]) * P.cells[2] + c3[:, 2], C)
+    assert np.all(np.diff(want) >= 0), "sorted by cell id"
+    assert want[-1] == C and ids[-1] == 3, "the out-of-grid particle sorts last"
+    assert cs[0] == 0 and cs[-1] == len(pos) - 1 and np.all(np.diff(cs) >= 0)
+    counts = np.bincount(want, minlength=C + 1)
+    assert np.array_equal(np.diff(cs), counts[:C]), "cellStart = exclusive scan of the histogram"
+    # stable: inside a cell, original indices ascend
+    for c in np.unique(want)[:50]:
+        seg = ids[want == c]
+        assert np.all(np.diff(seg) > 0)
+
+
+def test_kernel_identities(oracle):
+    R = np.float32(0.04)
+    rng = np.random.default_rng(3)
+    r3 = rng.uniform(-1.2 * R, 1.2 * R, (20000, 3)).astype(np.float32)
+    W, G, V, S = oracle.eval_kernels(r3, float(R))
+    r = np.sqrt((r3.astype(np.float64) ** 2).sum(1))
+    q = 2 * r / R
+    # support
+    assert not W[q > 2.0001].any() and not G[q > 2.0001].any() and not V[r > R * 1.0001].any() and not S[r > R * 1.0001].any()
+    # antisymmetry of the gradients
+    _, G2, _, S2 = oracle.eval_kernels(-r3, float(R))
+    assert np.array_equal(G2, -G), "gradW(-r) == -gradW(r)"          # (signed zeros compare equal)
+    assert np.array_equal(S2, -S), "surfGrad(-r) == -surfGrad(r)"
+    # closed forms in float64 (CUDAFunctions.cuh:23-50), loose tolerance
+    a = 0.25 / (np.pi * float(R) ** 3)
+    Wd = np.where(q > 2, 0, np.where(q > 1, a * (2 - q) ** 3, a * ((3 * q - 6) * q * q + 4)))
+    assert np.allclose(W, Wd, rtol=2e-5, atol=1e-3)
+    # W is continuous at q = 1 and vanishes at q = 2
+    e = np.array([[R / 2, 0, 0], [np.nextafter(R / 2, np.float32(1)), 0, 0], [R, 0, 0]], np.float32)
+    We = oracle.eval_kernels(e, float(R))[0]
+    assert abs(We[0] - We[1]) < 1e-3 * We[0] and We[2] == 0
+    # self term excluded
+    z = oracle.eval_kernels(np.zeros((1, 3), np.float32), float(R))
+    assert z[0][0] == 0 and not z[1].any() and not z[3].any()
+
+
+def test_fixed_iteration_mode_counts(oracle):
+    P, fluid, boundary = oracle.scene(8)
+    P.solver = oracle.DFSPH; P.dfsph_fixed_div = 3; P.dfsph_fixed_den = 5
+    s = oracle.System(P, fluid, boundary)
+    s.step()
+    assert s.iters() == (3, 5)
