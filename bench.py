@@ -74,7 +74,8 @@ def read_traffic(workload_key):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload_key)
+            entry = json.load(f).get(workload_key)
+            return entry["hbm_bytes_per_launch"] if entry else None
     except Exception:
         return None
 

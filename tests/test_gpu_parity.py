@@ -246,3 +246,26 @@ def test_full_size_properties_dfsph_1m(sphx):
     moved = np.count_nonzero(np.diff(cell2) < 0)
     assert moved < n // 100
     del cell
+
+
+def test_cpp_api_driver_matches_oracle(oracle, tmp_path):
+    """apps/sphx_demo is a main.cpp-style driver compiled against include/*.h (the C++ drop-in API,
+    default adaptive DFSPH exactly as main.cpp constructs it); its dump must equal the oracle."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "sphx_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "apps")])
+    out = str(tmp_path / "dump.bin")
+    subprocess.check_call([exe, "--solver", "dfsph", "--nx", "12", "--steps", "6", "--dump", out])
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    pos = np.frombuffer(raw[4:4 + 12 * n], np.float32).reshape(n, 3)
+    den = np.frombuffer(raw[4 + 12 * n:], np.float32)
+    P, fluid, boundary = oracle.scene(12)
+    P.solver = oracle.DFSPH
+    o = oracle.System(P, fluid, boundary)
+    for _ in range(6):
+        o.step()
+    assert_bit_equal(pos, o.get(oracle.F_POS), "demo pos")
+    assert_bit_equal(den, o.get(oracle.F_DENSITY), "demo density")

@@ -1,0 +1,61 @@
+"""Condenses rocprofv3 CSV output (kernel stats + FETCH_SIZE / WRITE_SIZE counter passes) into a text
+summary and gpurun_out/traffic_<tag>.json (per-launch HBM bytes of the dominant kernel)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+bench_args = sys.argv[3:]
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("sphx::", "").replace("(anonymous namespace)::", "")
+    return name[:110]
+
+
+print("rocprofv3 summary tag=%s bench_args=%s" % (tag, " ".join(bench_args)))
+ks = find("stats", "*kernel_stats.csv")
+if ks:
+    rows = list(csv.DictReader(open(ks)))
+    print("\n== kernel stats (rocprofv3 --kernel-trace --stats), %s" % os.path.basename(ks))
+    print("%-112s %8s %12s %8s" % ("kernel", "calls", "avg_us", "pct"))
+    for r in rows[:40]:
+        print("%-112s %8s %12.2f %8s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+else:
+    print("no kernel_stats.csv found")
+
+traffic = {}
+for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    cc = find(sub, "*counter_collection.csv")
+    if not cc:
+        print("no counter csv for", ctr)
+        continue
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(cc)):
+        if r.get("Counter_Name") != ctr:
+            continue
+        k = short(r["Kernel_Name"])
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    print("\n== %s per dispatch (raw counter units: KiB; gfx950 FETCH_SIZE under-reads wide streams by 2x)" % ctr)
+    for k, (tot, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:25]:
+        print("%-112s %6d launches  avg %12.1f KiB" % (k, n, tot / n))
+        if "k_rate<true" in k or "k_rate<(bool)1" in k:
+            traffic.setdefault("k_rate_density", {})[ctr] = tot / n * 1024.0
+if traffic:
+    kr = traffic["k_rate_density"]
+    fetch = kr.get("FETCH_SIZE"); write = kr.get("WRITE_SIZE")
+    if fetch is not None and write is not None:
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE reports 1/2 of wide coalesced streaming reads on gfx950; this
+        # kernel's reads are mostly 16-byte gathers + 4-byte coalesced rows, so both raw and x2 are reported
+        kr["hbm_bytes_raw"] = fetch + write
+        kr["hbm_bytes_fetch_x2"] = 2 * fetch + write
+    json.dump(traffic, open(os.path.join(os.path.dirname(out), "traffic_%s.json" % tag), "w"), indent=1)
+    print("\ntraffic:", json.dumps(traffic))
