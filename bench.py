@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--den-iters", type=int, default=4)
     ap.add_argument("--pbd-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-slab", action="store_true", help="run the x-slab driver even with one rank (debug)")
     ap.add_argument("--cpu-nx", type=int, default=40, help="bounded CPU sample: nx of the oracle run")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -95,7 +96,9 @@ def main():
     if sphx.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
 
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_slab:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from multi_gpu import run_slab_bench        # x-slab decomposition, torch.distributed (RCCL)
         result = run_slab_bench(args, rank, world, local_rank)
         if rank == 0:

@@ -174,7 +174,12 @@ int sphx_create(const sphx_params* P, const float* fluid, int n, const float* bo
     const float3 space = make_float3(P->space[0], P->space[1], P->space[2]);
     const float3 G = make_float3(P->gravity[0], P->gravity[1], P->gravity[2]);
     const int3 cells = make_int3(P->cells[0], P->cells[1], P->cells[2]);
-    if (run_ctor_step)
+    if (P->reserved[1] != 0 || P->reserved[2] != 0) {
+        if (run_ctor_step) return fail(SPHX_ERR_INVALID, "sphx_create: slab systems take run_ctor_step = 0");
+        h->system.reset(new SPHSystem(SPHSystem::Slab{P->reserved[1]}, fluids, walls, solver, space, P->cell_length, P->radius,
+                                      P->dt, P->m0, P->rho0, P->rho_boundary, P->stiff, P->visc, P->surface_tension,
+                                      P->air_pressure, G, cells));
+    } else if (run_ctor_step)
         h->system.reset(new SPHSystem(fluids, walls, solver, space, P->cell_length, P->radius, P->dt, P->m0, P->rho0,
                                       P->rho_boundary, P->stiff, P->visc, P->surface_tension, P->air_pressure, G, cells));
     else
@@ -254,6 +259,8 @@ static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
     case SPHX_F_POS_LAST: if (h->pbd) { p = h->pbd->getPosLast().addr(); sz = 12 * n; } else known = false; break;
     case SPHX_F_LAMBDA: if (h->pbd) { p = h->pbd->getLambda().addr(); sz = 4 * n; } else known = false; break;
     case SPHX_F_BUF3: if (h->wcsph) { p = h->wcsph->getColorGradient().addr(); sz = 12 * n; } else known = false; break;
+    case SPHX_F_VEL4: if (h->wcsph) { p = h->wcsph->engineVel4(); sz = 16 * n; } else known = false; break;
+    case SPHX_F_CG4: if (h->wcsph) { p = h->wcsph->engineCg4(); sz = 16 * n; } else known = false; break;
     default: known = false; break;
     }
     if (!known) return SPHX_ERR_INVALID;
@@ -289,7 +296,8 @@ int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
 
 int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
 {
-    if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM) return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
+    if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM && field != SPHX_F_BMASS)
+        return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
     void* p; size_t sz;
     if (!h || !src || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
     if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
@@ -297,6 +305,37 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
     if (hipMemcpyAsync(p, src, sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
         hipStreamSynchronize(sphx::stream()) != hipSuccess)
         return fail(SPHX_ERR_HIP, "sphx_set: copy failed");
+    if (field == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
+    return SPHX_OK;
+}
+
+int sphx_run_phase(sphx_system* h, int phase)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "sphx_run_phase: null system");
+    try {
+        h->system->phase(phase);
+    } catch (const char* msg) {
+        return fail(SPHX_ERR_STATE, msg);
+    }
+    return SPHX_OK;
+}
+
+int sphx_set_count(sphx_system* h, int n_fluid)
+{
+    if (!h || n_fluid < 0 || n_fluid > h->n) return fail(SPHX_ERR_INVALID, "sphx_set_count: count exceeds the capacity given to sphx_create");
+    h->system->getFluids()->setActiveCount((unsigned)n_fluid);
+    return SPHX_OK;
+}
+
+int sphx_use_stream(void* hip_stream)
+{
+    sphx::use_external_stream(reinterpret_cast<hipStream_t>(hip_stream));
+    return SPHX_OK;
+}
+
+int sphx_sync(void)
+{
+    if (hipStreamSynchronize(sphx::stream()) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_sync failed");
     return SPHX_OK;
 }
 
@@ -373,6 +412,14 @@ __global__ void k_eval_kernels(const float3* __restrict__ r3, int n, KernelConst
     G[i] = kGradW(d, q, k);
     V[i] = kViscLap(r, k);
     S[i] = kSurfGrad(d, r, k);
+}
+
+// global cell column of each position: exactly the expression of cell_of() (true fp32 division,
+// truncation), for drivers that must agree with the engine on which column a particle is in
+__global__ void k_cell_columns(const float3* __restrict__ pos, int n, float cellLength, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)(pos[i].x / cellLength);
 }
 
 __global__ void k_ieee_probe(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int n,
@@ -456,6 +503,14 @@ int sphx_ieee_probe(const float* a, const float* b, const float* c, int n, float
     HIP_CALL(hipMemcpyAsync(trunc, dt.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_CALL(hipMemcpyAsync(muladd, dm.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_ieee_probe failed");
+    return SPHX_OK;
+}
+
+int sphx_cell_columns(const float* device_xyz, int n, float cell_length, int* device_out)
+{
+    if (n <= 0) return SPHX_OK;
+    if (!device_xyz || !device_out) return fail(SPHX_ERR_INVALID, "sphx_cell_columns: bad argument");
+    k_cell_columns<<<blocks_for(n), 256, 0, sphx::stream()>>>(reinterpret_cast<const float3*>(device_xyz), n, cell_length, device_out);
     return SPHX_OK;
 }
 

@@ -11,6 +11,7 @@
 #include "DFSPHSolver.h"
 #include "engine.hpp"
 #include "sweep_ops.hpp"
+#include "sphx_c.h"
 
 using namespace sphx;
 
@@ -177,39 +178,140 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         advect(fluids, dt, spaceSize);
         return;
     }
-    // fused schedule: [density+alpha+first divergence error] -> divergence loop -> gravity ->
-    // [viscosity+colour gradient] -> [surface (+ vel += deltaV)] -> density solve -> advect
+    // fused schedule, stage by stage (the same stages a distributed driver runs through
+    // SPHSystem::phase with halo refreshes in between):
+    //   prepare -> [density+alpha+first divergence error] -> divergence loop -> gravity ->
+    //   [viscosity+colour gradient] -> [surface (+ vel += deltaV)] -> density solve -> advect
+    auto run = [&](int ph, bool reduce = false) {
+        runPhase(ph, fluids, boundaries, cellStartFluid, cellStartBoundary, spaceSize, cellSize, cellLength, radius, dt, rho0,
+                 rhoB, visc, G, surfaceTensionIntensity, airPressure, reduce);
+    };
+    run(SPHX_PH_SEARCH);
+    run(SPHX_PH_HEAD);
+    {
+        const bool adaptive = fixedDiv < 0;
+        auto totalError = std::numeric_limits<float>::max();
+        int iter = 0;
+        while (adaptive ? ((iter < 1 || totalError > divergenceErrorThreshold * num * rho0) && iter < maxIter) : (iter < fixedDiv)) {
+            run(SPHX_PH_DIV_CORRECT);
+            run(SPHX_PH_DIV_ERROR, adaptive);
+            ++iter;
+            if (adaptive) totalError = readErrorTotal();
+        }
+        lastDiv = iter;
+    }
+    run(SPHX_PH_FORCE);
+    run(SPHX_PH_VISC_COLOR);
+    run(SPHX_PH_SURFACE);
+    run(SPHX_PH_WARM_CORRECT);
+    run(SPHX_PH_DEN_ERROR_SET);
+    {
+        const bool adaptive = fixedDen < 0;
+        auto totalError = std::numeric_limits<float>::max();
+        int iter = 0;
+        while (adaptive ? ((iter < 2 || totalError > densityErrorThreshold * num * rho0) && iter < maxIter) : (iter < fixedDen)) {
+            run(SPHX_PH_DEN_CORRECT);
+            ++iter;
+            const bool needTotal = adaptive && iter >= 2;
+            run(SPHX_PH_DEN_ERROR_ACC, needTotal);
+            if (needTotal) totalError = readErrorTotal();
+        }
+        lastDen = iter;
+    }
+    run(SPHX_PH_ADVECT);
+}
+
+// One stage of the fused schedule.  Reference stages: DFSPHSolver.cu:33-72 (order), :160-210 and
+// :331-363 (the two solver loops whose bodies are the CORRECT / ERROR stages).
+void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
+                           const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float3 spaceSize,
+                           int3 cellSize, float cellLength, float radius, float dt, float rho0, float rhoB, float visc,
+                           float3 G, float surfaceTensionIntensity, float airPressure, bool reduce)
+{
+    SweepCache& c = cache();
+    const int num = (int)fluids->size();
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
+    if (phase == SPHX_PH_SEARCH) {
+        invalidatePositions();
+        c.setup(cellSize, cellLength, radius);
+        c.packFluid(*fluids);
+        c.packBoundary(*boundaries);
+        c.ensureList(cellStartFluid, cellStartBoundary);
+        ScopedKernel t("warm_permute");   // DFSPHSolver.cu:170-171
+        ew_gather_float(scratch.addr(), denWarmStiff.addr(), fluids->getSortPerm(), num);
+        ew_copy(denWarmStiff.addr(), scratch.addr(), sizeof(float) * num);
+        return;
+    }
+    if (phase == SPHX_PH_FORCE) { force(fluids, dt, G); return; }
+    if (phase == SPHX_PH_ADVECT) { advect(fluids, dt, spaceSize); return; }
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
     c.ensureList(cellStartFluid, cellStartBoundary);
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
-    if (num > 0) {
+    unsigned long long* accum = reduce ? reinterpret_cast<unsigned long long*>(errorAccum.addr()) : nullptr;
+    DArray<float3>& cg = colorGradientBuffer();
+    switch (phase) {
+    case SPHX_PH_HEAD: {
         ScopedKernel t("density_alpha_diverr");
         OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                        RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0}};
         launch_dfsph_head<true>(op, num);
+        break;
     }
-    headDidFirstError = true;
-    lastDiv = correctDivergenceError(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength,
-                                     radius, dt, divergenceErrorThreshold, maxIter);
-    force(fluids, dt, G);
-    DArray<float3>& cg = colorGradientBuffer();
-    if (surface) {
-        {
+    case SPHX_PH_DIV_CORRECT: {
+        ScopedKernel t("divergence_correct");
+        launch_op(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt}, num);
+        break;
+    }
+    case SPHX_PH_DIV_ERROR: {
+        ScopedKernel t("divergence_error");
+        launch_rate<false, 0>(OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0}}, num, reduce);
+        break;
+    }
+    case SPHX_PH_VISC_COLOR: {
+        if (surface) {
             ScopedKernel t("visc_color");
-            OpFluidProps<true, true, false> op{ctx, fluids->getVelPtr(), c.aux3.addr(), cg.addr(), nullptr, nullptr, nullptr,
-                                               rho0, rhoB, visc, dt, 0.0f};
-            launch_op(op, num);
+            launch_op(OpFluidProps<true, true, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), cg.addr(), nullptr, nullptr,
+                                                      nullptr, rho0, rhoB, visc, dt, 0.0f}, num);
+        } else {
+            ScopedKernel t("viscosity");
+            launch_op(OpFluidProps<true, false, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), nullptr, nullptr, nullptr,
+                                                       nullptr, rho0, rhoB, visc, dt, 0.0f}, num);
         }
-        ScopedKernel t("surface_tension");
-        OpSurface op{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0, surfaceTensionIntensity,
-                     airPressure, dt};
-        launch_op(op, num);
-    } else {
-        BasicSPHSolver::diffuse(fluids, cellStartFluid, cellSize, cellLength, rho0, radius, visc, dt);
+        break;
     }
-    lastDen = project(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength, radius, dt,
-                      densityErrorThreshold, maxIter);
-    advect(fluids, dt, spaceSize);
+    case SPHX_PH_SURFACE: {
+        if (surface) {
+            ScopedKernel t("surface_tension");
+            launch_op(OpSurface{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0,
+                                surfaceTensionIntensity, airPressure, dt}, num);
+        } else {
+            ScopedKernel t("add_delta_v");
+            launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), num);
+        }
+        break;
+    }
+    case SPHX_PH_WARM_CORRECT: {
+        ScopedKernel t("density_correct");
+        launch_op(OpCorrect<true>{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt}, num);
+        break;
+    }
+    case SPHX_PH_DEN_CORRECT: {
+        ScopedKernel t("density_correct");
+        launch_op(OpCorrect<true>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt}, num);
+        break;
+    }
+    case SPHX_PH_DEN_ERROR_SET:
+    case SPHX_PH_DEN_ERROR_ACC: {
+        ScopedKernel t("density_error");
+        const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                          RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0}};
+        if (phase == SPHX_PH_DEN_ERROR_SET) launch_rate<true, 1>(rate, num, reduce);
+        else launch_rate<true, 2>(rate, num, reduce);
+        break;
+    }
+    default: throw "DFSPHSolver::runPhase: unknown stage";
+    }
 }

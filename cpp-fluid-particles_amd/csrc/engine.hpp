@@ -16,7 +16,7 @@ namespace sphx {
 // tests (q > 2, r <= R, x > R) are monotone in r2 because correctly-rounded sqrt and division are
 // monotone, so "largest r2 that passes" is an exact threshold.
 KernelConsts make_kernel_consts(float radius);
-GridDesc make_grid_desc(int3 cellSize, float cellLength);
+GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 
 // Per-solver packed views of the particle sets and the per-step neighbour list, refreshed when
 // positions move.
@@ -43,6 +43,7 @@ struct SweepCache {
     std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
     int nb = 0;
     int cap = 96;
+    int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)
     int flags = 0;
     bool fluidValid = false;
     bool boundaryValid = false;
@@ -103,6 +104,7 @@ void ew_copy(void* dst, const void* src, size_t bytes);
 void ew_fill_float(float* dst, float value, int n);
 void ew_iota(int* dst, int n);
 
+void use_external_stream(hipStream_t s);
 const std::string& last_error_text();
 void set_error_text(const std::string& s);
 

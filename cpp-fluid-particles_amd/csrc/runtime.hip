@@ -15,8 +15,13 @@ static std::once_flag g_stream_once;
 static thread_local std::string g_last_error;
 static std::string g_last_error_global;
 
+static hipStream_t g_external_stream = nullptr;
+static bool g_use_external = false;
+void use_external_stream(hipStream_t s) { g_external_stream = s; g_use_external = true; }
+
 hipStream_t stream()
 {
+    if (g_use_external) return g_external_stream;
     std::call_once(g_stream_once, [] {
         if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr;
     });
@@ -68,11 +73,12 @@ KernelConsts make_kernel_consts(float R)
     return k;
 }
 
-GridDesc make_grid_desc(int3 cs, float cellLength)
+GridDesc make_grid_desc(int3 cs, float cellLength, int cellOffsetX)
 {
     GridDesc g;
     g.gx = cs.x; g.gy = cs.y; g.gz = cs.z; g.C = cs.x * cs.y * cs.z;
     g.cellLength = cellLength;
+    g.xOff = cellOffsetX;
     return g;
 }
 
@@ -204,8 +210,9 @@ SweepCache::SweepCache(int num)
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
 {
     if (radius != radiusKey) { k = make_kernel_consts(radius); radiusKey = radius; }
+    g.xOff = cellOffsetX;
     if (cellLength != cellKey || cellSize.x != cellsKey.x || cellSize.y != cellsKey.y || cellSize.z != cellsKey.z) {
-        g = make_grid_desc(cellSize, cellLength);
+        g = make_grid_desc(cellSize, cellLength, cellOffsetX);
         cellKey = cellLength; cellsKey = cellSize;
     }
 }
@@ -213,6 +220,7 @@ void SweepCache::setup(int3 cellSize, float cellLength, float radius)
 void SweepCache::packFluid(const SPHParticles& fluids)
 {
     if (fluidValid) return;
+    n = (int)fluids.size();
     ScopedKernel t("pack_fluid");
     if (n > 0)
         k_pack_fluid<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), n);
@@ -222,6 +230,7 @@ void SweepCache::packFluid(const SPHParticles& fluids)
 
 void SweepCache::packFluidKick(const SPHParticles& fluids, float3 dv)
 {
+    n = (int)fluids.size();
     ScopedKernel t("pack_kick");
     if (n > 0)
         k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), dv, n);

@@ -30,6 +30,7 @@ struct KernelConsts {
 struct GridDesc {
     int gx, gy, gz, C;   // cells per axis, C = gx*gy*gz (also the out-of-grid sentinel id)
     float cellLength;
+    int xOff;            // global x index of local cell column 0 (0 for a whole domain; slabs: x0-1)
 };
 
 // ---- float3 helpers with helper_math.h semantics (explicit association) ----------------------
@@ -88,9 +89,10 @@ __device__ __forceinline__ float pow7(float x)
 }
 
 // particlePos2cellIdx + make_int3(pos / cellLength), CUDAFunctions.cuh:64-78
-__device__ __forceinline__ int3 cell_of(float3 p, float cellLength)
+// (local coordinates: the global x index minus g.xOff, so a slab's sub-grid sees the same cells)
+__device__ __forceinline__ int3 cell_of(float3 p, const GridDesc& g)
 {
-    return make_int3((int)(p.x / cellLength), (int)(p.y / cellLength), (int)(p.z / cellLength));
+    return make_int3((int)(p.x / g.cellLength) - g.xOff, (int)(p.y / g.cellLength), (int)(p.z / g.cellLength));
 }
 __device__ __forceinline__ int cell_id(int x, int y, int z, const GridDesc& g)
 {
@@ -124,7 +126,7 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
                                         const float4* __restrict__ posmF, const int* __restrict__ csB,
                                         const float4* __restrict__ posmB, const float3 pi, Body& body)
 {
-    const int3 c0 = cell_of(pi, g.cellLength);
+    const int3 c0 = cell_of(pi, g);
     for (int dx = -1; dx <= 1; ++dx) {
         const int X = c0.x + dx;
         if (X < 0 || X >= g.gx) continue;
@@ -212,8 +214,8 @@ __device__ __forceinline__ bool tile_table(const SweepCtx& c, const int i0, Tile
 {
     const int lane = threadIdx.x;
     const int i1 = min(i0 + kTile, c.n);
-    const int3 cf = cell_of(xyz4(c.posm[i0]), c.g.cellLength);
-    const int3 cl = cell_of(xyz4(c.posm[i1 - 1]), c.g.cellLength);
+    const int3 cf = cell_of(xyz4(c.posm[i0]), c.g);
+    const int3 cl = cell_of(xyz4(c.posm[i1 - 1]), c.g);
     const int idF = cell_id(cf.x, cf.y, cf.z, c.g), idL = cell_id(cl.x, cl.y, cl.z, c.g);
     const bool ok = idF < c.g.C && idL < c.g.C && idF <= idL;
     int len = 0;
@@ -242,7 +244,7 @@ __device__ __forceinline__ bool tile_table(const SweepCtx& c, const int i0, Tile
 template <bool WANT_BOUNDARY, class Visit>
 __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, Visit&& visit)
 {
-    const int3 c0 = cell_of(pi, c.g.cellLength);
+    const int3 c0 = cell_of(pi, c.g);
     for (int dx = -1; dx <= 1; ++dx) {
         const int X = c0.x + dx;
         if (X < 0 || X >= c.g.gx) continue;
@@ -329,7 +331,7 @@ __device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, const floa
     const float3 pi = v3(self.x, self.y, self.z);
     unsigned int* row = nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
     int cnt = 0;
-    const int3 c0 = cell_of(pi, c.g.cellLength);
+    const int3 c0 = cell_of(pi, c.g);
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
     for (int dx = -1; dx <= 1; ++dx) {
         const int X = c0.x + dx;

@@ -409,9 +409,10 @@ static __global__ void k_add_const3(float3* __restrict__ v, float4* __restrict__
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float3 r = add3(v[i], c);
-    v[i] = r;
-    if (v4) v4[i] = make_float4(r.x, r.y, r.z, 0.0f);
+    v[i] = add3(v[i], c);
+    // the mirror is advanced from the mirror: for an owned particle both hold the same bits; for a
+    // slab's ghost particle only the mirror is kept current (halo refresh), and it must stay so
+    if (v4) { const float4 q = v4[i]; v4[i] = make_float4(q.x + c.x, q.y + c.y, q.z + c.z, 0.0f); }
 }
 static __global__ void k_add3(float3* __restrict__ v, float4* __restrict__ v4, const float3* __restrict__ w, int n)
 {

@@ -8,13 +8,15 @@
 #include <cstdlib>
 #include <iostream>
 
+#include "DFSPHSolver.h"
 #include "SPHSystem.h"
+#include "sphx_c.h"
 #include "engine.hpp"
 
 using namespace sphx;
 
 // ================================================================================ particle sets
-Particles::Particles(const std::vector<float3>& p) : pos((unsigned)p.size()), vel((unsigned)p.size())
+Particles::Particles(const std::vector<float3>& p) : pos((unsigned)p.size()), vel((unsigned)p.size()), _active((unsigned)p.size())
 {
     if (!p.empty()) {
         HIP_CALL(hipMemcpyAsync(pos.addr(), p.data(), sizeof(float3) * p.size(), hipMemcpyHostToDevice, sphx::stream()));
@@ -52,7 +54,8 @@ namespace sphx {
 struct GridScratch {
     explicit GridScratch(int maxParticles, int cells)
         : slot((unsigned)maxParticles), order((unsigned)maxParticles), tmp3((unsigned)maxParticles),
-          tmpi((unsigned)maxParticles), blockSums((unsigned)(cells / 2048 + 2)), posm(4u * (unsigned)maxParticles)
+          tmpi((unsigned)maxParticles), blockSums((unsigned)(std::max(cells, maxParticles) / 2048 + 2)),
+          posm(4u * (unsigned)maxParticles), outRank((unsigned)maxParticles + 1u)
     {
     }
     DArray<int> slot;       // arrival slot of particle i inside its cell (atomic order, arbitrary)
@@ -61,6 +64,7 @@ struct GridScratch {
     DArray<int> tmpi;
     DArray<int> blockSums;  // scan scratch
     DArray<float> posm;     // packed boundary positions for the boundary-mass sweep
+    DArray<int> outRank;    // stable rank of each out-of-grid particle inside the sentinel bucket
 };
 
 struct StepGraph {
@@ -84,7 +88,7 @@ __global__ void k_cell_and_count(int* __restrict__ p2c, int* __restrict__ slot, 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int3 c = cell_of(pos[i], g.cellLength);
+    const int3 c = cell_of(pos[i], g);
     const int id = cell_id(c.x, c.y, c.z, g);
     p2c[i] = id;
     slot[i] = atomicAdd(&counts[id], 1);
@@ -160,15 +164,27 @@ __global__ void k_place(int* __restrict__ order, const int* __restrict__ p2c, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[cellStart[p2c[i]] + slot[i]] = i;
 }
+// The out-of-grid sentinel bucket can hold any number of particles (a blown-up run, parked slots),
+// so its stable rank comes from an exclusive scan of the "is out of grid" flags instead of the
+// quadratic bucket loop.
+__global__ void k_flag_out_of_grid(int* __restrict__ flag, const int* __restrict__ p2c, int sentinel, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) flag[i] = (i < n && p2c[i] == sentinel) ? 1 : 0;
+}
 __global__ void k_stable_rank(int* __restrict__ perm, const int* __restrict__ order, const int* __restrict__ p2c,
-                              const int* __restrict__ cellStart, int n, int cellsPlusOne)
+                              const int* __restrict__ cellStart, const int* __restrict__ outRank, int n, int cellsPlusOne)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const int i = order[q];
     const int c = p2c[i];
     const int s = cellStart[c];
-    const int e = (c + 1 < cellsPlusOne) ? cellStart[c + 1] : n;   // sentinel bucket runs to n
+    if (c + 1 >= cellsPlusOne) {           // sentinel bucket
+        perm[s + outRank[i]] = i;
+        return;
+    }
+    const int e = cellStart[c + 1];
     int rank = 0;
     for (int t = s; t < e; ++t) rank += (order[t] < i) ? 1 : 0;
     perm[s + rank] = i;
@@ -231,18 +247,44 @@ SPHSystem::SPHSystem(NoInitialStep, std::shared_ptr<SPHParticles>& fluidParticle
     initialise(sphM0, false);
 }
 
+SPHSystem::SPHSystem(Slab slab, std::shared_ptr<SPHParticles>& fluidParticles,
+                     std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+                     const float3 spaceSize, const float sphCellLength, const float sphSmoothingRadius, const float dt,
+                     const float sphM0, const float sphRho0, const float sphRhoBoundary, const float sphStiff,
+                     const float sphVisc, const float sphSurfaceTensionIntensity, const float sphAirPressure,
+                     const float3 sphG, const int3 cellSize)
+    : SPHX_SYSTEM_INIT_LIST
+{
+    _cellOffsetX = slab.cellOffsetX;
+    _slab = true;
+    if (auto* s = dynamic_cast<BasicSPHSolver*>(_solver.get())) s->setCellOffsetX(slab.cellOffsetX);
+    initialise(sphM0, false);
+}
+
 SPHSystem::~SPHSystem() noexcept {}
+
+// one stage of the DFSPH step (distributed drivers; see sphx_phase)
+void SPHSystem::phase(int p)
+{
+    auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
+    if (!dfsph) throw "SPHSystem::phase: stage-wise stepping needs a DFSPHSolver";
+    if (p == SPHX_PH_SEARCH) neighborSearch(_fluids, cellStartFluid);
+    dfsph->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
+                    _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphVisc, _sphG, _sphSurfaceTensionIntensity,
+                    _sphAirPressure, false);
+    if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
+}
 
 // the constructor sequence of SPHSystem.cu:68-76
 void SPHSystem::initialise(float sphM0, bool runStep)
 {
     const int cells = _cellSize.x * _cellSize.y * _cellSize.z;
-    _grid.reset(new GridScratch(std::max(std::max(fluidSize(), boundarySize()), 1), cells));
+    _grid.reset(new GridScratch(std::max(std::max((int)_fluids->capacity(), (int)_boundaries->capacity()), 1), cells));
     _graph.reset(new StepGraph());
     neighborSearch(_boundaries, cellStartBoundary);
     computeBoundaryMass();
-    ew_fill_float(_fluids->getMassPtr(), sphM0, fluidSize());
-    neighborSearch(_fluids, cellStartFluid);
+    ew_fill_float(_fluids->getMassPtr(), sphM0, (int)_fluids->capacity());
+    if (!_slab) neighborSearch(_fluids, cellStartFluid);   // a slab's particles arrive with the first exchange
     HIP_CALL(hipStreamSynchronize(sphx::stream()));
     if (runStep) step();
 }
@@ -252,7 +294,7 @@ void SPHSystem::computeBoundaryMass()
     const int nb = boundarySize();
     if (nb <= 0) return;
     const KernelConsts k = make_kernel_consts(_sphSmoothingRadius);
-    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength);
+    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength, _cellOffsetX);
     float4* posm = reinterpret_cast<float4*>(_grid->posm.addr());
     ScopedKernel t("boundary_mass");
     k_pack_pos_only<<<blocks_for(nb), 256, 0, sphx::stream()>>>(posm, _boundaries->getPosPtr(), nb);
@@ -268,7 +310,7 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
 {
     const int num = (int)particles->size();
     const int cellsPlusOne = _cellSize.x * _cellSize.y * _cellSize.z + 1;
-    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength);
+    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength, _cellOffsetX);
     hipStream_t st = sphx::stream();
     int* p2c = particles->getParticle2Cell();
     int* perm = particles->getSortPerm();
@@ -278,20 +320,26 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
         ScopedKernel t("grid_cell_count");
         k_cell_and_count<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), particles->getPosPtr(), g, num);
     }
-    {
-        ScopedKernel t("grid_scan");
-        const int tiles = (cellsPlusOne - 1) / kScanTile + 1;
-        k_scan_tiles<<<tiles, 256, 0, st>>>(cellStart.addr(), _grid->blockSums.addr(), cellsPlusOne);
+    auto exclusiveScan = [&](int* data, int count) {
+        const int tiles = (count - 1) / kScanTile + 1;
+        k_scan_tiles<<<tiles, 256, 0, st>>>(data, _grid->blockSums.addr(), count);
         if (tiles > 1) {
             k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles);
-            k_scan_add_offsets<<<blocks_for(cellsPlusOne), 256, 0, st>>>(cellStart.addr(), _grid->blockSums.addr(), cellsPlusOne);
+            k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(data, _grid->blockSums.addr(), count);
         }
+    };
+    {
+        ScopedKernel t("grid_scan");
+        exclusiveScan(cellStart.addr(), cellsPlusOne);
     }
     if (num <= 0) return;
     {
         ScopedKernel t("grid_stable_rank");
+        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num);
+        exclusiveScan(_grid->outRank.addr(), num + 1);
         k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
-        k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), num, cellsPlusOne);
+        k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(),
+                                                       num, cellsPlusOne);
     }
     {
         ScopedKernel t("grid_gather");

@@ -23,6 +23,10 @@ BasicSPHSolver::~BasicSPHSolver() noexcept {}
 
 void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; }
+void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
+void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
+void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; }
+void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)

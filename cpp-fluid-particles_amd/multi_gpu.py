@@ -1,0 +1,417 @@
+"""multi_gpu.py — x-slab domain decomposition of the DFSPH step over torch.distributed (RCCL on GPUs).
+
+One process per GPU.  The linear cell id runs x slowest, so rank r's slab of cell columns
+[x0, x1) plus its one-cell halos x0-1 and x1 is ONE contiguous range of the globally cell-sorted
+particle arrays.  Every rank therefore holds a local array [left ghosts | owned | right ghosts]
+that is, entry for entry, a slice of the array a single device would hold; every per-particle sum
+visits the same neighbours in the same order, so the distributed run is bit-identical to the
+single-device run for any number of ranks (tests/test_slab_*.py check exactly that).
+
+Per step (fixed DFSPH iteration counts v, d):
+  1. particle exchange: every rank sends each neighbour the particles it owned last step whose new
+     cell column lies within one column of the shared cut (migrants and ghost copies alike, in
+     array order; pos, vel, id, warm stiffness = 32 B each) and rebuilds its pre-sort array as
+     [from left | previously owned | from right] — ascending in last step's global order, which is
+     what keeps the stable cell sort identical to the single-device one;
+  2. the engine's stages (sphx_run_phase) with a halo refresh after each stage that writes a field
+     the next stage reads from neighbours (kappa, vel4, cg4).  Because the boundary layers are
+     contiguous ranges of the sorted arrays, a halo message is a plain slice: no pack kernels.
+     v + d + 3 refreshes of the velocity mirror, v + d + 1 of kappa, one of the colour gradient.
+
+Collectives: only neighbour point-to-point messages (dist.batch_isend_irecv, i.e. grouped
+ncclSend/ncclRecv over xGMI on GPUs); no all-reduce in fixed-iteration mode.  The engine enqueues on
+torch's current stream, so NCCL's stream dependencies order messages with kernels without host
+synchronisation; the only host round trips per step are the message sizes and the five layer offsets.
+
+Status this round: DFSPH only; static cut planes chosen from the initial particle histogram;
+halo refreshes are not yet overlapped with interior work; adaptive iteration mode (needs a 1-word
+all-reduce of the exact integer error sum) is not wired.  The driver is engine-agnostic: the HIP
+engine is used on GPUs, and the CPU tests plug in the oracle to exercise this file under gloo.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+(PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
+ PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT) = range(12)
+
+EPS = 1e-6
+
+
+# ------------------------------------------------------------------------------------ partitioning
+def cell_column(x, cell_length):
+    """global cell column of positions x (float32): true fp32 division, truncation"""
+    if isinstance(x, torch.Tensor):
+        return torch.div(x, torch.tensor(cell_length, dtype=torch.float32, device=x.device)).to(torch.int32)
+    return (x.astype(np.float32) / np.float32(cell_length)).astype(np.int32)
+
+
+def choose_cuts(columns, gx, world):
+    """cut planes x_0=0 < x_1 < ... < x_world=gx balancing particle counts; every slab >= 2 columns"""
+    hist = np.bincount(np.clip(columns, 0, gx - 1), minlength=gx).astype(np.int64)
+    cdf = np.cumsum(hist)
+    total = int(cdf[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        x = int(np.searchsorted(cdf, target, side="left")) + 1
+        x = max(x, cuts[-1] + 2)
+        x = min(x, gx - 2 * (world - r))
+        cuts.append(x)
+    cuts.append(gx)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a < 2:
+            raise ValueError("domain too narrow for %d slabs: cuts %s" % (world, cuts))
+    return cuts
+
+
+# ------------------------------------------------------------------------------------ transport
+class Neighbors:
+    """point-to-point exchange with the left/right slab neighbour (None at the domain ends)"""
+
+    def __init__(self, rank, world):
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.stage_through_host = world > 1 and dist.get_backend() == "gloo"
+
+    def exchange(self, to_left, to_right, from_left, from_right):
+        """send to_left/to_right (tensors or None), receive into from_left/from_right (tensors or None)"""
+        ops, staged = [], []
+
+        # Device tensors handed to NCCL are always torch-allocated copies: the engine's arrays are
+        # foreign memory to torch's caching allocator (zero-copy views), and a halo slice is small.
+        def prep_send(t):
+            if t is None or t.numel() == 0:
+                return None
+            if t.is_cuda:
+                return t.contiguous().cpu() if self.stage_through_host else t.clone(memory_format=torch.contiguous_format)
+            return t.contiguous()
+
+        def prep_recv(t):
+            if t is None or t.numel() == 0:
+                return None
+            if t.is_cuda:
+                h = torch.empty(t.shape, dtype=t.dtype, device="cpu" if self.stage_through_host else t.device)
+                staged.append((t, h))
+                return h
+            if not t.is_contiguous():
+                h = torch.empty_like(t)
+                staged.append((t, h))
+                return h
+            return t
+
+        for peer, s, r in ((self.left, to_left, from_left), (self.right, to_right, from_right)):
+            if peer is None:
+                continue
+            s, r = prep_send(s), prep_recv(r)
+            if s is not None:
+                ops.append(dist.P2POp(dist.isend, s, peer))
+            if r is not None:
+                ops.append(dist.P2POp(dist.irecv, r, peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for dst, h in staged:
+            dst.copy_(h)
+
+
+# ------------------------------------------------------------------------------------ engines
+class _DevView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class HipSlabEngine:
+    """the HIP engine (libsphx.so) on one slab; fields are zero-copy torch views of device memory"""
+
+    def __init__(self, sphx, params, cap, boundary_pos, boundary_mass, device):
+        self.sphx, self.cap, self.device = sphx, cap, device
+        self.sys = sphx.System(params, np.zeros((cap, 3), np.float32), boundary_pos, ctor_step=False)
+        if len(boundary_pos):
+            self.sys.set(sphx.F_BMASS, np.ascontiguousarray(boundary_mass, np.float32))
+        self.C = self.sys.cells
+
+        def view(field, comps, typestr="<f4"):
+            shape = (cap, comps) if comps > 1 else (cap,)
+            return torch.as_tensor(_DevView(self.sys.device_ptr(field), shape, typestr), device=device)
+
+        self.f = {"pos": view(sphx.F_POS, 3), "vel": view(sphx.F_VEL, 3), "ids": view(sphx.F_ID, 1, "<i4"),
+                  "warm": view(sphx.F_WARM, 1), "kappa": view(sphx.F_KAPPA, 1), "vel_nbr": view(sphx.F_VEL4, 4),
+                  "cg_nbr": view(sphx.F_CG4, 4), "density": view(sphx.F_DENSITY, 1)}
+        self.cell_start = torch.as_tensor(_DevView(self.sys.device_ptr(sphx.F_CELLSTART_F), (self.C + 1,), "<i4"),
+                                          device=device)
+
+    def set_count(self, n):
+        self.sys.set_count(n)
+
+    def run(self, phase):
+        self.sys.run_phase(phase)
+
+    def read(self, name, lo, hi):
+        return self.f[name][lo:hi]
+
+    def write(self, name, lo, t):
+        self.f[name][lo:lo + t.shape[0]].copy_(t)
+
+    def cell_starts(self, idx):
+        return [int(v) for v in self.cell_start[torch.as_tensor(idx, device=self.device, dtype=torch.long)].cpu()]
+
+    def columns(self, lo, hi, cell_length):
+        """global cell column of particles [lo, hi), computed by the engine's own division"""
+        out = torch.empty(hi - lo, dtype=torch.int32, device=self.device)
+        if hi > lo:
+            self.sphx.cell_columns(self.f["pos"][lo:hi].data_ptr(), hi - lo, cell_length, out.data_ptr())
+        return out
+
+    def to_device(self, arr):
+        return torch.as_tensor(arr, device=self.device)
+
+
+class OracleSlabEngine:
+    """CPU stand-in used only by the tests: the oracle behind the same interface (copies, no views)"""
+
+    def __init__(self, O, params, cap, boundary_pos, boundary_mass):
+        self.O, self.cap = O, cap
+        self.sys = O.System(params, np.zeros((cap, 3), np.float32), boundary_pos, ctor_step=False)
+        if len(boundary_pos):
+            self.sys.set(O.F_BMASS, np.ascontiguousarray(boundary_mass, np.float32))
+        self.C = self.sys.C
+        self.map = {"pos": O.F_POS, "vel": O.F_VEL, "ids": O.F_ID, "warm": O.F_WARM, "kappa": O.F_KAPPA,
+                    "vel_nbr": O.F_VEL, "cg_nbr": O.F_BUF3, "density": O.F_DENSITY}
+        self.count = cap
+
+    def set_count(self, n):
+        self.sys.set_count(n)
+        self.count = n
+
+    def run(self, phase):
+        self.sys.run_phase(phase)
+
+    def read(self, name, lo, hi):
+        self.sys.set_count(self.cap)               # whole-capacity view for the copy
+        out = torch.from_numpy(self.sys.get(self.map[name])[lo:hi].copy())
+        self.sys.set_count(self.count)
+        return out
+
+    def write(self, name, lo, t):
+        self.sys.set_count(self.cap)
+        full = self.sys.get(self.map[name])
+        full[lo:lo + t.shape[0]] = t.numpy()
+        self.sys.set(self.map[name], full)
+        self.sys.set_count(self.count)
+
+    def cell_starts(self, idx):
+        cs = self.sys.get(self.O.F_CELLSTART_F)
+        return [int(cs[i]) for i in idx]
+
+    def columns(self, lo, hi, cell_length):
+        return torch.from_numpy(cell_column(self.read("pos", lo, hi).numpy()[:, 0], cell_length))
+
+    def to_device(self, arr):
+        return torch.as_tensor(arr)
+
+
+# ------------------------------------------------------------------------------------ the driver
+class SlabDriver:
+    def __init__(self, engine, nbrs, x0, x1, gy, gz, cell_length, div_iters, den_iters, surface, timers=None):
+        self.e, self.nb = engine, nbrs
+        self.x0, self.x1, self.L = x0, x1, gy * gz
+        self.gxl = (x1 - x0) + 2
+        self.cl = cell_length
+        self.v, self.d, self.surface = div_iters, den_iters, surface
+        self.owned = (0, 0)
+        self.layers = None
+        self.t_comm = 0.0
+        self.timers = timers
+
+    # -- initial distribution: this rank's owned particles in generation order
+    def load_initial(self, pos, vel=None):
+        n = pos.shape[0]
+        e = self.e
+        if n > e.cap:
+            raise RuntimeError("slab capacity %d too small for %d particles" % (e.cap, n))
+        e.write("pos", 0, pos)
+        e.write("vel", 0, vel if vel is not None else torch.zeros_like(pos))
+        e.write("warm", 0, torch.zeros(n, dtype=torch.float32, device=pos.device))
+        self.owned = (0, n)
+
+    def _exchange_particles(self):
+        e = self.e
+        o0, o1 = self.owned
+        pos, vel = e.read("pos", o0, o1), e.read("vel", o0, o1)
+        ids, warm = e.read("ids", o0, o1), e.read("warm", o0, o1)
+        col = e.columns(o0, o1, self.cl)
+        if o1 > o0 and (int(col.min()) < self.x0 - 1 or int(col.max()) > self.x1):
+            raise RuntimeError("a particle crossed more than one cell column in one step")
+        payload = torch.cat([pos, vel, ids.view(torch.float32).unsqueeze(1), warm.unsqueeze(1)], dim=1)   # [m, 8]
+        to_left = payload[col <= self.x0] if self.nb.left is not None else None
+        to_right = payload[col >= self.x1 - 1] if self.nb.right is not None else None
+        dev = payload.device
+        # message sizes first
+        cnt_send_l = torch.tensor([0 if to_left is None else to_left.shape[0]], dtype=torch.int64, device=dev)
+        cnt_send_r = torch.tensor([0 if to_right is None else to_right.shape[0]], dtype=torch.int64, device=dev)
+        cnt_recv_l = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt_recv_r = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.nb.exchange(cnt_send_l, cnt_send_r, cnt_recv_l, cnt_recv_r)
+        nl, nr = int(cnt_recv_l.item()), int(cnt_recv_r.item())
+        from_left = torch.empty((nl, 8), dtype=torch.float32, device=dev)
+        from_right = torch.empty((nr, 8), dtype=torch.float32, device=dev)
+        self.nb.exchange(to_left, to_right, from_left, from_right)
+        pre = torch.cat([from_left, payload, from_right], dim=0)
+        n = pre.shape[0]
+        if n > e.cap:
+            raise RuntimeError("slab capacity %d exceeded (%d particles)" % (e.cap, n))
+        e.write("pos", 0, pre[:, 0:3])
+        e.write("vel", 0, pre[:, 3:6])
+        e.write("ids", 0, pre[:, 6].contiguous().view(torch.int32))
+        e.write("warm", 0, pre[:, 7].contiguous())
+        e.set_count(n)
+
+    def _update_layers(self):
+        L, g = self.L, self.gxl
+        c = self.e.cell_starts([L, 2 * L, (g - 2) * L, (g - 1) * L, g * L])
+        # [0,c0) left ghosts, [c0,c1) first owned layer, [c2,c3) last owned layer, [c3,c4) right ghosts
+        self.layers = c
+        self.owned = (c[0], c[3])
+
+    def _halo(self, name):
+        t0 = time.perf_counter() if self.timers is not None else 0.0
+        c0, c1, c2, c3, c4 = self.layers
+        e = self.e
+        send_l = e.read(name, c0, c1) if self.nb.left is not None else None
+        send_r = e.read(name, c2, c3) if self.nb.right is not None else None
+        recv_l = e.read(name, 0, c0) if self.nb.left is not None else None
+        recv_r = e.read(name, c3, c4) if self.nb.right is not None else None
+        if isinstance(e, OracleSlabEngine):
+            if recv_l is not None:
+                recv_l = torch.empty_like(recv_l)
+            if recv_r is not None:
+                recv_r = torch.empty_like(recv_r)
+        self.nb.exchange(send_l, send_r, recv_l, recv_r)
+        if isinstance(e, OracleSlabEngine):
+            if recv_l is not None and recv_l.numel():
+                e.write(name, 0, recv_l)
+            if recv_r is not None and recv_r.numel():
+                e.write(name, c3, recv_r)
+        if self.timers is not None:
+            self.timers["halo"] = self.timers.get("halo", 0.0) + time.perf_counter() - t0
+
+    def step(self):
+        e = self.e
+        self._exchange_particles()
+        e.run(PH_SEARCH)
+        self._update_layers()
+        e.run(PH_HEAD); self._halo("kappa")
+        for _ in range(self.v):
+            e.run(PH_DIV_CORRECT); self._halo("vel_nbr")
+            e.run(PH_DIV_ERROR); self._halo("kappa")
+        e.run(PH_FORCE)
+        e.run(PH_VISC_COLOR)
+        if self.surface:
+            self._halo("cg_nbr")
+        e.run(PH_SURFACE); self._halo("vel_nbr")
+        e.run(PH_WARM_CORRECT); self._halo("vel_nbr")
+        e.run(PH_DEN_ERROR_SET); self._halo("kappa")
+        for k in range(self.d):
+            e.run(PH_DEN_CORRECT); self._halo("vel_nbr")
+            e.run(PH_DEN_ERROR_ACC)
+            if k + 1 < self.d:
+                self._halo("kappa")
+        e.run(PH_ADVECT)
+
+    def owned_state(self):
+        """(ids, pos, vel, density) of the particles this rank owns, as CPU numpy arrays"""
+        o0, o1 = self.owned
+        e = self.e
+        return tuple(e.read(k, o0, o1).cpu().numpy().copy() for k in ("ids", "pos", "vel", "density"))
+
+
+# ------------------------------------------------------------------------------------ set-up helper
+def build_slab(make_engine, scene_params, fluid, boundary_sorted, boundary_mass, rank, world, capacity_factor=1.3,
+               velocity=None):
+    """cuts the global scene into `world` x-slabs and creates this rank's engine + driver.
+    `boundary_sorted`/`boundary_mass`: the GLOBAL boundary set in cell-sorted order with its masses
+    (computed by a whole-domain boundary-only system, SPHSystem.cu:69-71).  `make_engine(params,
+    cap, bpos, bmass)` returns a HipSlabEngine or an OracleSlabEngine."""
+    P = scene_params
+    gx, gy, gz = P.cells[0], P.cells[1], P.cells[2]
+    cl = P.cell_length
+    col = cell_column(fluid[:, 0], cl)
+    cuts = choose_cuts(col, gx, world)
+    x0, x1 = cuts[rank], cuts[rank + 1]
+    mine = fluid[(col >= x0) & (col < x1)]
+    bcol = cell_column(boundary_sorted[:, 0], cl)
+    bsel = (bcol >= x0 - 1) & (bcol <= x1)
+    counts = [int(((col >= a) & (col < b)).sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+    cap = int(max(counts) * capacity_factor) + 4096
+    Pl = type(P)()
+    for name, _ in P._fields_:
+        setattr(Pl, name, getattr(P, name))
+    Pl.cells[0] = (x1 - x0) + 2
+    Pl.reserved[1] = x0 - 1          # global column of local column 0
+    Pl.reserved[2] = 1               # slab system (also when the offset is 0)
+    engine = make_engine(Pl, cap, np.ascontiguousarray(boundary_sorted[bsel]), np.ascontiguousarray(boundary_mass[bsel]))
+    surface = P.surface_tension > EPS or P.air_pressure > EPS
+    nbrs = Neighbors(rank, world)
+    drv = SlabDriver(engine, nbrs, x0, x1, gy, gz, cl, P.dfsph_fixed_div, P.dfsph_fixed_den, surface)
+    sel = (col >= x0) & (col < x1)
+    drv.load_initial(engine.to_device(np.ascontiguousarray(mine)),
+                     None if velocity is None else engine.to_device(np.ascontiguousarray(velocity[sel])))
+    # ids: global generation index of each initial particle
+    gid = np.flatnonzero((col >= x0) & (col < x1)).astype(np.int32)
+    engine.write("ids", 0, engine.to_device(gid))
+    return drv, cuts, counts
+
+
+# ------------------------------------------------------------------------------------ bench entry
+def run_slab_bench(args, rank, world, local_rank):
+    """bench.py --gpus N (N > 1): the same global workload split into N x-slabs (strong scaling)."""
+    import sphx
+    torch.cuda.set_device(local_rank)
+    sphx.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    sphx.use_stream(torch.cuda.current_stream().cuda_stream)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=device)
+    P, fluid, boundary = sphx.scene(args.nx)
+    P.solver = sphx.DFSPH
+    P.dfsph_fixed_div, P.dfsph_fixed_den = args.div_iters, args.den_iters
+    # global boundary masses from a boundary-only whole-domain system (SPHSystem.cu:69-71)
+    bsys = sphx.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
+    bpos, bmass = bsys.get(sphx.F_BPOS), bsys.get(sphx.F_BMASS)
+    bsys.close()
+
+    def make_engine(Pl, cap, bp, bm):
+        return HipSlabEngine(sphx, Pl, cap, bp, bm, device)
+
+    drv, cuts, counts = build_slab(make_engine, P, fluid, bpos, bmass, rank, world)
+    n_total = len(fluid)
+    drv.step()                                   # = the constructor step of the single-device path
+    for _ in range(args.warmup):
+        drv.step()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step()
+    torch.cuda.synchronize(); dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    bpp = 420 + 92 * args.div_iters + 104 * args.den_iters + 72
+    steps_per_s = args.steps / wall
+    return {
+        "metric": "simulation steps/sec, DFSPH dam-break", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, DFSPH(%d div + %d density iters, fixed), dt=%g"
+                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), args.div_iters, args.den_iters, P.dt),
+                   "particles": n_total, "decomposition": "%d x-slabs, cuts %s, initial particles per slab %s, one-cell halos over RCCL p2p"
+                                                          % (world, cuts, counts),
+                   "step_algorithmic_bytes_per_particle": bpp,
+                   "step_algorithmic_GBps": bpp * n_total * steps_per_s / 1e9,
+                   "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
+        "roofline": None,
+    }

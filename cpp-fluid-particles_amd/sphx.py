@@ -16,7 +16,10 @@ LIB_PATH = os.path.join(_HERE, "libsphx.so")
 WCSPH, DFSPH, PBD = 0, 1, 2
 
 (F_POS, F_VEL, F_DENSITY, F_PRESSURE, F_MASS, F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID, F_BPOS,
- F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3) = range(18)
+ F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3, F_VEL4, F_CG4) = range(20)
+
+(PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
+ PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT) = range(12)
 
 _INT_FIELDS = (F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID)
 _VEC_FIELDS = (F_POS, F_VEL, F_BPOS, F_POS_LAST, F_BUF3)
@@ -26,7 +29,8 @@ EXPORTS = [
     "sphx_scene_params", "sphx_scene_counts", "sphx_scene_fill", "sphx_create", "sphx_destroy",
     "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
-    "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect",
+    "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_set_count", "sphx_use_stream",
+    "sphx_sync", "sphx_cell_columns",
 ]
 
 
@@ -90,6 +94,10 @@ def lib():
         L.sphx_eval_kernels.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         L.sphx_ieee_probe.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
         L.sphx_generate_dots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sphx_run_phase.argtypes = [C.c_void_p, C.c_int]
+        L.sphx_set_count.argtypes = [C.c_void_p, C.c_int]
+        L.sphx_use_stream.argtypes = [C.c_void_p]
+        L.sphx_cell_columns.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
         L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.sphx_sizeof_params() != C.sizeof(Params):
@@ -165,6 +173,12 @@ class System:
         arr = np.ascontiguousarray(arr)
         _check(lib().sphx_set(self._h, field, arr.ctypes.data, arr.nbytes))
 
+    def set_count(self, n):
+        _check(lib().sphx_set_count(self._h, n))
+
+    def run_phase(self, phase):
+        _check(lib().sphx_run_phase(self._h, phase))
+
     def device_ptr(self, field):
         p = C.c_void_p()
         _check(lib().sphx_device_ptr(self._h, field, C.byref(p)))
@@ -187,6 +201,19 @@ class System:
             self.close()
         except Exception:
             pass
+
+
+def use_stream(hip_stream_handle):
+    """enqueue all engine work on a caller-owned hipStream_t (int handle), e.g. torch's current stream"""
+    _check(lib().sphx_use_stream(C.c_void_p(hip_stream_handle)))
+
+
+def cell_columns(device_xyz_ptr, n, cell_length, device_out_ptr):
+    _check(lib().sphx_cell_columns(C.c_void_p(device_xyz_ptr), n, cell_length, C.c_void_p(device_out_ptr)))
+
+
+def sync():
+    _check(lib().sphx_sync())
 
 
 def kernel_timer(enable, name_filter=""):

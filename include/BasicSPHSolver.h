@@ -34,6 +34,13 @@ public:
     // bit 2: stage neighbour ranges in LDS per 64-particle tile)
     const DArray<float3>& getColorGradient() const { return bufferFloat3; }
     void setEngineFlags(int flags);
+    // slab decompositions: global x index of this solver's local cell column 0
+    void setCellOffsetX(int cellOffsetX);
+    // raw device pointers of the float4 mirrors the sweeps gather from (halo exchange targets)
+    void* engineVel4() const;
+    void* engineCg4() const;
+    // call after writing boundary positions/masses through raw pointers
+    void invalidateBoundary();
 
 protected:
     virtual void force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G) override final;

@@ -30,6 +30,14 @@ public:
         fixedDen = densityIters;
     }
     bool graphSafe() const override { return fixedDiv >= 0 && fixedDen >= 0; }
+    // one stage of the fused schedule (values of sphx_phase in sphx_c.h, except SEARCH which here
+    // means "prepare": pack, neighbour rows, carry the warm stiffness through the sort).
+    // `reduce` accumulates the |error| total of the error stages for readErrorTotal().
+    void runPhase(int phase, std::shared_ptr<SPHParticles>& fluids,
+                  const std::shared_ptr<SPHParticles>& boundaries, const DArray<int>& cellStartFluid,
+                  const DArray<int>& cellStartBoundary, float3 spaceSize, int3 cellSize, float cellLength,
+                  float radius, float dt, float rho0, float rhoB, float visc, float3 G,
+                  float surfaceTensionIntensity, float airPressure, bool reduce = false);
     int lastDivergenceIterations() const { return lastDiv; }
     int lastDensityIterations() const { return lastDen; }
     const DArray<float>& getAlpha() const { return alpha; }

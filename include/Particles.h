@@ -15,16 +15,22 @@ public:
     Particles(const Particles&) = delete;
     Particles& operator=(const Particles&) = delete;
 
-    unsigned int size() const { return pos.length(); }
+    unsigned int size() const { return _active; }
     float3* getPosPtr() const { return pos.addr(); }
     float3* getVelPtr() const { return vel.addr(); }
     const DArray<float3>& getPos() const { return pos; }
 
     void advect(float dt);
 
+    // --- engine extension: the arrays are allocated for capacity() particles; size() is the number
+    // currently in use (distributed drivers move particles between processes every step)
+    unsigned int capacity() const { return pos.length(); }
+    void setActiveCount(unsigned int n) { _active = n <= pos.length() ? n : pos.length(); }
+
     virtual ~Particles() noexcept {}
 
 protected:
     DArray<float3> pos;
     DArray<float3> vel;
+    unsigned int _active;
 };

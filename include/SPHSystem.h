@@ -46,6 +46,17 @@ public:
               float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
               float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
               float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
+    // slab decompositions: this system covers a sub-grid whose local cell column 0 is global column
+    // `cellOffsetX` (cellSize.x = local columns incl. one ghost layer per side); no initial step.
+    // phase(p) runs one stage of the DFSPH step (see sphx_phase in sphx_c.h) so that a distributed
+    // driver can refresh halo fields between stages.
+    struct Slab { int cellOffsetX; };
+    SPHSystem(Slab, std::shared_ptr<SPHParticles>& fluidParticles,
+              std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+              float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
+              float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
+              float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
+    void phase(int p);
     const DArray<int>& getCellStartFluid() const { return cellStartFluid; }
     const DArray<int>& getCellStartBoundary() const { return cellStartBoundary; }
     BaseSolver* getSolver() const { return _solver.get(); }
@@ -73,6 +84,8 @@ private:
     const float _sphSurfaceTensionIntensity;
     const float _sphAirPressure;
     const int3 _cellSize;
+    int _cellOffsetX = 0;
+    bool _slab = false;
     DArray<int> bufferInt;
     std::unique_ptr<sphx::GridScratch> _grid;
     std::unique_ptr<sphx::StepGraph> _graph;

@@ -86,6 +86,8 @@ typedef enum sphx_field {
     SPHX_F_POS_LAST,       /* float[3n]  PBDSolver::fluidPosLast                       */
     SPHX_F_LAMBDA,         /* float[n]   PBDSolver::bufferFloat (lambda)               */
     SPHX_F_BUF3,           /* float[3n]  BasicSPHSolver::bufferFloat3 (colour gradient)*/
+    SPHX_F_VEL4,           /* float[4n]  engine mirror of vel (x,y,z,0), what sweeps gather    */
+    SPHX_F_CG4,            /* float[4n]  engine mirror of the colour gradient                  */
     SPHX_F_COUNT_
 } sphx_field;
 
@@ -117,6 +119,37 @@ int  sphx_step(sphx_system *sys, float *ms);
  * hipGraph); *ms_total is the hipEvent time of the whole batch.                               */
 int  sphx_step_n(sphx_system *sys, int n, float *ms_total);
 
+/* Stage-wise DFSPH step for distributed drivers (x-slab decomposition).  The
+ * stages are the fused schedule of DFSPHSolver::step (DFSPHSolver.cu:33-72 restated); between two
+ * stages the driver refreshes the halo copy of the field the next stage reads from neighbours.
+ * A slab system is created with run_ctor_step = 0, params.cells[0] = local cell columns (owned +
+ * one ghost layer per side) and params.reserved[1] = global x index of local column 0.          */
+typedef enum sphx_phase {
+    SPHX_PH_SEARCH = 0,       /* neighbour search, pack, neighbour rows, warm stiffness follows sort */
+    SPHX_PH_HEAD,             /* density, alpha, first divergence error -> error, kappa            */
+    SPHX_PH_DIV_CORRECT,      /* vel += sum m (k_i + k_j) gradW                 (writes vel)       */
+    SPHX_PH_DIV_ERROR,        /* divergence error                               (writes kappa)     */
+    SPHX_PH_FORCE,            /* gravity                                                            */
+    SPHX_PH_VISC_COLOR,       /* viscosity delta-v + colour gradient            (writes cg)        */
+    SPHX_PH_SURFACE,          /* vel += deltaV, surface tension + air pressure  (writes vel)       */
+    SPHX_PH_WARM_CORRECT,     /* warm start: density correction with last step's stiffness (vel)   */
+    SPHX_PH_DEN_ERROR_SET,    /* density error, warm = kappa                    (writes kappa)     */
+    SPHX_PH_DEN_CORRECT,      /* density correction                             (writes vel)       */
+    SPHX_PH_DEN_ERROR_ACC,    /* density error, warm += kappa                   (writes kappa)     */
+    SPHX_PH_ADVECT            /* pos += dt vel, box clamp                                           */
+} sphx_phase;
+int  sphx_run_phase(sphx_system *sys, int phase);
+/* number of fluid particles in use (<= the n_fluid capacity given to sphx_create); slab drivers
+ * change it every step as particles migrate between processes                                   */
+int  sphx_set_count(sphx_system *sys, int n_fluid);
+/* make the engine enqueue on a caller-owned hipStream_t (e.g. torch's current stream) so that the
+ * caller's collectives are ordered with the engine's kernels; call before sphx_create.          */
+int  sphx_use_stream(void *hip_stream);
+int  sphx_sync(void);                                  /* hipStreamSynchronize(engine stream) */
+/* global cell column (int)(x / cell_length) of n DEVICE positions (xyz triples), computed with the
+ * engine's own division so that a driver agrees with the grid about column membership          */
+int  sphx_cell_columns(const float *device_xyz, int n, float cell_length, int *device_out);
+
 /* SPHSystem::size/boundarySize (SPHSystem.h:44-55) and grid size */
 int  sphx_counts(const sphx_system *sys, int *n_fluid, int *n_boundary, int *n_cells);
 /* iteration counts of the last DFSPH step (the values DFSPHSolver.cu:49,65 compute and drop) */
@@ -125,7 +158,7 @@ int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iter
 /* field access: blocking D2H / H2D copies of whole fields, and raw device pointers */
 int  sphx_field_bytes(const sphx_system *sys, int field, size_t *bytes);
 int  sphx_get(const sphx_system *sys, int field, void *host_dst, size_t bytes);
-int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM */
+int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM, BMASS */
 int  sphx_device_ptr(const sphx_system *sys, int field, void **device_ptr);
 
 /* per-kernel timing of the last sphx_profile_step: names/ms arrays of up to cap entries */

@@ -64,6 +64,8 @@ def lib():
         L.oracle_scene_fill.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_eval_kernels.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_run_phase.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_count.argtypes = [C.c_void_p, C.c_int]
         assert L.oracle_sizeof_params() == C.sizeof(Params)
         _lib = L
     return _lib
@@ -120,6 +122,13 @@ class System:
     def set(self, field, arr):
         arr = np.ascontiguousarray(arr)
         assert lib().oracle_set(self._h, field, arr.ctypes.data, arr.nbytes) == 0
+
+    def set_count(self, n):
+        assert lib().oracle_set_count(self._h, n) == 0
+        self.n = n
+
+    def run_phase(self, phase):
+        assert lib().oracle_run_phase(self._h, phase) == 0
 
     def iters(self):
         a, b = C.c_int(), C.c_int()

@@ -66,7 +66,7 @@ typedef struct {
 
 typedef struct {
     oracle_params P;
-    int n, nb, C;
+    int n, nb, C, cap;
     f3 *pos, *vel;  float *pressure, *density, *mass;  int *p2c;  int *ids;
     f3 *bpos, *bvel; float *bmass; int *bp2c;
     int *csF, *csB;                 /* cellStart arrays, C+1 entries */
@@ -136,10 +136,12 @@ static inline int cell_id(int x, int y, int z, const int *cs)
     return (x >= 0 && x < cs[0] && y >= 0 && y < cs[1] && z >= 0 && z < cs[2])
                ? ((x * cs[1] + y) * cs[2] + z) : (cs[0] * cs[1] * cs[2]);
 }
-/* make_int3(pos / cellLength): fp32 division, truncation toward zero (helper_math.h) */
+/* make_int3(pos / cellLength): fp32 division, truncation toward zero (helper_math.h).  g_xoff is the
+ * global x index of local cell column 0 (0 for a whole domain; slab tests use x0-1). */
+static int g_xoff = 0;
 static inline void cell_of(f3 p, float cl, int *c)
 {
-    c[0] = (int)(p.x / cl); c[1] = (int)(p.y / cl); c[2] = (int)(p.z / cl);
+    c[0] = (int)(p.x / cl) - g_xoff; c[1] = (int)(p.y / cl); c[2] = (int)(p.z / cl);
 }
 
 /* --------------------------------------------------------------------------- neighbour grid */
@@ -680,6 +682,7 @@ static double now_ms(void)
 float oracle_step(oracle_sys *s)
 {
     const double t0 = now_ms();
+    g_xoff = s->P.reserved[1];
     neighbor_search(s, s->pos, s->vel, s->p2c, s->ids, s->n, s->csF);
     switch (s->P.solver) {
     case 1: dfsph_step(s); break;
@@ -688,6 +691,39 @@ float oracle_step(oracle_sys *s)
     }
     s->steps++;
     return (float)(now_ms() - t0);
+}
+
+/* Stage-wise DFSPH step (same stage numbering as sphx_phase in include/sphx_c.h), used by the
+ * world_size-2 gloo tests of the slab driver with this oracle standing in for the HIP engine. */
+enum { PH_SEARCH = 0, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
+       PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT };
+int oracle_run_phase(oracle_sys *s, int phase)
+{
+    const oracle_params *P = &s->P;
+    const int surface = P->surface_tension > ORACLE_EPS || P->air_pressure > ORACLE_EPS;
+    g_xoff = P->reserved[1];
+    switch (phase) {
+    case PH_SEARCH:
+        neighbor_search(s, s->pos, s->vel, s->p2c, s->ids, s->n, s->csF);
+        resort_float(s, s->warm);
+        break;
+    case PH_HEAD: k_density_alpha(s); k_divergence_error(s); break;
+    case PH_DIV_CORRECT: k_correct(s, s->kappa, 0); break;
+    case PH_DIV_ERROR: k_divergence_error(s); break;
+    case PH_FORCE: k_force(s); break;
+    case PH_VISC_COLOR: k_viscosity(s); if (surface) k_color_grad(s); break;
+    case PH_SURFACE: if (surface) k_surface(s); break;
+    case PH_WARM_CORRECT: k_correct(s, s->warm, 1); break;
+    case PH_DEN_ERROR_SET: k_density_error(s); memcpy(s->warm, s->kappa, sizeof(float) * (size_t)s->n); break;
+    case PH_DEN_CORRECT: k_correct(s, s->kappa, 1); break;
+    case PH_DEN_ERROR_ACC:
+        k_density_error(s);
+        for (int i = 0; i < s->n; ++i) s->warm[i] = s->warm[i] + s->kappa[i];
+        break;
+    case PH_ADVECT: k_advect(s); s->steps++; break;
+    default: return -1;
+    }
+    return 0;
 }
 
 void oracle_destroy(oracle_sys *s)
@@ -706,7 +742,7 @@ oracle_sys *oracle_create(const oracle_params *P, const float *fluid_xyz, int n,
                           const float *boundary_xyz, int nb, int run_ctor_step)
 {
     oracle_sys *s = (oracle_sys *)calloc(1, sizeof(oracle_sys));
-    s->P = *P; s->n = n; s->nb = nb;
+    s->P = *P; s->n = n; s->nb = nb; s->cap = n;
     s->C = P->cells[0] * P->cells[1] * P->cells[2];
     const size_t nm = (size_t)(n > nb ? n : nb) + 1;
     s->pos = calloc((size_t)n + 1, sizeof(f3)); s->vel = calloc((size_t)n + 1, sizeof(f3));
@@ -726,6 +762,7 @@ oracle_sys *oracle_create(const oracle_params *P, const float *fluid_xyz, int n,
     memcpy(s->bpos, boundary_xyz, sizeof(f3) * (size_t)nb);
     for (int i = 0; i < n; ++i) s->ids[i] = i;
     s->visc_r6 = powf(P->radius, 6);
+    g_xoff = P->reserved[1];
 
     neighbor_search(s, s->bpos, s->bvel, s->bp2c, NULL, nb, s->csB);
     boundary_mass(s);
@@ -775,12 +812,17 @@ int oracle_set(oracle_sys *s, int field, const void *src, long long bytes)
     case OF_POS: dst = s->pos; want = 12LL * s->n; break;
     case OF_VEL: dst = s->vel; want = 12LL * s->n; break;
     case OF_WARM: dst = s->warm; want = 4LL * s->n; break;
+    case OF_ID: dst = s->ids; want = 4LL * s->n; break;
+    case OF_KAPPA: dst = s->kappa; want = 4LL * s->n; break;
+    case OF_BUF3: dst = s->buf3; want = 12LL * s->n; break;
+    case OF_BMASS: dst = s->bmass; want = 4LL * s->nb; break;
     default: return -1;
     }
     if (bytes != want) return -1;
     memcpy(dst, src, (size_t)bytes);
     return 0;
 }
+int oracle_set_count(oracle_sys *s, int n) { if (n < 0 || n > s->cap) return -1; s->n = n; return 0; }
 void oracle_iters(const oracle_sys *s, int *div, int *den) { *div = s->it_div; *den = s->it_den; }
 int oracle_sizeof_params(void) { return (int)sizeof(oracle_params); }
 void oracle_set_threads(int t)

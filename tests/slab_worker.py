@@ -1,0 +1,63 @@
+"""worker processes of the slab-decomposition tests (spawned with torch.multiprocessing)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+
+
+def splash(n, P, seed):
+    rng = np.random.default_rng(seed)
+    lo = 0.03 * P.space[0]
+    pos = rng.uniform(lo, 0.9 * P.space[0], (n, 3)).astype(np.float32)
+    pos[:, 1] = rng.uniform(lo, 0.3 * P.space[1], n).astype(np.float32)
+    vel = rng.normal(0, 0.6, (n, 3)).astype(np.float32)
+    vel[:, 0] += np.where(pos[:, 0] < 0.5 * P.space[0], 2.5, -2.5).astype(np.float32)   # drive flow across the cuts
+    return pos, vel
+
+
+def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    import multi_gpu as M
+    if engine_kind == "oracle":
+        from oracle import oracle as E
+        P, fluid, boundary = E.scene(nx)
+    else:
+        import sphx as E
+        E.set_device(0)
+        torch.cuda.set_device(0)
+        E.use_stream(torch.cuda.current_stream().cuda_stream)
+        P, fluid, boundary = E.scene(nx)
+    P.solver = E.DFSPH
+    P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3
+    P.dt = 0.001
+    pos, vel = splash(len(fluid), P, seed)
+    bsys = E.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
+    bpos, bmass = bsys.get(E.F_BPOS), bsys.get(E.F_BMASS)
+    bsys.close()
+    if engine_kind == "oracle":
+        make = lambda Pl, cap, bp, bm: M.OracleSlabEngine(E, Pl, cap, bp, bm)
+    else:
+        dev = torch.device("cuda", 0)
+        make = lambda Pl, cap, bp, bm: M.HipSlabEngine(E, Pl, cap, bp, bm, dev)
+    drv, cuts, counts = M.build_slab(make, P, pos, bpos, bmass, rank, world, capacity_factor=2.0, velocity=vel)
+    migrated = 0
+    prev = None
+    for _ in range(steps):
+        drv.step()
+        ids = drv.owned_state()[0]
+        if prev is not None:
+            migrated += len(np.setdiff1d(ids, prev))
+        prev = ids
+    ids, p, v, d = drv.owned_state()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), ids=ids, pos=p, vel=v, density=d, cuts=np.array(cuts),
+             migrated=np.array(migrated))
+    dist.barrier()
+    dist.destroy_process_group()
