@@ -407,11 +407,12 @@ __global__ void k_eval_kernels(const float3* __restrict__ r3, int n, KernelConst
     if (i >= n) return;
     const float3 d = r3[i];
     const float r = len3(d);
-    const float q = q_of(r, k);
+    // plain operators here; the fast instantiations are compared with them by sphx_fastmath_selftest
+    const float q = q_of<false>(r, k);
     W[i] = kW(q, k);
-    G[i] = kGradW(d, q, k);
+    G[i] = kGradW<false>(d, q, k);
     V[i] = kViscLap(r, k);
-    S[i] = kSurfGrad(d, r, k);
+    S[i] = kSurfGrad<false>(d, r, k);
 }
 
 // global cell column of each position: exactly the expression of cell_of() (true fp32 division,
@@ -503,6 +504,14 @@ int sphx_ieee_probe(const float* a, const float* b, const float* c, int n, float
     HIP_CALL(hipMemcpyAsync(trunc, dt.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_CALL(hipMemcpyAsync(muladd, dm.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) return fail(SPHX_ERR_HIP, "sphx_ieee_probe failed");
+    return SPHX_OK;
+}
+
+int sphx_fastmath_selftest(float radius, unsigned long long samples, unsigned int* mismatches3, int* enabled2)
+{
+    if (!mismatches3 || !enabled2) return fail(SPHX_ERR_INVALID, "sphx_fastmath_selftest: bad argument");
+    if (sphx_device_count() <= 0) return fail(SPHX_ERR_NO_DEVICE, "no HIP device");
+    fastmath_selftest(radius, samples, mismatches3, enabled2);
     return SPHX_OK;
 }
 

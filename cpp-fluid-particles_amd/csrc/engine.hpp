@@ -16,6 +16,8 @@ namespace sphx {
 // tests (q > 2, r <= R, x > R) are monotone in r2 because correctly-rounded sqrt and division are
 // monotone, so "largest r2 that passes" is an exact threshold.
 KernelConsts make_kernel_consts(float radius);
+void validate_fast_math(KernelConsts& k);
+void fastmath_selftest(float R, unsigned long long samples, unsigned int out[3], int flags[2]);
 GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 
 // Per-solver packed views of the particle sets and the per-step neighbour list, refreshed when
@@ -25,8 +27,7 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 //   nbr/nbrCount : wave-interleaved compact neighbour rows (sph_device.hpp), `cap` entries/particle
 //   aux3         : second float3 scratch (viscosity delta-v while bufferFloat3 holds the colour
 //                  gradient in the fused sweeps)
-// kFlagTiles: stage neighbour ranges in LDS per 64-particle tile (tested, currently slower than
-// global gathers at one wave per 40 KB of LDS; off by default)
+// kFlagTiles: LDS-streamed tiles (sph_device.hpp, entry format 2)
 enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4 };
 
 struct SweepCache {
@@ -38,7 +39,7 @@ struct SweepCache {
     DArray<float> vel4;                      // float4 mirror of vel, kept in step by every velocity writer
     DArray<float> cg4;                       // float4 mirror of the colour gradient
     DArray<int> nbrCount;
-    DArray<int> tileFmt;                     // per 64-particle tile: 1 = rows hold LDS slots
+    DArray<int> tileFmt;                     // per 64-particle tile: entry format of its rows (0 or 2)
     std::unique_ptr<DArray<int>> nbr;        // allocated on first use
     std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
     int nb = 0;

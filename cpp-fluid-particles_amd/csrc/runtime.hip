@@ -70,7 +70,111 @@ KernelConsts make_kernel_consts(float R)
     const float tW = largest_true([R](float r2) { volatile float r = sqrtf(r2); volatile float q = 2.0f * r / R; return !(q > 2.0f); });
     const float tR = largest_true([R](float r2) { volatile float r = sqrtf(r2); return r <= R; });
     k.tCut = tW > tR ? tW : tR;
+    k.rcpR = 1.0f / R;
+    k.fastQ = 0;
+    k.fastDiv = 0;
     return k;
+}
+
+// ---- validation of the exact fast paths (sph_device.hpp) ------------------------------------------------
+// every float x in {0} U [2^-47, lastBits] (q_of sends smaller positive x to the plain operator)
+__global__ void k_check_q_division(KernelConsts k, unsigned int lastBits, unsigned int* mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned int first = 0x28000000u;   // 2^-47
+    unsigned int bad = 0;
+    for (unsigned long long b = first + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= lastBits; b += stride) {
+        const float x = __uint_as_float((unsigned int)b);
+        bad += (__float_as_uint(div_by_radius<true>(x, k)) != __float_as_uint(x / k.R)) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(div_by_radius<true>(0.0f, k)) != __float_as_uint(0.0f / k.R)) ? 1u : 0u;
+    if (bad) atomicAdd(mismatches, bad);
+}
+__global__ void k_check_sqrt(unsigned int firstBits, unsigned int lastBits, unsigned int* mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    for (unsigned long long b = firstBits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= lastBits; b += stride) {
+        const float x = __uint_as_float((unsigned int)b);
+        if (x != 0.0f && x < 1.2621774483536189e-29f) continue;   // below 2^-96 the sweeps use sqrtf
+        bad += (__float_as_uint(sqrt_sel<true>(x)) != __float_as_uint(sqrtf(x))) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+__device__ __forceinline__ unsigned int mix32(unsigned int v)
+{
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+// pseudo-random numerators (zero, tiny, ordinary, both signs) over denominators spanning the
+// accepted range; compares div3_exact with three IEEE divisions
+__global__ void k_check_div3(KernelConsts k, float denLo, float denHi, unsigned long long samples, unsigned int* mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    const float lgLo = log2f(denLo), lgHi = log2f(denHi);
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < samples; t += stride) {
+        const unsigned int h0 = mix32((unsigned int)t * 4u + 1u), h1 = mix32((unsigned int)t * 4u + 2u);
+        const unsigned int h2 = mix32((unsigned int)t * 4u + 3u), h3 = mix32((unsigned int)t * 4u + 4u);
+        // denominator: random mantissa, exponent uniform in [lgLo, lgHi]
+        const float den = exp2f(lgLo + (lgHi - lgLo) * ((h0 >> 8) * (1.0f / 16777216.0f))) * (1.0f + (h1 & 0x7fffffu) * (1.0f / 8388608.0f) * 0.5f);
+        auto numer = [](unsigned int h) {
+            const unsigned int kind = h & 7u;
+            if (kind == 0u) return 0.0f;
+            const int e = (kind == 1u) ? (-140 + (int)((h >> 3) % 45u)) : (-40 + (int)((h >> 3) % 47u));   // tiny or ordinary
+            const float m = 1.0f + ((h >> 9) & 0x7fffffu) * (1.0f / 8388608.0f);
+            const float v = ldexpf(m, e);
+            return (h & 0x80000000u) ? -v : v;
+        };
+        const float3 n = make_float3(numer(h1), numer(h2), numer(h3));
+        // numerators below 2^-101 take the plain operators in the sweeps (pair_needs_plain_ops)
+        const float3 a = pair_needs_plain_ops(n, 1.0f, k) ? div3s(n, den) : div3_sel<true>(n, den), b = div3s(n, den);
+        bad += (__float_as_uint(a.x) != __float_as_uint(b.x)) + (__float_as_uint(a.y) != __float_as_uint(b.y)) +
+               (__float_as_uint(a.z) != __float_as_uint(b.z));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// enables the fast paths of `k` that hold for its radius; runs a few ms of device work and one sync
+void validate_fast_math(KernelConsts& k)
+{
+    if (getenv("SPHX_NO_FASTMATH")) return;
+    const float R = k.R;
+    // denominators seen by div3_exact: PI*(q+EPS)*R^5 for q in [0, 2], and stK*x for x in [EPS, R]
+    const float r5 = R * R * R * R * R;
+    const float dLo = fminf(kPi * kEps * r5, k.stK * kEps), dHi = fmaxf(kPi * (2.0f + kEps) * r5 * 1.01f, k.stK * R);
+    k.fastDiv = (dLo >= ldexpf(1.0f, -90) && dHi <= ldexpf(1.0f, 16) && R < 64.0f) ? 1 : 0;
+    unsigned int* d_bad = nullptr;
+    if (hipMalloc((void**)&d_bad, sizeof(unsigned int)) != hipSuccess) return;
+    HIP_CALL(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream()));
+    unsigned int lastBits; const float top = 2.2f * R; std::memcpy(&lastBits, &top, 4);
+    { KernelConsts kq = k; kq.fastQ = 1; k_check_q_division<<<8192, 256, 0, stream()>>>(kq, lastBits, d_bad); }
+    unsigned int bad = 1;
+    HIP_CALL(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream()));
+    HIP_CALL(hipStreamSynchronize(stream()));
+    k.fastQ = (bad == 0) ? 1 : 0;
+    (void)hipFree(d_bad);
+}
+
+// sphx_fastmath_selftest: mismatch counts of {q division (exhaustive), sqrt (exhaustive over all
+// non-negative finite floats), div3 (samples)} against the plain IEEE operators
+void fastmath_selftest(float R, unsigned long long samples, unsigned int out[3], int flags[2])
+{
+    KernelConsts k = make_kernel_consts(R);
+    validate_fast_math(k);
+    flags[0] = k.fastQ; flags[1] = k.fastDiv;
+    unsigned int* d_bad = nullptr;
+    HIP_CALL(hipMalloc((void**)&d_bad, 3 * sizeof(unsigned int)));
+    HIP_CALL(hipMemsetAsync(d_bad, 0, 3 * sizeof(unsigned int), stream()));
+    unsigned int lastBits; const float top = 2.2f * R; std::memcpy(&lastBits, &top, 4);
+    { KernelConsts kq = k; kq.fastQ = 1; k_check_q_division<<<8192, 256, 0, stream()>>>(kq, lastBits, d_bad); }
+    k_check_sqrt<<<16384, 256, 0, stream()>>>(0u, 0x7f7fffffu, d_bad + 1);
+    const float r5 = R * R * R * R * R;
+    KernelConsts kf = k; kf.fastDiv = 1;
+    k_check_div3<<<8192, 256, 0, stream()>>>(kf, fminf(kPi * kEps * r5, k.stK * kEps), fmaxf(kPi * 2.1f * r5, k.stK * R), samples, d_bad + 2);
+    HIP_CALL(hipMemcpyAsync(out, d_bad, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    HIP_CALL(hipStreamSynchronize(stream()));
+    (void)hipFree(d_bad);
 }
 
 GridDesc make_grid_desc(int3 cs, float cellLength, int cellOffsetX)
@@ -168,34 +272,21 @@ __global__ void k_pack_kick_rt(float4* __restrict__ posm, float4* __restrict__ v
     vel[i] = v;
     vel4[i] = make_float4(v.x, v.y, v.z, 0.0f);
 }
-// tiled build: one wave per 64-particle tile decides whether the tile is staged, stages positions,
-// builds the rows with LDS slots as entries
-__global__ void __launch_bounds__(kTile) k_build_list_tiled(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt)
+// Row construction, one wave per 64-particle tile.  STREAM: each wave first decides whether its tile
+// can use LDS-streamed entries (fmt 2), records that in tileFmt, and stages candidates through LDS.
+template <bool STREAM>
+__global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt)
 {
-    __shared__ float4 pos[kTileSlots];
-    __shared__ TileTable tab;
-    const int lane = threadIdx.x;
-    const int tile = logical_block();
-    if (tile * kTile >= c.n) return;
-    const int i = tile * kTile + lane;
-    const bool tiled = tile_table(c, tile * kTile, tab);
-    if (tiled) {
-#pragma unroll 1
-        for (int r = 0; r < 18; ++r) {
-            const int s0 = tab.start[r], o = tab.off[r], len = tab.off[r + 1] - o;
-            const float4* src = r < 9 ? c.posm : c.bposm;
-            for (int t = lane; t < len; t += kTile) pos[o + t] = src[s0 + t];
-        }
-        __syncthreads();
-    }
-    if (lane == 0) tileFmt[tile] = tiled ? 1 : 0;
-    if (i < c.n) build_neighbor_row(c, tiled ? pos : nullptr, &tab, nbr, nbrCount, i);
-}
-// plain build: rows hold global indices
-__global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount)
-{
+    __shared__ float4 pos[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
     const int i = logical_block() * kWideBlock + threadIdx.x;
-    if (i < c.n) build_neighbor_row(c, nullptr, nullptr, nbr, nbrCount, i);
+    const int i0 = (i >> 6) << 6;
+    if (i0 >= c.n) return;                 // whole wave past the end
+    bool streamed = false;
+    if (STREAM) {
+        streamed = wave_ranges(c, i0).ok;
+        if ((threadIdx.x & 63) == 0) tileFmt[i >> 6] = streamed ? 2 : 0;
+    }
+    build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n);
 }
 
 SweepCache::SweepCache(int num)
@@ -209,7 +300,7 @@ SweepCache::SweepCache(int num)
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
 {
-    if (radius != radiusKey) { k = make_kernel_consts(radius); radiusKey = radius; }
+    if (radius != radiusKey) { k = make_kernel_consts(radius); validate_fast_math(k); radiusKey = radius; }
     g.xOff = cellOffsetX;
     if (cellLength != cellKey || cellSize.x != cellsKey.x || cellSize.y != cellsKey.y || cellSize.z != cellsKey.z) {
         g = make_grid_desc(cellSize, cellLength, cellOffsetX);
@@ -283,9 +374,9 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     ScopedKernel t("build_neighbor_list");
     unsigned int* rows = reinterpret_cast<unsigned int*>(nbr->addr());
     if (allowTiles && (flags & kFlagTiles))
-        k_build_list_tiled<<<xcd_grid(n, kTile), kTile, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
+        k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
     else
-        k_build_list<<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr());
+        k_build_list<false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
     listValid = true;
 }
 

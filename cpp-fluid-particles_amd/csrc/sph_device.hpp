@@ -25,6 +25,10 @@ struct KernelConsts {
     float stK;      // PI*cube(R)*cube(R)*cube(R)              CUDAFunctions.cuh:93
     float stC;      // 0.0156f*cube(R)*cube(R)                 CUDAFunctions.cuh:95
     float tCut;     // largest squared distance at which ANY kernel can be non-zero (exact)
+    // --- exact fast paths (validated on the device by validate_fast_math, else 0 = plain IEEE ops)
+    float rcpR;     // RN(1/R)
+    int fastQ;      // 1: x/R == fma-refined x*rcpR for EVERY float x in [0, 2.2R] (checked exhaustively)
+    int fastDiv;    // 1: the denominators of gradW / surface gradient stay inside [2^-100, 2^100]
 };
 
 struct GridDesc {
@@ -51,22 +55,96 @@ __device__ __forceinline__ float max_eps(float x) { return (x > kEps) ? x : kEps
 __device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
 __device__ __forceinline__ float min0(float x) { return (x < 0.0f) ? x : ((x == 0.0f) ? x : 0.0f); }
 
+// ---- exact fast paths for sqrt and division ----------------------------------------------------
+// hipcc's correctly rounded sqrtf / `/` are v_sqrt / v_rcp followed by FMA refinement, wrapped in
+// range scaling (v_div_scale, 2^+-32 pre-scaling) and special-case fix-ups (v_div_fmas,
+// v_div_fixup, v_cmp_class).  When the operands are known to be in the range where the scaling is
+// the identity, the refinement alone yields the same correctly rounded bits with a third of the
+// instructions.  Every pair evaluates ONE predicate (pair_needs_plain_ops) and the whole wave
+// branches uniformly: the <true> instantiations below are branch-free, the <false> ones are the
+// plain operators.  sphx_fastmath_selftest compares both bit for bit (x/R over every float the
+// sweeps can produce, sqrt over every non-negative float, the shared-denominator division over
+// 2^28 operand triples), and every parity test runs through them.
+
+// correctly rounded sqrt for x == 0 or x >= 2^-96: the compiler's own refinement without its
+// denormal pre-scaling
+template <bool FAST>
+__device__ __forceinline__ float sqrt_sel(float x)
+{
+    if (!FAST) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u);
+    const float sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    float out = (rm <= 0.0f) ? sm : s;
+    out = (rp > 0.0f) ? sp : out;
+    return out;
+}
+
+// n / den for three numerators sharing one denominator: one reciprocal refinement, then the
+// compiler's quotient refinement per component.  Requires den in [2^-90, 2^16] (k.fastDiv) and
+// every numerator zero or >= 2^-101 in magnitude.
+template <bool FAST>
+__device__ __forceinline__ float3 div3_sel(float3 n, float den)
+{
+    if (!FAST) return div3s(n, den);
+    float rc = __builtin_amdgcn_rcpf(den);
+    rc = __builtin_fmaf(__builtin_fmaf(-den, rc, 1.0f), rc, rc);
+    float3 q;
+    {
+        float q0 = n.x * rc; q0 = __builtin_fmaf(__builtin_fmaf(-den, q0, n.x), rc, q0);
+        q.x = __builtin_fmaf(__builtin_fmaf(-den, q0, n.x), rc, q0);
+    }
+    {
+        float q0 = n.y * rc; q0 = __builtin_fmaf(__builtin_fmaf(-den, q0, n.y), rc, q0);
+        q.y = __builtin_fmaf(__builtin_fmaf(-den, q0, n.y), rc, q0);
+    }
+    {
+        float q0 = n.z * rc; q0 = __builtin_fmaf(__builtin_fmaf(-den, q0, n.z), rc, q0);
+        q.z = __builtin_fmaf(__builtin_fmaf(-den, q0, n.z), rc, q0);
+    }
+    return q;
+}
+
+// x / R for the constant R: with y = RN(1/R), two FMA refinement steps of x*y equal RN(x/R) for
+// x == 0 or x >= 2^-47.  That is not a theorem for arbitrary R, so validate_fast_math checks EVERY
+// float in {0} U [2^-47, 2.2R] before k.fastQ is set.
+template <bool FAST>
+__device__ __forceinline__ float div_by_radius(float x, const KernelConsts& k)
+{
+    if (!FAST) return x / k.R;
+    float q0 = x * k.rcpR;
+    q0 = __builtin_fmaf(__builtin_fmaf(-k.R, q0, x), k.rcpR, q0);
+    return __builtin_fmaf(__builtin_fmaf(-k.R, q0, x), k.rcpR, q0);
+}
+
+// true when this pair must use the plain operators: a positive squared distance below 2^-96 (then
+// r < 2^-48 as well), a non-zero displacement component below 2^-101, or fast paths not validated
+__device__ __forceinline__ bool pair_needs_plain_ops(float3 d, float r2, const KernelConsts& k)
+{
+    const int e = min(min(__builtin_amdgcn_frexp_expf(d.x), __builtin_amdgcn_frexp_expf(d.y)), __builtin_amdgcn_frexp_expf(d.z));
+    return (k.fastQ & k.fastDiv) == 0 || e < -100 || (__float_as_uint(r2) - 1u) < (0x0f800000u - 1u);
+}
+
 // ---- smoothing kernels ------------------------------------------------------------------------
 // q = 2*|r|/R as computed by both cubic-spline functions
-__device__ __forceinline__ float q_of(float r, const KernelConsts& k) { return 2.0f * r / k.R; }
+template <bool FAST>
+__device__ __forceinline__ float q_of(float r, const KernelConsts& k) { return div_by_radius<FAST>(2.0f * r, k); }
 
 // cubic_spline_kernel, CUDAFunctions.cuh:23-35
 __device__ __forceinline__ float kW(float q, const KernelConsts& k)
 {
-    if (q > 2.0f || q < kEps) return 0.0f;
-    return k.wA * ((q > 1.0f) ? (2.0f - q) * (2.0f - q) * (2.0f - q) : ((3.0f * q - 6.0f) * q * q + 4.0f));
+    const float w = k.wA * ((q > 1.0f) ? (2.0f - q) * (2.0f - q) * (2.0f - q) : ((3.0f * q - 6.0f) * q * q + 4.0f));
+    return (q > 2.0f || q < kEps) ? 0.0f : w;
 }
 // cubic_spline_kernel_gradient, CUDAFunctions.cuh:37-50
+template <bool FAST>
 __device__ __forceinline__ float3 kGradW(float3 d, float q, const KernelConsts& k)
 {
-    if (q > 2.0f) return v3(0.0f, 0.0f, 0.0f);
-    const float3 a = div3s(d, kPi * (q + kEps) * k.R * k.R * k.R * k.R * k.R);
-    return mul3s(a, (q > 1.0f) ? ((12.0f - 3.0f * q) * q - 12.0f) : ((9.0f * q - 12.0f) * q));
+    const float3 a = div3_sel<FAST>(d, kPi * (q + kEps) * k.R * k.R * k.R * k.R * k.R);
+    const float3 g = mul3s(a, (q > 1.0f) ? ((12.0f - 3.0f * q) * q - 12.0f) : ((9.0f * q - 12.0f) * q));
+    return (q > 2.0f) ? v3(0.0f, 0.0f, 0.0f) : g;      // select instead of an early return (same value)
 }
 // viscosity_kernel_laplacian, CUDAFunctions.cuh:52-54
 __device__ __forceinline__ float kViscLap(float r, const KernelConsts& k)
@@ -74,11 +152,14 @@ __device__ __forceinline__ float kViscLap(float r, const KernelConsts& k)
     return (r <= k.R) ? (45.0f * (k.R - r) / k.viscDen) : 0.0f;
 }
 // surface_tension_kernel_gradient, CUDAFunctions.cuh:82-98
+template <bool FAST>
 __device__ __forceinline__ float3 kSurfGrad(float3 d, float x, const KernelConsts& k)
 {
-    if (x > k.R || x < kEps) return v3(0.0f, 0.0f, 0.0f);
-    const float3 a = div3s(smul3(136.0241f, neg3(d)), k.stK * x);
-    return mul3s(a, (2.0f * x <= k.R) ? (2.0f * cube(k.R - x) * cube(x) - k.stC) : (cube(k.R - x) * cube(x)));
+    const bool outside = x > k.R || x < kEps;
+    // (outside the support the quotient is discarded; a harmless denominator keeps it finite)
+    const float3 a = div3_sel<FAST>(smul3(136.0241f, neg3(d)), outside ? 1.0f : k.stK * x);
+    const float3 g = mul3s(a, (2.0f * x <= k.R) ? (2.0f * cube(k.R - x) * cube(x) - k.stC) : (cube(k.R - x) * cube(x)));
+    return outside ? v3(0.0f, 0.0f, 0.0f) : g;
 }
 
 // x^7 of the Tait equation of state (BasicSPHSolver.cu:108): fp64 multiply chain, one rounding
@@ -162,42 +243,38 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
     }
 }
 
-// ---- per-step compact neighbour list + LDS-staged tiles ---------------------------------------------
+// ---- per-step compact neighbour rows + LDS-streamed tiles -----------------------------------------
 // While positions are frozen (all sweeps of a WCSPH/DFSPH step; the two sweeps of one PBD
 // iteration) every sweep of particle i meets the same candidates and rejects the same ones, and a
 // rejected candidate contributes exactly +0.  The first pass therefore records, per particle, the
 // candidates with r2 <= tCut IN VISIT ORDER (self excluded: its terms are exactly zero); later
-// sweeps walk that list.  Order is preserved, so every accumulated bit is.
+// sweeps walk that row.  Order is preserved, so every accumulated bit is.
 //
 // Row layout: wave-interleaved — entry k of particle i lives at ((i>>6)*cap + k)*64 + (i&63), so
-// the 64 lanes of a wave read 256 contiguous bytes per k.  Bit 31 marks a boundary particle.
-// count > cap means the row overflowed: that lane falls back to the direct 27-cell walk.
+// the 64 lanes of a wave read 256 contiguous bytes per k.  count > cap means the row overflowed:
+// that lane falls back to the direct 27-cell walk.
 //
-// Tiles: a tile is 64 consecutive (cell-sorted) particles = one wave = one workgroup.  Because the
-// linear cell id runs z fastest, the 27-cell neighbourhoods of a tile are covered by 9 contiguous
-// cell-id ranges [first+off-1, last+off+1], off = (dx*gy+dy)*gz, i.e. 9 contiguous particle ranges
-// of the fluid array and 9 of the boundary array.  A tiled sweep copies those ranges (position+mass
-// and the one per-particle field the sweep reads from neighbours) into LDS with coalesced loads and
-// then gathers from LDS; row entries of a tiled tile are LDS slots instead of global indices.
-// Divergent global gathers cost ~64 cycles per wave-instruction on a CU's single texture-address
-// pipe and bound the un-tiled sweeps; LDS gathers cost ~10.  Tiles whose ranges exceed kTileSlots,
-// that touch the out-of-grid sentinel, or whose positions are not the binned ones (PBD) keep
-// global indices (tileFmt = 0).
+// Entry formats (per 64-particle tile, chosen by the row builder, recorded in tileFmt):
+//   fmt 0  bit31 = boundary, bits 0..30 = global index: sweeps gather from global memory.  Each
+//          divergent gather costs ~64 cycles of the CU's single texture-address pipe per
+//          wave-instruction, which is what bounds these sweeps.
+//   fmt 2  bits 30..29 = dx group g (0,1,2 <-> dx = -1,0,+1), bit 28 = boundary, bits 0..27 = slot
+//          in the LDS stage of that group.  A tile is one wave of consecutive cell-sorted particles;
+//          because the cell id runs z fastest, the neighbour cells of the whole tile for one
+//          (dx,dy) are ONE contiguous cell range [first+off-1, last+off+1], off = (dx*gy+dy)*gz,
+//          i.e. one contiguous particle range of the fluid array and one of the boundary array.
+//          The sweep streams through the three dx groups: the wave copies the group's 3+3 ranges
+//          (position+mass and the one per-neighbour field of the sweep) into its private LDS slab
+//          with coalesced loads, then every lane walks the entries of that group from LDS.  Rows
+//          are in visit order (dx outermost), so the entries of a group are contiguous.
+//          Used when positions are the binned ones (not PBD), the tile is in-grid and every group
+//          fits kGroupSlots; otherwise the tile keeps fmt 0.
 constexpr int kTile = 64;
-constexpr int kWideBlock = 256;     // threads per block of the un-tiled kernels (4 adjacent tiles share a CU's L1)
-constexpr int kTileSlots = 1280;
+constexpr int kWideBlock = 256;     // threads per block: 4 waves = 4 adjacent tiles share a CU
+constexpr int kGroupSlots = 384;    // LDS slots per wave and dx group
 constexpr unsigned int kBoundaryBit = 0x80000000u;
-
-struct SweepCtx {
-    GridDesc g; KernelConsts k;
-    const int* csF; const float4* posm;     // fluid cell starts, packed (x,y,z,mass)
-    const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass)
-    const unsigned int* nbr; const int* nbrCount; int cap;   // nbr == nullptr: direct sweeps only
-    const int* tileFmt;                     // per tile: 1 = row entries are LDS slots (nullptr: never)
-    float4* vel4;                           // 16-byte aligned mirror of the fluid velocities (one gather)
-    float4* cg4;                            // 16-byte aligned mirror of the colour gradient
-    int n;
-};
+constexpr unsigned int kStreamBoundaryBit = 0x10000000u;
+constexpr unsigned int kStreamSlotMask = 0x0fffffffu;
 
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each XCD
 // has its own L2.  Logical block = (b % 8) * chunk + b / 8 gives every XCD one contiguous run of
@@ -207,37 +284,59 @@ struct SweepCtx {
 __device__ __forceinline__ int logical_block() { return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3); }
 inline unsigned int xcd_grid(int n, int block) { const int nb = n > 0 ? (n - 1) / block + 1 : 1; return (unsigned int)(((nb + 7) / 8) * 8); }
 
-struct TileTable { int start[18]; int off[19]; };   // ranges 0..8 fluid (dx,dy), 9..17 boundary
+struct SweepCtx {
+    GridDesc g; KernelConsts k;
+    const int* csF; const float4* posm;     // fluid cell starts, packed (x,y,z,mass)
+    const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass)
+    const unsigned int* nbr; const int* nbrCount; int cap;   // nbr == nullptr: direct sweeps only
+    const int* tileFmt;                     // per tile entry format (nullptr: all tiles fmt 0)
+    float4* vel4;                           // 16-byte aligned mirror of the fluid velocities (one gather)
+    float4* cg4;                            // 16-byte aligned mirror of the colour gradient
+    int n;
+};
 
-// All 64 lanes call this.  Returns true when the tile can be staged.
-__device__ __forceinline__ bool tile_table(const SweepCtx& c, const int i0, TileTable& tab)
+// The 18 neighbour ranges of a tile, one per lane (lanes 0..8 fluid, 9..17 boundary; r = 3*(dx+1) +
+// (dy+1)), with each range's offset inside the LDS stage of its dx group (fluid dy=-1,0,1 first,
+// then boundary dy=-1,0,1).  Wave-synchronous: all 64 lanes call it, only shuffles inside.
+struct WaveRanges { int start, len, off; bool ok; };
+
+__device__ __forceinline__ WaveRanges wave_ranges(const SweepCtx& c, const int i0)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    WaveRanges w; w.start = 0; w.len = 0; w.off = 0;
     const int i1 = min(i0 + kTile, c.n);
     const int3 cf = cell_of(xyz4(c.posm[i0]), c.g);
     const int3 cl = cell_of(xyz4(c.posm[i1 - 1]), c.g);
     const int idF = cell_id(cf.x, cf.y, cf.z, c.g), idL = cell_id(cl.x, cl.y, cl.z, c.g);
-    const bool ok = idF < c.g.C && idL < c.g.C && idF <= idL;
-    int len = 0;
+    bool ok = idF < c.g.C && idL < c.g.C && idF <= idL;
+    const int r = lane % 9;
     if (lane < 18) {
-        const int r = lane % 9;
         const int off = ((r / 3 - 1) * c.g.gy + (r % 3 - 1)) * c.g.gz;
         const int lo = max(idF + off - 1, 0), hi = min(idL + off + 1, c.g.C - 1);
         const int* cs = lane < 9 ? c.csF : c.csB;
-        int s0 = 0;
-        if (ok && lo <= hi) { s0 = cs[lo]; len = cs[hi + 1] - s0; }
-        tab.start[lane] = s0;
+        if (ok && lo <= hi) { w.start = cs[lo]; w.len = cs[hi + 1] - w.start; }
     }
-    int incl = len;
+    // position q of this lane's range inside its group: fluid dy (0..2), then boundary dy (3..5)
+    const int g = r / 3, q = (lane < 9 ? 0 : 3) + r % 3;
+    int gsize = 0;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
+    for (int qq = 0; qq < 6; ++qq) {
+        const int src = (qq < 3 ? 0 : 9) + g * 3 + (qq % 3);
+        const int l = __shfl(w.len, src, 64);
+        if (qq < q) w.off += l;
+        gsize += l;
     }
-    if (lane < 18) tab.off[lane] = incl - len;
-    if (lane == 17) tab.off[18] = incl;
-    __syncthreads();
-    return ok && tab.off[18] <= kTileSlots;
+    // every group must fit the stage (lanes 0,3,6 hold the three group sizes)
+    const int g0 = __shfl(gsize, 0, 64), g1 = __shfl(gsize, 3, 64), g2 = __shfl(gsize, 6, 64);
+    w.ok = ok && g0 <= kGroupSlots && g1 <= kGroupSlots && g2 <= kGroupSlots;
+    return w;
+}
+
+// make this wave's LDS writes visible to its own later reads (and vice versa) without a block barrier
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // direct walk in reference order; `visit(j, isBoundary, d, r2, mass_j)`
@@ -280,95 +379,191 @@ __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, V
     }
 }
 
-// The sweep of one particle.  Op supplies `Field` (the per-neighbour value its pair term reads) and
-// `stage(isBoundary, j)` (its global load; boundaries yield zeros); Body::pair(field, isBoundary,
-// d, r2, mass_j, j_or_-1) accumulates.  ldsPos/ldsField are the staged tile (nullptr: global).
-template <bool WANT_BOUNDARY, class Op, class Body>
-__device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, const float4* ldsPos,
-                                      const typename Op::Field* ldsField, const int i, const float3 pi, Body& body)
+// One pair term: the whole wave takes the branch-free fast arithmetic unless some lane's pair needs
+// the plain operators (a wave-uniform branch, so no exec-mask bookkeeping per pair).
+template <class Body, class Field>
+__device__ __forceinline__ void pair_dispatch(Body& body, const KernelConsts& k, const Field& f, bool isB, float3 d, float r2,
+                                              float mj, int idx)
 {
-    if (c.nbr) {
-        const int cnt = c.nbrCount[i];
-        if (cnt <= c.cap) {
-            const unsigned int* row = c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
-            if (ldsPos) {
-                for (int t = 0; t < cnt; ++t) {
-                    const unsigned int e = row[(size_t)t * 64u];
-                    const bool isB = (e & kBoundaryBit) != 0u;
-                    if (!WANT_BOUNDARY && isB) continue;
-                    const int slot = (int)(e & ~kBoundaryBit);
-                    const float4 pj = ldsPos[slot];
-                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                    body.pair(ldsField[slot], isB, d, dot3(d, d), pj.w, -1);
-                }
-            } else {
-                for (int t = 0; t < cnt; ++t) {
-                    const unsigned int e = row[(size_t)t * 64u];
-                    const bool isB = (e & kBoundaryBit) != 0u;
-                    if (!WANT_BOUNDARY && isB) continue;
-                    const int idx = (int)(e & ~kBoundaryBit);
-                    const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
-                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                    body.pair(op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
+    if (__builtin_expect(__any(pair_needs_plain_ops(d, r2, k)), 0)) body.template pair<false>(f, isB, d, r2, mj, idx);
+    else body.template pair<true>(f, isB, d, r2, mj, idx);
+}
+
+// The sweep of one particle (all 64 lanes of a wave call it together; `valid` = lane has a particle).
+// Op supplies `Field` (the per-neighbour value its pair term reads) and `stage(isBoundary, j)` (its
+// global load; boundaries yield zeros); Body::pair(field, isBoundary, d, r2, mass_j, j_or_-1)
+// accumulates.  ldsPos/ldsField: this wave's LDS slab (kGroupSlots entries) or nullptr.
+template <bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* ldsPos, typename Op::Field* ldsField,
+                                      const int i, const bool valid, const float3 pi, Body& body)
+{
+    const int lane = threadIdx.x & 63;
+    const bool rows = c.nbr != nullptr;
+    const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
+    const bool useRow = rows && valid && cnt <= c.cap;
+    const unsigned int* row = rows ? c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63) : nullptr;
+    // tile format is wave-uniform (i>>6 is the same for all lanes of the wave)
+    const int fmt = (rows && ldsPos && c.tileFmt) ? c.tileFmt[__builtin_amdgcn_readfirstlane(i >> 6)] : 0;
+    if (fmt == 2) {
+        const WaveRanges w = wave_ranges(c, (i >> 6) << 6);
+        int k = 0;
+        unsigned int e = (useRow && cnt > 0) ? row[0] : 0xffffffffu;
+#pragma unroll 1
+        for (int g = 0; g < 3; ++g) {
+#pragma unroll 1
+            for (int qq = 0; qq < 6; ++qq) {
+                const int src = (qq < 3 ? 0 : 9) + g * 3 + (qq % 3);
+                const int s0 = __shfl(w.start, src, 64), ln = __shfl(w.len, src, 64), o = __shfl(w.off, src, 64);
+                const bool isB = qq >= 3;
+                if (!WANT_BOUNDARY && isB) continue;
+                const float4* from = isB ? c.bposm : c.posm;
+                for (int t = lane; t < ln; t += kTile) {
+                    ldsPos[o + t] = from[s0 + t];
+                    ldsField[o + t] = op.stage(isB, s0 + t);
                 }
             }
-            return;
+            wave_lds_fence();
+            while (useRow && k < cnt && (e >> 29) == (unsigned)g) {
+                const bool isB = (e & kStreamBoundaryBit) != 0u;
+                const int slot = (int)(e & kStreamSlotMask);
+                ++k;
+                const unsigned int next = (k < cnt) ? row[(size_t)k * 64u] : 0xffffffffu;
+                if (WANT_BOUNDARY || !isB) {
+                    const float4 pj = ldsPos[slot];
+                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                    pair_dispatch(body, c.k, ldsField[slot], isB, d, dot3(d, d), pj.w, -1);
+                }
+                e = next;
+            }
+            wave_lds_fence();
         }
+        if (valid && !useRow)
+            walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+                body.template pair<false>(op.stage(isB, j), isB, d, r2, mj, j);
+            });
+        return;
+    }
+    if (!valid) return;
+    if (useRow) {
+        // The chain "row entry -> gather -> arithmetic" is latency-bound when walked one entry at a
+        // time (the row streams from HBM, the gathers mostly from L2).  kAhead entries and their
+        // gathers are issued together so kAhead*3 loads are in flight per lane; the pair terms are
+        // then accumulated strictly in row order.
+        constexpr int kAhead = 4;
+        int t = 0;
+        for (; t + kAhead <= cnt; t += kAhead) {
+            unsigned int e[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) e[u] = row[(size_t)(t + u) * 64u];
+            float4 pj[kAhead];
+            typename Op::Field f[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const bool isB = (e[u] & kBoundaryBit) != 0u;
+                const int idx = (int)(e[u] & ~kBoundaryBit);
+                pj[u] = isB ? c.bposm[idx] : c.posm[idx];
+                f[u] = op.stage(isB, idx);
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const bool isB = (e[u] & kBoundaryBit) != 0u;
+                if (!WANT_BOUNDARY && isB) continue;
+                const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+                pair_dispatch(body, c.k, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & ~kBoundaryBit));
+            }
+        }
+        for (; t < cnt; ++t) {
+            const unsigned int e = row[(size_t)t * 64u];
+            const bool isB = (e & kBoundaryBit) != 0u;
+            if (!WANT_BOUNDARY && isB) continue;
+            const int idx = (int)(e & ~kBoundaryBit);
+            const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
+            const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+            pair_dispatch(body, c.k, op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
+        }
+        return;
     }
     walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
-        body.pair(op.stage(isB, j), isB, d, r2, mj, j);
+        body.template pair<false>(op.stage(isB, j), isB, d, r2, mj, j);
     });
 }
 
-// Row construction for particle i: the same walk; the three z-adjacent cells of a (dx,dy) column
-// are contiguous in memory, so when they hold no boundary particles the fluid ranges are visited
-// as one run (identical order).  With a staged tile candidates are read from LDS and entries are
-// LDS slots: slot = tab.off[r] + (j - tab.start[r]), r = (dx+1)*3 + (dy+1) (+9 for boundaries).
-__device__ __forceinline__ void build_neighbor_row(const SweepCtx& c, const float4* ldsPos, const TileTable* tab,
-                                                   unsigned int* nbr, int* nbrCount, const int i)
+// Row construction for one wave = one tile.  Same walk as walk_cells; the three z-adjacent cells of
+// a (dx,dy) column are contiguous in memory, so when they hold no boundary particles the fluid
+// ranges are visited as one run (identical order).  With `ldsPos` (streamed tile, fmt 2) the wave
+// stages one dx group at a time, candidates are read from LDS and entries carry (group, slot).
+__device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* ldsPos, const bool streamed,
+                                                    unsigned int* nbr, int* nbrCount, const int i, const bool valid)
 {
-    const float4 self = c.posm[i];
+    const int lane = threadIdx.x & 63;
+    const float4 self = valid ? c.posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float3 pi = v3(self.x, self.y, self.z);
     unsigned int* row = nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
     int cnt = 0;
     const int3 c0 = cell_of(pi, c.g);
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
+    WaveRanges w; w.start = w.len = w.off = 0; w.ok = false;
+    if (streamed) w = wave_ranges(c, (i >> 6) << 6);
+#pragma unroll 1
     for (int dx = -1; dx <= 1; ++dx) {
+        const int g = dx + 1;
+        if (streamed) {
+#pragma unroll 1
+            for (int qq = 0; qq < 6; ++qq) {
+                const int src = (qq < 3 ? 0 : 9) + g * 3 + (qq % 3);
+                const int s0 = __shfl(w.start, src, 64), ln = __shfl(w.len, src, 64), o = __shfl(w.off, src, 64);
+                const float4* from = qq >= 3 ? c.bposm : c.posm;
+                for (int t = lane; t < ln; t += kTile) ldsPos[o + t] = from[s0 + t];
+            }
+            wave_lds_fence();
+        }
+        // slot = j + shift for the three columns of this group (shuffles stay in uniform control flow)
+        int fSh[3] = {0, 0, 0}, bSh[3] = {0, 0, 0};
+        if (streamed) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                fSh[t] = __shfl(w.off, g * 3 + t, 64) - __shfl(w.start, g * 3 + t, 64);
+                bSh[t] = __shfl(w.off, 9 + g * 3 + t, 64) - __shfl(w.start, 9 + g * 3 + t, 64);
+            }
+        }
         const int X = c0.x + dx;
-        if (X < 0 || X >= c.g.gx) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int Y = c0.y + dy;
-            if (Y < 0 || Y >= c.g.gy || zlo > zhi) continue;
-            const int base = (X * c.g.gy + Y) * c.g.gz;
-            const int r = (dx + 1) * 3 + (dy + 1);
-            const int fShift = ldsPos ? tab->off[r] - tab->start[r] : 0;       // slot = j + shift
-            const int bShift = ldsPos ? tab->off[r + 9] - tab->start[r + 9] : 0;
-            const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
-            const int step = noWall ? (zhi - zlo + 1) : 1;
-            for (int z = zlo; z <= zhi; z += step) {
-                const int cell = base + z;
-                const int e = c.csF[cell + step];
-                for (int j = c.csF[cell]; j < e; ++j) {
-                    const float4 pj = ldsPos ? ldsPos[j + fShift] : c.posm[j];
-                    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                    if (dot3(d, d) > c.k.tCut || j == i) continue;
-                    if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift);
-                    ++cnt;
-                }
-                if (!noWall) {
-                    const int eb = c.csB[cell + 1];
-                    for (int j = c.csB[cell]; j < eb; ++j) {
-                        const float4 pj = ldsPos ? ldsPos[j + bShift] : c.bposm[j];
+        if (valid && X >= 0 && X < c.g.gx && zlo <= zhi) {
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int Y = c0.y + dy;
+                if (Y < 0 || Y >= c.g.gy) continue;
+                const int base = (X * c.g.gy + Y) * c.g.gz;
+                const int fShift = dy < 0 ? fSh[0] : (dy == 0 ? fSh[1] : fSh[2]);
+                const int bShift = dy < 0 ? bSh[0] : (dy == 0 ? bSh[1] : bSh[2]);
+                const unsigned int fTag = streamed ? ((unsigned)g << 29) : 0u;
+                const unsigned int bTag = streamed ? (((unsigned)g << 29) | kStreamBoundaryBit) : kBoundaryBit;
+                const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
+                const int step = noWall ? (zhi - zlo + 1) : 1;
+                for (int z = zlo; z <= zhi; z += step) {
+                    const int cell = base + z;
+                    const int e = c.csF[cell + step];
+                    for (int j = c.csF[cell]; j < e; ++j) {
+                        const float4 pj = streamed ? ldsPos[j + fShift] : c.posm[j];
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                        if (dot3(d, d) > c.k.tCut) continue;
-                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | kBoundaryBit;
+                        if (dot3(d, d) > c.k.tCut || j == i) continue;
+                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift) | fTag;
                         ++cnt;
+                    }
+                    if (!noWall) {
+                        const int eb = c.csB[cell + 1];
+                        for (int j = c.csB[cell]; j < eb; ++j) {
+                            const float4 pj = streamed ? ldsPos[j + bShift] : c.bposm[j];
+                            const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                            if (dot3(d, d) > c.k.tCut) continue;
+                            if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag;
+                            ++cnt;
+                        }
                     }
                 }
             }
         }
+        if (streamed) wave_lds_fence();
     }
-    nbrCount[i] = cnt;
+    if (valid) nbrCount[i] = cnt;
 }
 
 __device__ __forceinline__ float3 ld3(const float3* __restrict__ p, int i) { return p[i]; }

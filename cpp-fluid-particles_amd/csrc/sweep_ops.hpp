@@ -15,49 +15,27 @@
 
 namespace sphx {
 
-// ---- tile staging + launch ------------------------------------------------------------------------
-template <class Op, bool TILED>
-struct TileLds {
-    float4 pos[TILED ? kTileSlots : 1];
-    typename Op::Field field[TILED ? kTileSlots : 1];
-    TileTable tab;
+// ---- launch: 256-thread blocks, one 64-particle tile per wave, optional per-wave LDS slab ------------
+template <class Op, bool STREAM>
+struct BlockLds {
+    float4 pos[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
+    typename Op::Field field[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
 };
 
-// copies the tile's 18 ranges into LDS (coalesced); returns false when this tile is not staged
-template <class Op, bool TILED>
-__device__ __forceinline__ bool stage_tile(const Op& op, const SweepCtx& c, TileLds<Op, TILED>& lds)
+template <class Op, bool STREAM>
+__global__ void __launch_bounds__(kWideBlock) k_run_op(const Op op, int n)
 {
-    const int tile = logical_block();
-    if (!TILED || !c.nbr || !c.tileFmt || tile * kTile >= c.n || !c.tileFmt[tile]) return false;
-    tile_table(c, tile * kTile, lds.tab);
-    const int lane = threadIdx.x;
-#pragma unroll 1
-    for (int r = 0; r < 18; ++r) {
-        const int s0 = lds.tab.start[r], o = lds.tab.off[r], len = lds.tab.off[r + 1] - o;
-        const float4* src = r < 9 ? c.posm : c.bposm;
-        for (int t = lane; t < len; t += kTile) {
-            lds.pos[o + t] = src[s0 + t];
-            lds.field[o + t] = op.stage(r >= 9, s0 + t);
-        }
-    }
-    __syncthreads();
-    return true;
-}
-
-// TILED: one wave per 64-particle tile with LDS staging; otherwise 256-thread blocks, global gathers
-template <class Op, bool TILED>
-__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_run_op(const Op op, int n)
-{
-    __shared__ TileLds<Op, TILED> lds;
-    const bool tiled = stage_tile<Op, TILED>(op, op.c, lds);
-    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
-    if (i < n) op(i, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr);
+    __shared__ BlockLds<Op, STREAM> lds;
+    const int wave = threadIdx.x >> 6;
+    const int i = logical_block() * kWideBlock + threadIdx.x;
+    if (((i >> 6) << 6) >= n) return;      // whole wave past the end (wave-uniform)
+    op(i, i < n, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
 }
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
     if (n <= 0) return;
-    if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(op, n);
+    if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(op, n);
     else k_run_op<Op, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(op, n);
 }
 
@@ -71,6 +49,8 @@ __device__ __forceinline__ void accumulate_error(long long fixed, unsigned long 
 
 __device__ __forceinline__ float4 f4(const float3 v) { return make_float4(v.x, v.y, v.z, 0.0f); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+// the lane's own position (lanes past the end of the array still take part in wave-wide staging)
+__device__ __forceinline__ float3 own_pos(const SweepCtx& c, int i, bool valid) { return valid ? xyz(c.posm[i]) : v3(0, 0, 0); }
 
 // =================================================================================== shared sweeps
 // Per-particle properties that depend on positions (and the current velocities) only:
@@ -87,27 +67,29 @@ struct OpFluidProps {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return (VISC && !isB) ? c.vel4[j] : f4zero(); }
     struct Body {
         const OpFluidProps& o; float3 vi; float3 a; float3 cg; float cden; float den;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
-            const float r = sqrtf(r2);
+            const float r = sqrt_sel<FAST>(r2);
             if (VISC && !isB)
                 a = add3(a, mul3s(smul3(mj, div3s(sub3(xyz(vj), vi), o.rho0)), kViscLap(r, o.c.k)));
             if (COLOR || DENS) {
-                const float q = q_of(r, o.c.k);
+                const float q = q_of<FAST>(r, o.c.k);
                 const float w = kW(q, o.c.k);
                 if (DENS) den += mj * w;
                 if (COLOR) {
                     const float vol = mj / (isB ? o.rhoB : o.rho0);
-                    cg = add3(cg, smul3(vol, kGradW(d, q, o.c.k)));
+                    cg = add3(cg, smul3(vol, kGradW<FAST>(d, q, o.c.k)));
                     cden += vol * w;
                 }
             }
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, VISC ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f};
-        sweep<COLOR || DENS>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        Body b{*this, (VISC && valid) ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f};
+        sweep<COLOR || DENS>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
         if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
         if (DENS) {
@@ -131,21 +113,23 @@ struct OpSurface {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.cg4[j]; }
     struct Body {
         const OpSurface& o; float dii, li, ml; float3 a;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field cg4, bool, float3 d, float r2, float mj, int)
         {
-            const float r = sqrtf(r2);
-            const float q = q_of(r, o.c.k);
+            const float r = sqrt_sel<FAST>(r2);
+            const float q = q_of<FAST>(r, o.c.k);
             const float3 cgj = xyz(cg4);
-            a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad(d, r, o.c.k)));
-            a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW(d, q, o.c.k)), li), ml));
+            a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
+            a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW<FAST>(d, q, o.c.k)), li), ml));
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        const float3 cgi = colorGrad[i];
+        const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const float li = len3(cgi);
         Body b{*this, dot3(cgi, cgi), li, max_eps(li), v3(0, 0, 0)};
-        sweep<false>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        sweep<false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
         const float3 vn = add3(v, mul3s(b.a, dt));
@@ -163,16 +147,18 @@ struct OpPressureForce {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : pterm[j]; }
     struct Body {
         const OpPressureForce& o; int i; float pti; float3 a;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field ptj, bool isB, float3 d, float r2, float mj, int idx)
         {
             if (!isB && idx == i) return;
-            a = add3(a, smul3(-mj * (pti + ptj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
+            a = add3(a, smul3(-mj * (pti + ptj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, i, pterm[i], v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        Body b{*this, i, valid ? pterm[i] : 0.0f, v3(0, 0, 0)};
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         float3 a = b.a;
         if (len3(a) > kMaxA) a = mul3s(mul3s(a, 1.0f / sqrtf(dot3(a, a))), kMaxA);
         vel[i] = add3(vel[i], mul3s(a, dt));
@@ -216,11 +202,12 @@ struct OpDfsphHead {
     struct Body {
         const OpDfsphHead& o; float3 vi; float den, sl, e; float3 gs;
         bool withRate;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
-            const float q = q_of(sqrtf(r2), o.c.k);
+            const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
             den += mj * kW(q, o.c.k);
-            const float3 gw = kGradW(d, q, o.c.k);
+            const float3 gw = kGradW<FAST>(d, q, o.c.k);
             const float3 gr = smul3(mj, gw);
             gs = add3(gs, gr);
             if (!isB) sl += dot3(gr, gr);
@@ -228,16 +215,18 @@ struct OpDfsphHead {
         }
     };
 };
-template <bool WITH_RATE, bool TILED>
-__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_dfsph_head(const OpDfsphHead o, int n)
+template <bool WITH_RATE, bool STREAM>
+__global__ void __launch_bounds__(kWideBlock) k_dfsph_head(const OpDfsphHead o, int n)
 {
-    __shared__ TileLds<OpDfsphHead, TILED> lds;
-    const bool tiled = stage_tile<OpDfsphHead, TILED>(o, o.c, lds);
-    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
+    __shared__ BlockLds<OpDfsphHead, STREAM> lds;
+    const int wave = threadIdx.x >> 6;
+    const int i = logical_block() * kWideBlock + threadIdx.x;
+    if (((i >> 6) << 6) >= n) return;
+    const bool valid = i < n;
     long long fixed = 0;
-    if (i < n) {
-        OpDfsphHead::Body b{o, WITH_RATE ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
-        sweep<true>(o, o.c, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr, i, xyz(o.c.posm[i]), b);
+    OpDfsphHead::Body b{o, (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
+    sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
+    if (valid) {
         const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
         o.density[i] = b.den;
         o.alpha[i] = al;
@@ -249,7 +238,7 @@ template <bool WITH_RATE>
 inline void launch_dfsph_head(const OpDfsphHead& o, int n)
 {
     if (n <= 0) return;
-    if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(o, n);
+    if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
     else k_dfsph_head<WITH_RATE, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -263,31 +252,32 @@ struct OpRate {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
     struct Body {
         const OpRate& o; float3 vi; float e;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool, float3 d, float r2, float mj, int)
         {
-            e += mj * dot3(sub3(vi, xyz(vj)), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k));
+            e += mj * dot3(sub3(vi, xyz(vj)), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k));
         }
     };
 };
-template <bool DENSITY_MODE, int WARM, bool TILED>
-__global__ void __launch_bounds__(TILED ? kTile : kWideBlock) k_rate(const OpRate o, int n)
+template <bool DENSITY_MODE, int WARM, bool STREAM>
+__global__ void __launch_bounds__(kWideBlock) k_rate(const OpRate o, int n)
 {
-    __shared__ TileLds<OpRate, TILED> lds;
-    const bool tiled = stage_tile<OpRate, TILED>(o, o.c, lds);
-    const int i = logical_block() * (TILED ? kTile : kWideBlock) + threadIdx.x;
+    __shared__ BlockLds<OpRate, STREAM> lds;
+    const int wave = threadIdx.x >> 6;
+    const int i = logical_block() * kWideBlock + threadIdx.x;
+    if (((i >> 6) << 6) >= n) return;
+    const bool valid = i < n;
     long long fixed = 0;
-    if (i < n) {
-        OpRate::Body b{o, o.vel[i], 0.0f};
-        sweep<true>(o, o.c, tiled ? lds.pos : nullptr, tiled ? lds.field : nullptr, i, xyz(o.c.posm[i]), b);
-        fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
-    }
+    OpRate::Body b{o, valid ? o.vel[i] : v3(0, 0, 0), 0.0f};
+    sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
+    if (valid) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool DENSITY_MODE, int WARM>
 inline void launch_rate_kernel(const OpRate& o, int n)
 {
     if (n <= 0) return;
-    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<xcd_grid(n, kTile), kTile, 0, stream()>>>(o, n);
+    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
     else k_rate<DENSITY_MODE, WARM, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -302,15 +292,17 @@ struct OpCorrect {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : kappa[j]; }
     struct Body {
         const OpCorrect& o; float ki; float3 a;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field kj, bool, float3 d, float r2, float mj, int)
         {
-            a = add3(a, smul3(mj * (ki + kj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
+            a = add3(a, smul3(mj * (ki + kj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, kappa[i], v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        Body b{*this, valid ? kappa[i] : 0.0f, v3(0, 0, 0)};
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         const float3 vn = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
         vel[i] = vn;
         c.vel4[i] = f4(vn);
@@ -328,20 +320,22 @@ struct OpLambda {
     __device__ __forceinline__ Field stage(bool, int) const { return 0.0f; }
     struct Body {
         const OpLambda& o; float den, sl; float3 gs;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field, bool, float3 d, float r2, float mj, int)
         {
-            const float q = q_of(sqrtf(r2), o.c.k);
+            const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
             den += mj * kW(q, o.c.k);
-            float3 gr = smul3(-mj, kGradW(d, q, o.c.k));
+            float3 gr = smul3(-mj, kGradW<FAST>(d, q, o.c.k));
             if (o.rb != 1.0f) gr = div3s(gr, o.rb);
             gs = sub3(gs, gr);
             sl += dot3(gr, gr);
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         density[i] = b.den;
         float lam = (b.den > rho0) ? (-(b.den / rho0 - 1.0f) / (dot3(b.gs, b.gs) + b.sl + kEps)) : 0.0f;
         lam *= relaxation;
@@ -358,15 +352,17 @@ struct OpDeltaPos {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : lambda[j]; }
     struct Body {
         const OpDeltaPos& o; float li; float3 a;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field lj, bool, float3 d, float r2, float mj, int)
         {
-            a = add3(a, smul3(mj * (li + lj), kGradW(d, q_of(sqrtf(r2), o.c.k), o.c.k)));
+            a = add3(a, smul3(mj * (li + lj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, lambda[i], v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        Body b{*this, valid ? lambda[i] : 0.0f, v3(0, 0, 0)};
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         deltaPos[i] = div3s(b.a, rho0);
     }
 };
@@ -382,22 +378,24 @@ struct OpXsph {
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
     struct Body {
         const OpXsph& o; float3 vi; float3 a; float3 cg; float cden;
+        template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
-            const float q = q_of(sqrtf(r2), o.c.k);
+            const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
             const float w = kW(q, o.c.k);
             if (!isB) a = add3(a, mul3s(smul3(mj, sub3(xyz(vj), vi)), w));
             if (COLOR) {
                 const float vol = mj / (isB ? o.rhoB : o.rho0);
-                cg = add3(cg, smul3(vol, kGradW(d, q, o.c.k)));
+                cg = add3(cg, smul3(vol, kGradW<FAST>(d, q, o.c.k)));
                 cden += vol * w;
             }
         }
     };
-    __device__ void operator()(int i, const float4* lp, const Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, vel[i], v3(0, 0, 0), v3(0, 0, 0), 0.0f};
-        sweep<COLOR>(*this, c, lp, lf, i, xyz(c.posm[i]), b);
+        Body b{*this, valid ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f};
+        sweep<COLOR>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));   // not the live velocity yet: vel4 untouched
         if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
     }

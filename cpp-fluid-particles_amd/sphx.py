@@ -30,7 +30,7 @@ EXPORTS = [
     "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_set_count", "sphx_use_stream",
-    "sphx_sync", "sphx_cell_columns",
+    "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest",
 ]
 
 
@@ -210,6 +210,13 @@ def use_stream(hip_stream_handle):
 
 def cell_columns(device_xyz_ptr, n, cell_length, device_out_ptr):
     _check(lib().sphx_cell_columns(C.c_void_p(device_xyz_ptr), n, cell_length, C.c_void_p(device_out_ptr)))
+
+
+def fastmath_selftest(radius, samples=1 << 28):
+    bad = (C.c_uint * 3)(); en = (C.c_int * 2)()
+    lib().sphx_fastmath_selftest.argtypes = [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    _check(lib().sphx_fastmath_selftest(radius, samples, bad, en))
+    return list(bad), list(en)
 
 
 def sync():

@@ -181,6 +181,12 @@ int  sphx_eval_kernels(const float *r3, int n, float radius, float *W, float *gr
 int  sphx_ieee_probe(const float *a, const float *b, const float *c, int n,
                      float *quot, float *root, int *trunc, float *muladd);
 
+/* Self-test of the engine's exact fast paths for sqrt and division (sph_device.hpp): counts
+ * bit mismatches against the plain IEEE operators for {x/R over every float x in [0, 2.2R]; sqrt
+ * over every non-negative finite float; shared-denominator division over `samples` pseudo-random
+ * operand triples}.  enabled2 = {fastQ, fastDiv} as the engine would set them for this radius.   */
+int  sphx_fastmath_selftest(float radius, unsigned long long samples, unsigned int *mismatches3, int *enabled2);
+
 /* generate_dots (vbo.cu:26-51): position copy + density colour ramp into caller device
  * buffers dot[3n], color[3n] (the render-side consumer of the path).                          */
 int  sphx_generate_dots(const sphx_system *sys, float *device_dot, float *device_color);

@@ -269,3 +269,16 @@ def test_cpp_api_driver_matches_oracle(oracle, tmp_path):
         o.step()
     assert_bit_equal(pos, o.get(oracle.F_POS), "demo pos")
     assert_bit_equal(den, o.get(oracle.F_DENSITY), "demo density")
+
+
+@pytest.mark.parametrize("radius", [0.04, 0.013, 0.5])
+def test_exact_fast_paths_match_ieee_operators(sphx, radius):
+    """the rcp/sqrt + FMA-refinement fast paths equal the plain IEEE operators: x/R exhaustively over
+    every float in [0, 2.2R], sqrt exhaustively over every non-negative finite float, the shared-
+    denominator division over 2^28 pseudo-random triples incl. zero and tiny numerators."""
+    bad, enabled = sphx.fastmath_selftest(radius)
+    assert bad[1] == 0, "sqrt_exact differs from sqrtf"
+    assert bad[2] == 0, "div3_exact differs from IEEE division"
+    assert enabled[0] == (1 if bad[0] == 0 else 0)
+    if radius == 0.04:
+        assert enabled == [1, 1], "the reference radius must run on the fast paths"
