@@ -296,7 +296,8 @@ int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
 
 int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
 {
-    if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM && field != SPHX_F_BMASS)
+    if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM && field != SPHX_F_BMASS && field != SPHX_F_POS_LAST &&
+        field != SPHX_F_ID)
         return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
     void* p; size_t sz;
     if (!h || !src || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
@@ -306,6 +307,7 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
         hipStreamSynchronize(sphx::stream()) != hipSuccess)
         return fail(SPHX_ERR_HIP, "sphx_set: copy failed");
     if (field == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
+    if (field == SPHX_F_POS_LAST && h->pbd) h->pbd->markPosLastInitialized();
     return SPHX_OK;
 }
 
@@ -409,9 +411,9 @@ __global__ void k_eval_kernels(const float3* __restrict__ r3, int n, KernelConst
     const float r = len3(d);
     // plain operators here; the fast instantiations are compared with them by sphx_fastmath_selftest
     const float q = q_of<false>(r, k);
-    W[i] = kW(q, k);
+    W[i] = kW<false>(q, k);
     G[i] = kGradW<false>(d, q, k);
-    V[i] = kViscLap(r, k);
+    V[i] = kViscLap<false>(r, k);
     S[i] = kSurfGrad<false>(d, r, k);
 }
 

@@ -70,6 +70,7 @@ KernelConsts make_kernel_consts(float R)
     const float tW = largest_true([R](float r2) { volatile float r = sqrtf(r2); volatile float q = 2.0f * r / R; return !(q > 2.0f); });
     const float tR = largest_true([R](float r2) { volatile float r = sqrtf(r2); return r <= R; });
     k.tCut = tW > tR ? tW : tR;
+    k.q2Free = (tW >= tR) ? 1 : 0;
     k.rcpR = 1.0f / R;
     k.fastQ = 0;
     k.fastDiv = 0;
@@ -128,7 +129,7 @@ __global__ void k_check_div3(KernelConsts k, float denLo, float denHi, unsigned 
         };
         const float3 n = make_float3(numer(h1), numer(h2), numer(h3));
         // numerators below 2^-101 take the plain operators in the sweeps (pair_needs_plain_ops)
-        const float3 a = pair_needs_plain_ops(n, 1.0f, k) ? div3s(n, den) : div3_sel<true>(n, den), b = div3s(n, den);
+        const float3 a = pair_needs_plain_ops(n, 1.0f) ? div3s(n, den) : div3_sel<true>(n, den), b = div3s(n, den);
         bad += (__float_as_uint(a.x) != __float_as_uint(b.x)) + (__float_as_uint(a.y) != __float_as_uint(b.y)) +
                (__float_as_uint(a.z) != __float_as_uint(b.z));
     }

@@ -28,7 +28,8 @@ struct KernelConsts {
     // --- exact fast paths (validated on the device by validate_fast_math, else 0 = plain IEEE ops)
     float rcpR;     // RN(1/R)
     int fastQ;      // 1: x/R == fma-refined x*rcpR for EVERY float x in [0, 2.2R] (checked exhaustively)
-    int fastDiv;    // 1: the denominators of gradW / surface gradient stay inside [2^-100, 2^100]
+    int fastDiv;    // 1: the denominators of gradW / surface gradient stay inside [2^-90, 2^16]
+    int q2Free;     // 1: r2 <= tCut implies q <= 2 and r <= R, i.e. row entries never fail a support test
 };
 
 struct GridDesc {
@@ -121,11 +122,14 @@ __device__ __forceinline__ float div_by_radius(float x, const KernelConsts& k)
 
 // true when this pair must use the plain operators: a positive squared distance below 2^-96 (then
 // r < 2^-48 as well), a non-zero displacement component below 2^-101, or fast paths not validated
-__device__ __forceinline__ bool pair_needs_plain_ops(float3 d, float r2, const KernelConsts& k)
+// (positions are frozen while a row is valid, so the row builder evaluates this once per pair and
+// stores it as a flag bit of the entry; the sweeps only test the bit)
+__device__ __forceinline__ bool pair_needs_plain_ops(float3 d, float r2)
 {
     const int e = min(min(__builtin_amdgcn_frexp_expf(d.x), __builtin_amdgcn_frexp_expf(d.y)), __builtin_amdgcn_frexp_expf(d.z));
-    return (k.fastQ & k.fastDiv) == 0 || e < -100 || (__float_as_uint(r2) - 1u) < (0x0f800000u - 1u);
+    return e < -100 || (__float_as_uint(r2) - 1u) < (0x0f800000u - 1u);
 }
+__device__ __forceinline__ bool fast_paths_enabled(const KernelConsts& k) { return (k.fastQ & k.fastDiv & k.q2Free) != 0; }
 
 // ---- smoothing kernels ------------------------------------------------------------------------
 // q = 2*|r|/R as computed by both cubic-spline functions
@@ -133,10 +137,12 @@ template <bool FAST>
 __device__ __forceinline__ float q_of(float r, const KernelConsts& k) { return div_by_radius<FAST>(2.0f * r, k); }
 
 // cubic_spline_kernel, CUDAFunctions.cuh:23-35
+// (FAST: the pair comes from a row, so q <= 2 already holds — KernelConsts::q2Free)
+template <bool FAST>
 __device__ __forceinline__ float kW(float q, const KernelConsts& k)
 {
     const float w = k.wA * ((q > 1.0f) ? (2.0f - q) * (2.0f - q) * (2.0f - q) : ((3.0f * q - 6.0f) * q * q + 4.0f));
-    return (q > 2.0f || q < kEps) ? 0.0f : w;
+    return ((!FAST && q > 2.0f) || q < kEps) ? 0.0f : w;
 }
 // cubic_spline_kernel_gradient, CUDAFunctions.cuh:37-50
 template <bool FAST>
@@ -144,18 +150,21 @@ __device__ __forceinline__ float3 kGradW(float3 d, float q, const KernelConsts& 
 {
     const float3 a = div3_sel<FAST>(d, kPi * (q + kEps) * k.R * k.R * k.R * k.R * k.R);
     const float3 g = mul3s(a, (q > 1.0f) ? ((12.0f - 3.0f * q) * q - 12.0f) : ((9.0f * q - 12.0f) * q));
+    if (FAST) return g;
     return (q > 2.0f) ? v3(0.0f, 0.0f, 0.0f) : g;      // select instead of an early return (same value)
 }
 // viscosity_kernel_laplacian, CUDAFunctions.cuh:52-54
+template <bool FAST>
 __device__ __forceinline__ float kViscLap(float r, const KernelConsts& k)
 {
-    return (r <= k.R) ? (45.0f * (k.R - r) / k.viscDen) : 0.0f;
+    const float l = 45.0f * (k.R - r) / k.viscDen;
+    return (FAST || r <= k.R) ? l : 0.0f;
 }
 // surface_tension_kernel_gradient, CUDAFunctions.cuh:82-98
 template <bool FAST>
 __device__ __forceinline__ float3 kSurfGrad(float3 d, float x, const KernelConsts& k)
 {
-    const bool outside = x > k.R || x < kEps;
+    const bool outside = (!FAST && x > k.R) || x < kEps;
     // (outside the support the quotient is discarded; a harmless denominator keeps it finite)
     const float3 a = div3_sel<FAST>(smul3(136.0241f, neg3(d)), outside ? 1.0f : k.stK * x);
     const float3 g = mul3s(a, (2.0f * x <= k.R) ? (2.0f * cube(k.R - x) * cube(x) - k.stC) : (cube(k.R - x) * cube(x)));
@@ -255,10 +264,10 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
 // that lane falls back to the direct 27-cell walk.
 //
 // Entry formats (per 64-particle tile, chosen by the row builder, recorded in tileFmt):
-//   fmt 0  bit31 = boundary, bits 0..30 = global index: sweeps gather from global memory.  Each
+//   fmt 0  bit31 = boundary, bit30 = pair needs the plain operators, bits 0..29 = global index: sweeps gather from global memory.  Each
 //          divergent gather costs ~64 cycles of the CU's single texture-address pipe per
 //          wave-instruction, which is what bounds these sweeps.
-//   fmt 2  bits 30..29 = dx group g (0,1,2 <-> dx = -1,0,+1), bit 28 = boundary, bits 0..27 = slot
+//   fmt 2  bits 30..29 = dx group g (0,1,2 <-> dx = -1,0,+1), bit 28 = boundary, bit 27 = plain ops, bits 0..26 = slot
 //          in the LDS stage of that group.  A tile is one wave of consecutive cell-sorted particles;
 //          because the cell id runs z fastest, the neighbour cells of the whole tile for one
 //          (dx,dy) are ONE contiguous cell range [first+off-1, last+off+1], off = (dx*gy+dy)*gz,
@@ -272,9 +281,12 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
 constexpr int kTile = 64;
 constexpr int kWideBlock = 256;     // threads per block: 4 waves = 4 adjacent tiles share a CU
 constexpr int kGroupSlots = 384;    // LDS slots per wave and dx group
-constexpr unsigned int kBoundaryBit = 0x80000000u;
-constexpr unsigned int kStreamBoundaryBit = 0x10000000u;
-constexpr unsigned int kStreamSlotMask = 0x0fffffffu;
+constexpr unsigned int kBoundaryBit = 0x80000000u;       // fmt 0: bit 31 boundary, bit 30 plain-ops, 0..29 index
+constexpr unsigned int kPlainBit = 0x40000000u;
+constexpr unsigned int kIndexMask = 0x3fffffffu;
+constexpr unsigned int kStreamBoundaryBit = 0x10000000u;  // fmt 2: 30..29 group, 28 boundary, 27 plain-ops, 0..26 slot
+constexpr unsigned int kStreamPlainBit = 0x08000000u;
+constexpr unsigned int kStreamSlotMask = 0x07ffffffu;
 
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each XCD
 // has its own L2.  Logical block = (b % 8) * chunk + b / 8 gives every XCD one contiguous run of
@@ -382,10 +394,10 @@ __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, V
 // One pair term: the whole wave takes the branch-free fast arithmetic unless some lane's pair needs
 // the plain operators (a wave-uniform branch, so no exec-mask bookkeeping per pair).
 template <class Body, class Field>
-__device__ __forceinline__ void pair_dispatch(Body& body, const KernelConsts& k, const Field& f, bool isB, float3 d, float r2,
+__device__ __forceinline__ void pair_dispatch(Body& body, const bool plain, const Field& f, bool isB, float3 d, float r2,
                                               float mj, int idx)
 {
-    if (__builtin_expect(__any(pair_needs_plain_ops(d, r2, k)), 0)) body.template pair<false>(f, isB, d, r2, mj, idx);
+    if (__builtin_expect(__any(plain), 0)) body.template pair<false>(f, isB, d, r2, mj, idx);
     else body.template pair<true>(f, isB, d, r2, mj, idx);
 }
 
@@ -399,6 +411,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
 {
     const int lane = threadIdx.x & 63;
     const bool rows = c.nbr != nullptr;
+    const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     const bool useRow = rows && valid && cnt <= c.cap;
     const unsigned int* row = rows ? c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63) : nullptr;
@@ -431,7 +444,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                 if (WANT_BOUNDARY || !isB) {
                     const float4 pj = ldsPos[slot];
                     const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                    pair_dispatch(body, c.k, ldsField[slot], isB, d, dot3(d, d), pj.w, -1);
+                    pair_dispatch(body, allPlain || (e & kStreamPlainBit) != 0u, ldsField[slot], isB, d, dot3(d, d), pj.w, -1);
                 }
                 e = next;
             }
@@ -449,7 +462,10 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
         // time (the row streams from HBM, the gathers mostly from L2).  kAhead entries and their
         // gathers are issued together so kAhead*3 loads are in flight per lane; the pair terms are
         // then accumulated strictly in row order.
-        constexpr int kAhead = 4;
+#ifndef SPHX_AHEAD
+#define SPHX_AHEAD 4
+#endif
+        constexpr int kAhead = SPHX_AHEAD;
         int t = 0;
         for (; t + kAhead <= cnt; t += kAhead) {
             unsigned int e[kAhead];
@@ -460,7 +476,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 const bool isB = (e[u] & kBoundaryBit) != 0u;
-                const int idx = (int)(e[u] & ~kBoundaryBit);
+                const int idx = (int)(e[u] & kIndexMask);
                 pj[u] = isB ? c.bposm[idx] : c.posm[idx];
                 f[u] = op.stage(isB, idx);
             }
@@ -469,17 +485,17 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                 const bool isB = (e[u] & kBoundaryBit) != 0u;
                 if (!WANT_BOUNDARY && isB) continue;
                 const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
-                pair_dispatch(body, c.k, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & ~kBoundaryBit));
+                pair_dispatch(body, allPlain || (e[u] & kPlainBit) != 0u, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & kIndexMask));
             }
         }
         for (; t < cnt; ++t) {
             const unsigned int e = row[(size_t)t * 64u];
             const bool isB = (e & kBoundaryBit) != 0u;
             if (!WANT_BOUNDARY && isB) continue;
-            const int idx = (int)(e & ~kBoundaryBit);
+            const int idx = (int)(e & kIndexMask);
             const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-            pair_dispatch(body, c.k, op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
+            pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
         }
         return;
     }
@@ -534,6 +550,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                 const int base = (X * c.g.gy + Y) * c.g.gz;
                 const int fShift = dy < 0 ? fSh[0] : (dy == 0 ? fSh[1] : fSh[2]);
                 const int bShift = dy < 0 ? bSh[0] : (dy == 0 ? bSh[1] : bSh[2]);
+                const unsigned int plainBit = streamed ? kStreamPlainBit : kPlainBit;
                 const unsigned int fTag = streamed ? ((unsigned)g << 29) : 0u;
                 const unsigned int bTag = streamed ? (((unsigned)g << 29) | kStreamBoundaryBit) : kBoundaryBit;
                 const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
@@ -541,11 +558,28 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                 for (int z = zlo; z <= zhi; z += step) {
                     const int cell = base + z;
                     const int e = c.csF[cell + step];
-                    for (int j = c.csF[cell]; j < e; ++j) {
+                    int j = c.csF[cell];
+                    // four candidates per trip: the loads are independent, the appends stay in order
+                    for (; j + 4 <= e; j += 4) {
+                        float4 pj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pj[u] = streamed ? ldsPos[j + u + fShift] : c.posm[j + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+                            const float r2 = dot3(d, d);
+                            if (r2 > c.k.tCut || j + u == i) continue;
+                            if (cnt < c.cap)
+                                row[(size_t)cnt * 64u] = (unsigned int)(j + u + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
+                            ++cnt;
+                        }
+                    }
+                    for (; j < e; ++j) {
                         const float4 pj = streamed ? ldsPos[j + fShift] : c.posm[j];
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                        if (dot3(d, d) > c.k.tCut || j == i) continue;
-                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift) | fTag;
+                        const float r2 = dot3(d, d);
+                        if (r2 > c.k.tCut || j == i) continue;
+                        if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
                         ++cnt;
                     }
                     if (!noWall) {
@@ -553,8 +587,9 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                         for (int j = c.csB[cell]; j < eb; ++j) {
                             const float4 pj = streamed ? ldsPos[j + bShift] : c.bposm[j];
                             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-                            if (dot3(d, d) > c.k.tCut) continue;
-                            if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag;
+                            const float r2 = dot3(d, d);
+                            if (r2 > c.k.tCut) continue;
+                            if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
                             ++cnt;
                         }
                     }

@@ -23,7 +23,10 @@ struct BlockLds {
 };
 
 template <class Op, bool STREAM>
-__global__ void __launch_bounds__(kWideBlock) k_run_op(const Op op, int n)
+#ifndef SPHX_MINWAVES
+#define SPHX_MINWAVES 1
+#endif
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op op, int n)
 {
     __shared__ BlockLds<Op, STREAM> lds;
     const int wave = threadIdx.x >> 6;
@@ -72,10 +75,10 @@ struct OpFluidProps {
         {
             const float r = sqrt_sel<FAST>(r2);
             if (VISC && !isB)
-                a = add3(a, mul3s(smul3(mj, div3s(sub3(xyz(vj), vi), o.rho0)), kViscLap(r, o.c.k)));
+                a = add3(a, mul3s(smul3(mj, div3s(sub3(xyz(vj), vi), o.rho0)), kViscLap<FAST>(r, o.c.k)));
             if (COLOR || DENS) {
                 const float q = q_of<FAST>(r, o.c.k);
-                const float w = kW(q, o.c.k);
+                const float w = kW<FAST>(q, o.c.k);
                 if (DENS) den += mj * w;
                 if (COLOR) {
                     const float vol = mj / (isB ? o.rhoB : o.rho0);
@@ -206,7 +209,7 @@ struct OpDfsphHead {
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
-            den += mj * kW(q, o.c.k);
+            den += mj * kW<FAST>(q, o.c.k);
             const float3 gw = kGradW<FAST>(d, q, o.c.k);
             const float3 gr = smul3(mj, gw);
             gs = add3(gs, gr);
@@ -216,7 +219,7 @@ struct OpDfsphHead {
     };
 };
 template <bool WITH_RATE, bool STREAM>
-__global__ void __launch_bounds__(kWideBlock) k_dfsph_head(const OpDfsphHead o, int n)
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const OpDfsphHead o, int n)
 {
     __shared__ BlockLds<OpDfsphHead, STREAM> lds;
     const int wave = threadIdx.x >> 6;
@@ -260,7 +263,7 @@ struct OpRate {
     };
 };
 template <bool DENSITY_MODE, int WARM, bool STREAM>
-__global__ void __launch_bounds__(kWideBlock) k_rate(const OpRate o, int n)
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate o, int n)
 {
     __shared__ BlockLds<OpRate, STREAM> lds;
     const int wave = threadIdx.x >> 6;
@@ -324,7 +327,7 @@ struct OpLambda {
         __device__ __forceinline__ void pair(Field, bool, float3 d, float r2, float mj, int)
         {
             const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
-            den += mj * kW(q, o.c.k);
+            den += mj * kW<FAST>(q, o.c.k);
             float3 gr = smul3(-mj, kGradW<FAST>(d, q, o.c.k));
             if (o.rb != 1.0f) gr = div3s(gr, o.rb);
             gs = sub3(gs, gr);
@@ -382,7 +385,7 @@ struct OpXsph {
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float q = q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k);
-            const float w = kW(q, o.c.k);
+            const float w = kW<FAST>(q, o.c.k);
             if (!isB) a = add3(a, mul3s(smul3(mj, sub3(xyz(vj), vi)), w));
             if (COLOR) {
                 const float vol = mj / (isB ? o.rhoB : o.rho0);

@@ -196,7 +196,7 @@ struct BoundaryMassBody {
     const KernelConsts& k;
     float sum;
     __device__ __forceinline__ void fluid(int, float3, float, float) {}
-    __device__ __forceinline__ void boundary(int, float3, float r2, float) { sum += kW(q_of<false>(sqrtf(r2), k), k); }
+    __device__ __forceinline__ void boundary(int, float3, float r2, float) { sum += kW<false>(q_of<false>(sqrtf(r2), k), k); }
 };
 __global__ void __launch_bounds__(256) k_boundary_mass(float* __restrict__ mass, const float4* __restrict__ posm,
                                                        const int* __restrict__ csB, GridDesc g, KernelConsts k,

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsphx.so")
+LIB_PATH = os.environ.get("SPHX_LIB", os.path.join(_HERE, "libsphx.so"))
 
 WCSPH, DFSPH, PBD = 0, 1, 2
 
@@ -256,3 +256,34 @@ def ieee_probe(a, b, c):
     _check(lib().sphx_ieee_probe(a.ctypes.data, b.ctypes.data, c.ctypes.data, n, q.ctypes.data, r.ctypes.data,
                                  t.ctypes.data, m.ctypes.data))
     return q, r, t, m
+
+
+# ------------------------------------------------------------------------------------ snapshots
+# A snapshot is everything a run needs to continue bit-identically: the scalars, the boundary set,
+# and the fluid state in its current (cell-sorted) order — positions, velocities, original ids and
+# the solver's persistent array (DFSPH warm stiffness / PBD last positions).  The reference has no
+# checkpoint facility; this is the "next" row §8(f)-2.
+def save_snapshot(system, path):
+    P = system.params
+    blob = {"params": np.frombuffer(bytes(P), np.uint8).copy(), "pos": system.get(F_POS), "vel": system.get(F_VEL),
+            "ids": system.get(F_ID), "bpos": system.get(F_BPOS)}
+    if P.solver == DFSPH:
+        blob["warm"] = system.get(F_WARM)
+    if P.solver == PBD:
+        blob["pos_last"] = system.get(F_POS_LAST)
+    np.savez_compressed(path, **blob)
+
+
+def load_snapshot(path):
+    """returns a System that continues the saved run (no constructor step)"""
+    z = np.load(path)
+    P = Params.from_buffer_copy(z["params"].tobytes())
+    s = System(P, z["pos"], z["bpos"], ctor_step=False)
+    # the constructor re-sorts (an identity permutation for a saved, sorted state) and zeroes velocities
+    s.set(F_VEL, z["vel"])
+    s.set(F_ID, z["ids"])
+    if "warm" in z.files:
+        s.set(F_WARM, z["warm"])
+    if "pos_last" in z.files:
+        s.set(F_POS_LAST, z["pos_last"])
+    return s

@@ -29,6 +29,8 @@ public:
 
     bool graphSafe() const override { return posLastInitialized; }
     const DArray<float3>& getPosLast() const { return fluidPosLast; }
+    // engine extension (snapshot restore): the last positions were written through the raw pointer
+    void markPosLastInitialized() { posLastInitialized = true; }
     const DArray<float>& getLambda() const { return bufferFloat; }
 
 protected:

@@ -158,7 +158,7 @@ int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iter
 /* field access: blocking D2H / H2D copies of whole fields, and raw device pointers */
 int  sphx_field_bytes(const sphx_system *sys, int field, size_t *bytes);
 int  sphx_get(const sphx_system *sys, int field, void *host_dst, size_t bytes);
-int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM, BMASS */
+int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM, BMASS, POS_LAST, ID */
 int  sphx_device_ptr(const sphx_system *sys, int field, void **device_ptr);
 
 /* per-kernel timing of the last sphx_profile_step: names/ms arrays of up to cap entries */
