@@ -81,8 +81,8 @@ int DFSPHSolver::correctDivergenceError(std::shared_ptr<SPHParticles>& fluids, c
     auto iter = 0;
     const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                       RateOut{error.addr(), bufferFloat.addr(), nullptr,
-                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0}};
-    const OpCorrect<false> correct{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt};
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw()}};
+    const OpCorrect<false> correct{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true};
     if (!headDidFirstError) {
         ScopedKernel t("divergence_error");
         launch_rate<false, 0>(rate, num, false);
@@ -126,8 +126,8 @@ int DFSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::share
     }
     const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                       RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(),
-                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0}};
-    OpCorrect<true> correct{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt};
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw()}};
+    OpCorrect<true> correct{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt, false};   // warm start: posf.w holds kappa, not the warm array
     {
         ScopedKernel t("density_correct");   // warm start
         launch_op(correct, num);
@@ -137,6 +137,7 @@ int DFSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::share
         launch_rate<true, 1>(rate, num, false);
     }
     correct.kappa = bufferFloat.addr();
+    correct.packedScalar = true;
     while (adaptive ? ((iter < 2 || totalError > errorThreshold * num * rho0) && iter < maxIterations) : (iter < fixedDen)) {
         {
             ScopedKernel t("density_correct");
@@ -255,19 +256,19 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_HEAD: {
         ScopedKernel t("density_alpha_diverr");
         OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                       RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0}};
+                       RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0, c.posfw()}};
         launch_dfsph_head<true>(op, num);
         break;
     }
     case SPHX_PH_DIV_CORRECT: {
         ScopedKernel t("divergence_correct");
-        launch_op(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt}, num);
+        launch_op(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true}, num);
         break;
     }
     case SPHX_PH_DIV_ERROR: {
         ScopedKernel t("divergence_error");
         launch_rate<false, 0>(OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0}}, num, reduce);
+                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw()}}, num, reduce);
         break;
     }
     case SPHX_PH_VISC_COLOR: {
@@ -295,19 +296,19 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     }
     case SPHX_PH_WARM_CORRECT: {
         ScopedKernel t("density_correct");
-        launch_op(OpCorrect<true>{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt}, num);
+        launch_op(OpCorrect<true>{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt, false}, num);
         break;
     }
     case SPHX_PH_DEN_CORRECT: {
         ScopedKernel t("density_correct");
-        launch_op(OpCorrect<true>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt}, num);
+        launch_op(OpCorrect<true>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true}, num);
         break;
     }
     case SPHX_PH_DEN_ERROR_SET:
     case SPHX_PH_DEN_ERROR_ACC: {
         ScopedKernel t("density_error");
         const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                          RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0}};
+                          RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0, c.posfw()}};
         if (phase == SPHX_PH_DEN_ERROR_SET) launch_rate<true, 1>(rate, num, reduce);
         else launch_rate<true, 2>(rate, num, reduce);
         break;

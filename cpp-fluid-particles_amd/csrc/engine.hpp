@@ -38,6 +38,9 @@ struct SweepCache {
     DArray<float3> aux3;
     DArray<float> vel4;                      // float4 mirror of vel, kept in step by every velocity writer
     DArray<float> cg4;                       // float4 mirror of the colour gradient
+    DArray<float> posf;                      // float4 (x, y, z, scalar neighbour field): one-gather sweeps
+    DArray<int> massUniform;                 // device flag set by the pack pass: all fluid masses equal
+    bool allowPacked = true;                 // false for slab systems (their halo refresh targets the plain arrays)
     DArray<int> nbrCount;
     DArray<int> tileFmt;                     // per 64-particle tile: entry format of its rows (0 or 2)
     std::unique_ptr<DArray<int>> nbr;        // allocated on first use
@@ -72,6 +75,7 @@ struct SweepCache {
     float4* fluid4w() { return reinterpret_cast<float4*>(posm.addr()); }
     float4* vel4w() const { return reinterpret_cast<float4*>(vel4.addr()); }
     float4* cg4w() const { return reinterpret_cast<float4*>(cg4.addr()); }
+    float4* posfw() const { return reinterpret_cast<float4*>(posf.addr()); }
     const float4* boundary4() const { return reinterpret_cast<const float4*>(bposm->addr()); }
 };
 

@@ -80,12 +80,12 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         }
         {
             ScopedKernel t("pbd_delta_pos");
-            OpDeltaPos dp{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0};
+            OpDeltaPos dp{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true};
             launch_op(dp, num);
         }
         {
             ScopedKernel t("pbd_apply_clamp");   // keeps the packed position view in step with pos
-            launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), bufferFloat3.addr(), spaceSize, num);
+            launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num);
             c.listValid = false;
         }
         ++iter;

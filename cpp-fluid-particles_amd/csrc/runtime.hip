@@ -218,14 +218,19 @@ __global__ void k_pack4(float4* __restrict__ dst, const float3* __restrict__ pos
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) { const float3 p = pos[q]; dst[q] = make_float4(p.x, p.y, p.z, w[q]); }
 }
-__global__ void k_pack_fluid(float4* __restrict__ posm, float4* __restrict__ vel4, const float3* __restrict__ pos,
-                             const float* __restrict__ mass, const float3* __restrict__ vel, int n)
+// (massUniform is preset to 1 by a memset; any particle whose mass differs from particle 0's clears it)
+__global__ void k_pack_fluid(float4* __restrict__ posm, float4* __restrict__ vel4, float4* __restrict__ posf,
+                             int* __restrict__ massUniform, const float3* __restrict__ pos, const float* __restrict__ mass,
+                             const float3* __restrict__ vel, int n)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const float3 p = pos[q], v = vel[q];
-    posm[q] = make_float4(p.x, p.y, p.z, mass[q]);
+    const float m = mass[q];
+    posm[q] = make_float4(p.x, p.y, p.z, m);
+    posf[q] = make_float4(p.x, p.y, p.z, 0.0f);
     vel4[q] = make_float4(v.x, v.y, v.z, 0.0f);
+    if (m != mass[0]) *massUniform = 0;
 }
 
 void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n)
@@ -262,13 +267,17 @@ void ew_iota(int* dst, int n)
 }
 
 // ------------------------------------------------------------------------------ SweepCache
-__global__ void k_pack_kick_rt(float4* __restrict__ posm, float4* __restrict__ vel4, const float3* __restrict__ pos,
-                               const float* __restrict__ mass, float3* __restrict__ vel, float3 dv, int n)
+__global__ void k_pack_kick_rt(float4* __restrict__ posm, float4* __restrict__ vel4, float4* __restrict__ posf,
+                               int* __restrict__ massUniform, const float3* __restrict__ pos, const float* __restrict__ mass,
+                               float3* __restrict__ vel, float3 dv, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float3 p = pos[i];
-    posm[i] = make_float4(p.x, p.y, p.z, mass[i]);
+    const float m = mass[i];
+    posm[i] = make_float4(p.x, p.y, p.z, m);
+    posf[i] = make_float4(p.x, p.y, p.z, 0.0f);
+    if (m != mass[0]) *massUniform = 0;
     const float3 v = add3(vel[i], dv);
     vel[i] = v;
     vel4[i] = make_float4(v.x, v.y, v.z, 0.0f);
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
-      cg4(4u * (unsigned)num), nbrCount((unsigned)num),
+      cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 1))
 {
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
@@ -314,8 +323,11 @@ void SweepCache::packFluid(const SPHParticles& fluids)
     if (fluidValid) return;
     n = (int)fluids.size();
     ScopedKernel t("pack_fluid");
-    if (n > 0)
-        k_pack_fluid<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), n);
+    if (n > 0) {
+        HIP_CALL(hipMemsetAsync(massUniform.addr(), 1, 1, stream()));   // low byte 1 -> flag value 1
+        k_pack_fluid<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), posfw(), massUniform.addr(), fluids.getPosPtr(),
+                                                          fluids.getMassPtr(), fluids.getVelPtr(), n);
+    }
     fluidValid = true;
     listValid = false;
 }
@@ -324,8 +336,11 @@ void SweepCache::packFluidKick(const SPHParticles& fluids, float3 dv)
 {
     n = (int)fluids.size();
     ScopedKernel t("pack_kick");
-    if (n > 0)
-        k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), fluids.getPosPtr(), fluids.getMassPtr(), fluids.getVelPtr(), dv, n);
+    if (n > 0) {
+        HIP_CALL(hipMemsetAsync(massUniform.addr(), 1, 1, stream()));
+        k_pack_kick_rt<<<blocks_for(n), 256, 0, stream()>>>(fluid4w(), vel4w(), posfw(), massUniform.addr(), fluids.getPosPtr(),
+                                                            fluids.getMassPtr(), fluids.getVelPtr(), dv, n);
+    }
     fluidValid = true;
     listValid = false;
 }
@@ -360,6 +375,8 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.n = n;
     c.vel4 = vel4w();
     c.cg4 = cg4w();
+    c.posf = posfw();
+    c.massUniform = (allowPacked && cellOffsetX == 0) ? massUniform.addr() : nullptr;
     return c;
 }
 

@@ -205,6 +205,10 @@ __device__ __forceinline__ void clamp_box(float3& p, float3& v, const float3 spa
     if (p.z >= hz) { p.z = hz; if (WITH_VEL) v.z = min0(v.z); }
 }
 
+template <class F> __device__ __forceinline__ F scalar_field(float v);
+template <> __device__ __forceinline__ float scalar_field<float>(float v) { return v; }
+template <> __device__ __forceinline__ float4 scalar_field<float4>(float v) { return make_float4(v, 0.0f, 0.0f, 0.0f); }
+
 // ---- neighbour sweep skeleton -------------------------------------------------------------------
 // Visits the 27 cells around the cell of `pi` in the reference order: dx outer, dy,
 // dz inner; per cell the fluid range then the boundary range, j ascending.  Candidates farther
@@ -304,6 +308,8 @@ struct SweepCtx {
     const int* tileFmt;                     // per tile entry format (nullptr: all tiles fmt 0)
     float4* vel4;                           // 16-byte aligned mirror of the fluid velocities (one gather)
     float4* cg4;                            // 16-byte aligned mirror of the colour gradient
+    float4* posf;                           // (x, y, z, scalar field): position AND the neighbour scalar in one gather
+    const int* massUniform;                 // device flag: 1 when every fluid particle has the mass of particle 0
     int n;
 };
 
@@ -391,6 +397,30 @@ __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, V
     }
 }
 
+// Ops whose neighbour field is one scalar (kappa, pterm, lambda) may declare `bool packedScalar`:
+// when all fluid masses are equal (checked on the device at pack time) position and field are read
+// with ONE 16-byte gather from posf instead of two gathers — the sweeps are bound by the vector L1's
+// line rate (~1 line per cycle per CU), so halving the gathers matters.  Same values, same order.
+template <class Op> __device__ __forceinline__ auto op_packed_impl(const Op& op, int) -> decltype(op.packedScalar) { return op.packedScalar; }
+template <class Op> __device__ __forceinline__ bool op_packed_impl(const Op&, long) { return false; }
+template <class Op> __device__ __forceinline__ bool op_packed_scalar(const Op& op) { return op_packed_impl(op, 0); }
+
+template <class Op>
+__device__ __forceinline__ void fetch_pair(const Op& op, const SweepCtx& c, bool packed, float m0, unsigned int e, float4& pj,
+                                           typename Op::Field& f)
+{
+    const bool isB = (e & kBoundaryBit) != 0u;
+    const int idx = (int)(e & kIndexMask);
+    if (packed) {
+        const float4 r = (isB ? c.bposm : c.posf)[idx];
+        pj = make_float4(r.x, r.y, r.z, isB ? r.w : m0);
+        f = scalar_field<typename Op::Field>(isB ? 0.0f : r.w);
+    } else {
+        pj = isB ? c.bposm[idx] : c.posm[idx];
+        f = op.stage(isB, idx);
+    }
+}
+
 // One pair term: the whole wave takes the branch-free fast arithmetic unless some lane's pair needs
 // the plain operators (a wave-uniform branch, so no exec-mask bookkeeping per pair).
 template <class Body, class Field>
@@ -457,6 +487,9 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
         return;
     }
     if (!valid) return;
+    // one-gather mode (ops with a scalar neighbour field): uniform over the launch
+    const bool packed = op_packed_scalar<Op>(op) && c.posf && c.massUniform && *c.massUniform != 0;
+    const float m0 = packed ? c.posm[0].w : 0.0f;
     if (useRow) {
         // The chain "row entry -> gather -> arithmetic" is latency-bound when walked one entry at a
         // time (the row streams from HBM, the gathers mostly from L2).  kAhead entries and their
@@ -475,10 +508,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
             typename Op::Field f[kAhead];
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                const bool isB = (e[u] & kBoundaryBit) != 0u;
-                const int idx = (int)(e[u] & kIndexMask);
-                pj[u] = isB ? c.bposm[idx] : c.posm[idx];
-                f[u] = op.stage(isB, idx);
+                fetch_pair<Op>(op, c, packed, m0, e[u], pj[u], f[u]);
             }
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
@@ -493,9 +523,10 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
             const bool isB = (e & kBoundaryBit) != 0u;
             if (!WANT_BOUNDARY && isB) continue;
             const int idx = (int)(e & kIndexMask);
-            const float4 pj = isB ? c.bposm[idx] : c.posm[idx];
+            float4 pj; typename Op::Field fj;
+            fetch_pair<Op>(op, c, packed, m0, e, pj, fj);
             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-            pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, op.stage(isB, idx), isB, d, dot3(d, d), pj.w, idx);
+            pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, fj, isB, d, dot3(d, d), pj.w, idx);
         }
         return;
     }

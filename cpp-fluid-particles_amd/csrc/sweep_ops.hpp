@@ -100,7 +100,9 @@ struct OpFluidProps {
             float p = stiff * (pow7(b.den / rho0) - 1.0f);
             if (p < 0.0f) p = 0.0f;
             pressure[i] = p;
-            pterm[i] = p / max_eps(b.den * b.den);
+            const float pt = p / max_eps(b.den * b.den);
+            pterm[i] = pt;
+            c.posf[i].w = pt;
         }
     }
 };
@@ -146,6 +148,7 @@ struct OpPressureForce {
     SweepCtx c;
     const float* pterm; float3* vel;
     float dt;
+    bool packedScalar;      // posf.w holds pterm
     using Field = float;    // neighbour p_j / max(EPS, rho_j^2)
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : pterm[j]; }
     struct Body {
@@ -175,6 +178,7 @@ struct OpPressureForce {
 struct RateOut {
     float* error; float* kappa; float* warm; unsigned long long* accum;
     float dt, rho0;
+    float4* posf;     // (x,y,z,kappa) records for the one-gather correction sweeps (may be nullptr)
 };
 template <bool DENSITY_MODE, int WARM>
 __device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float e, float den, float alpha)
@@ -189,6 +193,7 @@ __device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float 
     const float kap = err * alpha;
     r.error[i] = err;
     r.kappa[i] = kap;
+    if (r.posf) r.posf[i].w = kap;
     if (WARM == 1) r.warm[i] = kap;
     if (WARM == 2) r.warm[i] = r.warm[i] + kap;
     return error_fixed(err);
@@ -291,6 +296,7 @@ struct OpCorrect {
     SweepCtx c;
     const float* kappa; float3* vel;
     float dt;
+    bool packedScalar;      // posf.w currently holds THIS kappa array for every fluid particle
     using Field = float;    // neighbour stiffness
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : kappa[j]; }
     struct Body {
@@ -343,6 +349,7 @@ struct OpLambda {
         float lam = (b.den > rho0) ? (-(b.den / rho0 - 1.0f) / (dot3(b.gs, b.gs) + b.sl + kEps)) : 0.0f;
         lam *= relaxation;
         lambda[i] = lam;
+        c.posf[i].w = lam;
     }
 };
 
@@ -351,6 +358,7 @@ struct OpDeltaPos {
     SweepCtx c;
     const float* lambda; float3* deltaPos;
     float rho0;
+    bool packedScalar;      // posf.w holds lambda
     using Field = float;    // neighbour lambda
     __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : lambda[j]; }
     struct Body {
@@ -467,7 +475,7 @@ static __global__ void k_kick_remember_advect(float3* __restrict__ pos, float3* 
     vel[i] = v;
 }
 // pos += deltaPos; enforceBoundary_CUDA(pos): PBDSolver.cu:212-223, :247-253 (also refreshes posm)
-static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __restrict__ posm,
+static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __restrict__ posm, float4* __restrict__ posf,
                                            const float3* __restrict__ dpos, float3 space, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,6 +485,7 @@ static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __r
     clamp_box<false>(p, unused, space);
     pos[i] = p;
     posm[i] = make_float4(p.x, p.y, p.z, posm[i].w);
+    posf[i] = make_float4(p.x, p.y, p.z, 0.0f);
 }
 // vel = (pos - posLast) / dt, PBDSolver.cu:55-60
 static __global__ void k_velocity_from_displacement(float3* __restrict__ vel, float4* __restrict__ vel4,
@@ -514,9 +523,9 @@ inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLas
 {
     if (n > 0) k_kick_remember_advect<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, posLast, dv, dt, space, n);
 }
-inline void launch_apply_delta_clamp(float3* pos, float4* posm, const float3* dpos, float3 space, int n)
+inline void launch_apply_delta_clamp(float3* pos, float4* posm, float4* posf, const float3* dpos, float3 space, int n)
 {
-    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, dpos, space, n);
+    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n);
 }
 inline void launch_velocity_from_displacement(float3* vel, float4* vel4, const float3* pos, const float3* posLast, float dt, int n)
 {

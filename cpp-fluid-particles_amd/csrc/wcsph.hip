@@ -26,7 +26,7 @@ void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; }
-void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; }
+void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->allowPacked = false; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)
@@ -117,7 +117,7 @@ void BasicSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::s
     }
     {
         ScopedKernel t("pressure_force");
-        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt};
+        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt, true};
         launch_op(op, n);
     }
 }
@@ -171,7 +171,7 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
     }
     {
         ScopedKernel t("pressure_force");
-        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt};
+        OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt, true};
         launch_op(op, n);
     }
     advect(fluids, dt, spaceSize);
