@@ -261,6 +261,7 @@ static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
     case SPHX_F_BUF3: if (h->wcsph) { p = h->wcsph->getColorGradient().addr(); sz = 12 * n; } else known = false; break;
     case SPHX_F_VEL4: if (h->wcsph) { p = h->wcsph->engineVel4(); sz = 16 * n; } else known = false; break;
     case SPHX_F_CG4: if (h->wcsph) { p = h->wcsph->engineCg4(); sz = 16 * n; } else known = false; break;
+    case SPHX_F_PTERM: if (h->wcsph) { p = h->wcsph->enginePterm(); sz = 4 * n; } else known = false; break;
     default: known = false; break;
     }
     if (!known) return SPHX_ERR_INVALID;
@@ -316,6 +317,28 @@ int sphx_run_phase(sphx_system* h, int phase)
     if (!h) return fail(SPHX_ERR_INVALID, "sphx_run_phase: null system");
     try {
         h->system->phase(phase);
+    } catch (const char* msg) {
+        return fail(SPHX_ERR_STATE, msg);
+    }
+    return SPHX_OK;
+}
+
+int sphx_run_phase_reduce(sphx_system* h, int phase, int lo, int hi)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "sphx_run_phase_reduce: null system");
+    try {
+        h->system->phaseReduce(phase, lo, hi);
+    } catch (const char* msg) {
+        return fail(SPHX_ERR_STATE, msg);
+    }
+    return SPHX_OK;
+}
+
+int sphx_error_total_fixed(sphx_system* h, long long* total)
+{
+    if (!h || !total) return fail(SPHX_ERR_INVALID, "sphx_error_total_fixed: bad argument");
+    try {
+        *total = h->system->errorTotalFixed();
     } catch (const char* msg) {
         return fail(SPHX_ERR_STATE, msg);
     }

@@ -25,6 +25,14 @@ DFSPHSolver::DFSPHSolver(int num, float defaultDensityErrorThreshold, float defa
 }
 DFSPHSolver::~DFSPHSolver() noexcept {}
 
+long long DFSPHSolver::readErrorTotalFixed()
+{
+    unsigned long long acc = 0;
+    HIP_CALL(hipMemcpyAsync(&acc, errorAccum.addr(), sizeof(acc), hipMemcpyDeviceToHost, sphx::stream()));
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    return (long long)acc;
+}
+
 float DFSPHSolver::readErrorTotal()
 {
     unsigned long long acc = 0;
@@ -58,7 +66,7 @@ void DFSPHSolver::computeDensityAlpha(std::shared_ptr<SPHParticles>& fluids, con
     const int num = (int)fluids->size();
     if (num <= 0) return;
     ScopedKernel t("density_alpha");
-    OpDfsphHead op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{}};
+    OpDfsphHead op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, 0}};
     launch_dfsph_head<false>(op, num);
 }
 
@@ -81,7 +89,7 @@ int DFSPHSolver::correctDivergenceError(std::shared_ptr<SPHParticles>& fluids, c
     auto iter = 0;
     const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                       RateOut{error.addr(), bufferFloat.addr(), nullptr,
-                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw()}};
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw(), sumLo, sumHi}};
     const OpCorrect<false> correct{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true};
     if (!headDidFirstError) {
         ScopedKernel t("divergence_error");
@@ -126,7 +134,7 @@ int DFSPHSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::share
     }
     const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                       RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(),
-                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw()}};
+                              reinterpret_cast<unsigned long long*>(errorAccum.addr()), dt, rho0, c.posfw(), sumLo, sumHi}};
     OpCorrect<true> correct{ctx, denWarmStiff.addr(), fluids->getVelPtr(), dt, false};   // warm start: posf.w holds kappa, not the warm array
     {
         ScopedKernel t("density_correct");   // warm start
@@ -256,7 +264,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_HEAD: {
         ScopedKernel t("density_alpha_diverr");
         OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                       RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0, c.posfw()}};
+                       RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0, c.posfw(), sumLo, sumHi}};
         launch_dfsph_head<true>(op, num);
         break;
     }
@@ -268,7 +276,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_DIV_ERROR: {
         ScopedKernel t("divergence_error");
         launch_rate<false, 0>(OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw()}}, num, reduce);
+                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw(), sumLo, sumHi}}, num, reduce);
         break;
     }
     case SPHX_PH_VISC_COLOR: {
@@ -308,7 +316,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_DEN_ERROR_ACC: {
         ScopedKernel t("density_error");
         const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                          RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0, c.posfw()}};
+                          RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0, c.posfw(), sumLo, sumHi}};
         if (phase == SPHX_PH_DEN_ERROR_SET) launch_rate<true, 1>(rate, num, reduce);
         else launch_rate<true, 2>(rate, num, reduce);
         break;

@@ -179,6 +179,7 @@ struct RateOut {
     float* error; float* kappa; float* warm; unsigned long long* accum;
     float dt, rho0;
     float4* posf;     // (x,y,z,kappa) records for the one-gather correction sweeps (may be nullptr)
+    int sumLo, sumHi; // particles whose |error| enters the accumulated total (slab: the owned range)
 };
 template <bool DENSITY_MODE, int WARM>
 __device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float e, float den, float alpha)
@@ -196,7 +197,7 @@ __device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float 
     if (r.posf) r.posf[i].w = kap;
     if (WARM == 1) r.warm[i] = kap;
     if (WARM == 2) r.warm[i] = r.warm[i] + kap;
-    return error_fixed(err);
+    return (i >= r.sumLo && i < r.sumHi) ? error_fixed(err) : 0;
 }
 
 // computeDensityAlpha_CUDA (DFSPHSolver.cu:212-249), optionally fused with the first

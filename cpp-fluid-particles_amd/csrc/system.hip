@@ -264,8 +264,35 @@ SPHSystem::SPHSystem(Slab slab, std::shared_ptr<SPHParticles>& fluidParticles,
 SPHSystem::~SPHSystem() noexcept {}
 
 // one stage of the DFSPH step (distributed drivers; see sphx_phase)
+void SPHSystem::phaseReduce(int p, int sumLo, int sumHi)
+{
+    auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
+    if (!dfsph) throw "SPHSystem::phaseReduce: needs a DFSPHSolver";
+    dfsph->setErrorSumRange(sumLo, sumHi);
+    dfsph->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
+                    _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphVisc, _sphG, _sphSurfaceTensionIntensity,
+                    _sphAirPressure, true);
+}
+
+long long SPHSystem::errorTotalFixed()
+{
+    auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
+    if (!dfsph) throw "SPHSystem::errorTotalFixed: needs a DFSPHSolver";
+    return dfsph->readErrorTotalFixed();
+}
+
 void SPHSystem::phase(int p)
 {
+    if (p >= SPHX_PH_W_SEARCH || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
+        auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
+        if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
+        if (p == SPHX_PH_W_SEARCH) neighborSearch(_fluids, cellStartFluid);
+        w->runWcsphPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
+                         _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphStiff, _sphVisc, _sphG,
+                         _sphSurfaceTensionIntensity, _sphAirPressure);
+        if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
+        return;
+    }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
     if (!dfsph) throw "SPHSystem::phase: stage-wise stepping needs a DFSPHSolver";
     if (p == SPHX_PH_SEARCH) neighborSearch(_fluids, cellStartFluid);

@@ -15,6 +15,7 @@
 #include "BasicSPHSolver.h"
 #include "engine.hpp"
 #include "sweep_ops.hpp"
+#include "sphx_c.h"
 
 using namespace sphx;
 
@@ -25,6 +26,7 @@ void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
+void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; }
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->allowPacked = false; }
 
@@ -141,38 +143,67 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
         advect(fluids, dt, spaceSize);
         return;
     }
+    for (int ph : {SPHX_PH_W_SEARCH, SPHX_PH_W_PROPS, SPHX_PH_W_SURFACE, SPHX_PH_W_PRESSURE, SPHX_PH_ADVECT})
+        runWcsphPhase(ph, fluids, boundaries, cellStartFluid, cellStartBoundary, spaceSize, cellSize, cellLength, radius, dt,
+                      rho0, rhoB, stiff, visc, G, surfaceTensionIntensity, airPressure);
+}
+
+// One stage of the fused schedule (also what SPHSystem::phase runs for distributed drivers).
+void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& fluids,
+                                   const std::shared_ptr<SPHParticles>& boundaries, const DArray<int>& cellStartFluid,
+                                   const DArray<int>& cellStartBoundary, float3 spaceSize, int3 cellSize, float cellLength,
+                                   float radius, float dt, float rho0, float rhoB, float stiff, float visc, float3 G,
+                                   float surfaceTensionIntensity, float airPressure)
+{
+    SweepCache& c = cache();
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
     const int n = (int)fluids->size();
+    if (phase == SPHX_PH_W_SEARCH) {
+        invalidatePositions();
+        c.setup(cellSize, cellLength, radius);
+        c.packFluidKick(*fluids, make_float3(dt * G.x, dt * G.y, dt * G.z));
+        c.packBoundary(*boundaries);
+        c.ensureList(cellStartFluid, cellStartBoundary);
+        return;
+    }
+    if (phase == SPHX_PH_ADVECT) { advect(fluids, dt, spaceSize); return; }
     c.setup(cellSize, cellLength, radius);
-    c.packFluidKick(*fluids, make_float3(dt * G.x, dt * G.y, dt * G.z));
+    c.packFluid(*fluids);
     c.packBoundary(*boundaries);
     c.ensureList(cellStartFluid, cellStartBoundary);
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
-    if (surface) {
-        {
+    if (phase == SPHX_PH_W_PROPS) {
+        if (surface) {
             ScopedKernel t("visc_color_density");
             OpFluidProps<true, true, true> op{ctx, fluids->getVelPtr(), c.aux3.addr(), bufferFloat3.addr(),
                                               fluids->getDensityPtr(), fluids->getPressurePtr(), c.pterm.addr(),
                                               rho0, rhoB, visc, dt, stiff};
             launch_op(op, n);
-        }
-        ScopedKernel t("surface_tension");
-        OpSurface op{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0,
-                     surfaceTensionIntensity, airPressure, dt};
-        launch_op(op, n);
-    } else {
-        {
+        } else {
             ScopedKernel t("visc_density");
             OpFluidProps<true, false, true> op{ctx, fluids->getVelPtr(), c.aux3.addr(), nullptr, fluids->getDensityPtr(),
                                                fluids->getPressurePtr(), c.pterm.addr(), rho0, rhoB, visc, dt, stiff};
             launch_op(op, n);
         }
-        ScopedKernel t("add_delta_v");
-        launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), n);
+        return;
     }
-    {
+    if (phase == SPHX_PH_W_SURFACE) {
+        if (surface) {
+            ScopedKernel t("surface_tension");
+            OpSurface op{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), rho0,
+                         surfaceTensionIntensity, airPressure, dt};
+            launch_op(op, n);
+        } else {
+            ScopedKernel t("add_delta_v");
+            launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), n);
+        }
+        return;
+    }
+    if (phase == SPHX_PH_W_PRESSURE) {
         ScopedKernel t("pressure_force");
         OpPressureForce op{ctx, c.pterm.addr(), fluids->getVelPtr(), dt, true};
         launch_op(op, n);
+        return;
     }
-    advect(fluids, dt, spaceSize);
+    throw "BasicSPHSolver::runWcsphPhase: unknown stage";
 }

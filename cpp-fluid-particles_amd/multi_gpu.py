@@ -23,9 +23,13 @@ ncclSend/ncclRecv over xGMI on GPUs); no all-reduce in fixed-iteration mode.  Th
 torch's current stream, so NCCL's stream dependencies order messages with kernels without host
 synchronisation; the only host round trips per step are the message sizes and the five layer offsets.
 
-Status this round: DFSPH only; static cut planes chosen from the initial particle histogram;
-halo refreshes are not yet overlapped with interior work; adaptive iteration mode (needs a 1-word
-all-reduce of the exact integer error sum) is not wired.  The driver is engine-agnostic: the HIP
+DFSPH runs with fixed iteration counts or adaptively (the reference's loops): the
+termination sum is an exact integer, each rank sums its owned particles and a 1-word
+all-reduce gives every rank the identical total, so iteration counts equal the single-device ones.
+WCSPH uses four stages and two halo refreshes (colour gradient, pressure term).
+
+Status this round: DFSPH and WCSPH (PBD not yet); static cut planes chosen from the initial particle
+histogram; halo refreshes are not yet overlapped with interior work.  The driver is engine-agnostic: the HIP
 engine is used on GPUs, and the CPU tests plug in the oracle to exercise this file under gloo.
 """
 import os
@@ -36,7 +40,8 @@ import torch
 import torch.distributed as dist
 
 (PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
- PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT) = range(12)
+ PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE,
+ PH_W_PRESSURE) = range(16)
 
 EPS = 1e-6
 
@@ -76,6 +81,15 @@ class Neighbors:
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
         self.stage_through_host = world > 1 and dist.get_backend() == "gloo"
+
+    def allreduce_int(self, value, device):
+        """sum of one Python int over all ranks (exact: int64)"""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return int(value)
+        dev = "cpu" if dist.get_backend() == "gloo" else device
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
 
     def exchange(self, to_left, to_right, from_left, from_right):
         """send to_left/to_right (tensors or None), receive into from_left/from_right (tensors or None)"""
@@ -139,8 +153,12 @@ class HipSlabEngine:
             return torch.as_tensor(_DevView(self.sys.device_ptr(field), shape, typestr), device=device)
 
         self.f = {"pos": view(sphx.F_POS, 3), "vel": view(sphx.F_VEL, 3), "ids": view(sphx.F_ID, 1, "<i4"),
-                  "warm": view(sphx.F_WARM, 1), "kappa": view(sphx.F_KAPPA, 1), "vel_nbr": view(sphx.F_VEL4, 4),
-                  "cg_nbr": view(sphx.F_CG4, 4), "density": view(sphx.F_DENSITY, 1)}
+                  "vel_nbr": view(sphx.F_VEL4, 4), "cg_nbr": view(sphx.F_CG4, 4), "density": view(sphx.F_DENSITY, 1),
+                  "pterm": view(sphx.F_PTERM, 1)}
+        if params.solver == sphx.DFSPH:
+            self.f["warm"] = view(sphx.F_WARM, 1)
+            self.f["kappa"] = view(sphx.F_KAPPA, 1)
+        self.pressure_halo = ["pterm"]     # what the pressure-force stage reads from neighbours
         self.cell_start = torch.as_tensor(_DevView(self.sys.device_ptr(sphx.F_CELLSTART_F), (self.C + 1,), "<i4"),
                                           device=device)
 
@@ -149,6 +167,14 @@ class HipSlabEngine:
 
     def run(self, phase):
         self.sys.run_phase(phase)
+
+    def run_reduce(self, phase, lo, hi):
+        """error stage with the exact |error| sum over particles [lo, hi); returns the integer"""
+        self.sys.run_phase_reduce(phase, lo, hi)
+        return self.sys.error_total_fixed()
+
+    def has(self, name):
+        return name in self.f
 
     def read(self, name, lo, hi):
         return self.f[name][lo:hi]
@@ -179,9 +205,20 @@ class OracleSlabEngine:
         if len(boundary_pos):
             self.sys.set(O.F_BMASS, np.ascontiguousarray(boundary_mass, np.float32))
         self.C = self.sys.C
-        self.map = {"pos": O.F_POS, "vel": O.F_VEL, "ids": O.F_ID, "warm": O.F_WARM, "kappa": O.F_KAPPA,
-                    "vel_nbr": O.F_VEL, "cg_nbr": O.F_BUF3, "density": O.F_DENSITY}
+        self.map = {"pos": O.F_POS, "vel": O.F_VEL, "ids": O.F_ID, "vel_nbr": O.F_VEL, "cg_nbr": O.F_BUF3,
+                    "density": O.F_DENSITY, "pressure": O.F_PRESSURE}
+        if params.solver == O.DFSPH:
+            self.map["warm"] = O.F_WARM
+            self.map["kappa"] = O.F_KAPPA
+        self.pressure_halo = ["pressure", "density"]
         self.count = cap
+
+    def run_reduce(self, phase, lo, hi):
+        self.sys.run_phase(phase)
+        return self.sys.error_total_fixed(lo, hi)
+
+    def has(self, name):
+        return name in self.map
 
     def set_count(self, n):
         self.sys.set_count(n)
@@ -216,7 +253,11 @@ class OracleSlabEngine:
 
 # ------------------------------------------------------------------------------------ the driver
 class SlabDriver:
-    def __init__(self, engine, nbrs, x0, x1, gy, gz, cell_length, div_iters, den_iters, surface, timers=None):
+    def __init__(self, engine, nbrs, x0, x1, gy, gz, cell_length, div_iters, den_iters, surface, timers=None,
+                 solver="dfsph", adaptive=None):
+        """adaptive: None, or dict(n_global, rho0, div_thr, den_thr, max_iter) for the reference's loops"""
+        self.solver, self.adaptive = solver, adaptive
+        self.iters = (0, 0)
         self.e, self.nb = engine, nbrs
         self.x0, self.x1, self.L = x0, x1, gy * gz
         self.gxl = (x1 - x0) + 2
@@ -235,14 +276,16 @@ class SlabDriver:
             raise RuntimeError("slab capacity %d too small for %d particles" % (e.cap, n))
         e.write("pos", 0, pos)
         e.write("vel", 0, vel if vel is not None else torch.zeros_like(pos))
-        e.write("warm", 0, torch.zeros(n, dtype=torch.float32, device=pos.device))
+        if e.has("warm"):
+            e.write("warm", 0, torch.zeros(n, dtype=torch.float32, device=pos.device))
         self.owned = (0, n)
 
     def _exchange_particles(self):
         e = self.e
         o0, o1 = self.owned
         pos, vel = e.read("pos", o0, o1), e.read("vel", o0, o1)
-        ids, warm = e.read("ids", o0, o1), e.read("warm", o0, o1)
+        ids = e.read("ids", o0, o1)
+        warm = e.read("warm", o0, o1) if e.has("warm") else torch.zeros(o1 - o0, dtype=torch.float32, device=pos.device)
         col = e.columns(o0, o1, self.cl)
         if o1 > o0 and (int(col.min()) < self.x0 - 1 or int(col.max()) > self.x1):
             raise RuntimeError("a particle crossed more than one cell column in one step")
@@ -267,7 +310,8 @@ class SlabDriver:
         e.write("pos", 0, pre[:, 0:3])
         e.write("vel", 0, pre[:, 3:6])
         e.write("ids", 0, pre[:, 6].contiguous().view(torch.int32))
-        e.write("warm", 0, pre[:, 7].contiguous())
+        if e.has("warm"):
+            e.write("warm", 0, pre[:, 7].contiguous())
         e.set_count(n)
 
     def _update_layers(self):
@@ -299,15 +343,48 @@ class SlabDriver:
         if self.timers is not None:
             self.timers["halo"] = self.timers.get("halo", 0.0) + time.perf_counter() - t0
 
-    def step(self):
+    def _global_error(self, phase):
+        """run an error stage, all-reduce the exact integer |error| sum of the owned particles and return
+        it as the fp32 value DFSPHSolver compares with its threshold"""
+        fixed = self.e.run_reduce(phase, self.owned[0], self.owned[1])
+        total = self.nb.allreduce_int(fixed, getattr(self.e, "device", "cpu"))
+        return np.float32(np.float64(total) * (1.0 / 4294967296.0))
+
+    def _step_wcsph(self):
         e = self.e
+        self._exchange_particles()
+        e.run(PH_W_SEARCH)
+        self._update_layers()
+        e.run(PH_W_PROPS)
+        if self.surface:
+            self._halo("cg_nbr")
+        for name in e.pressure_halo:
+            self._halo(name)
+        e.run(PH_W_SURFACE)
+        e.run(PH_W_PRESSURE)
+        e.run(PH_ADVECT)
+
+    def step(self):
+        if self.solver == "wcsph":
+            return self._step_wcsph()
+        e = self.e
+        ad = self.adaptive
         self._exchange_particles()
         e.run(PH_SEARCH)
         self._update_layers()
         e.run(PH_HEAD); self._halo("kappa")
-        for _ in range(self.v):
-            e.run(PH_DIV_CORRECT); self._halo("vel_nbr")
-            e.run(PH_DIV_ERROR); self._halo("kappa")
+        if ad is None:
+            for _ in range(self.v):
+                e.run(PH_DIV_CORRECT); self._halo("vel_nbr")
+                e.run(PH_DIV_ERROR); self._halo("kappa")
+            it_div = self.v
+        else:       # DFSPHSolver.cu:347-361
+            limit = np.float32(ad["div_thr"]) * np.float32(ad["n_global"]) * np.float32(ad["rho0"])
+            it_div, total = 0, np.float32(3.4028235e38)
+            while (it_div < 1 or total > limit) and it_div < ad["max_iter"]:
+                e.run(PH_DIV_CORRECT); self._halo("vel_nbr")
+                total = self._global_error(PH_DIV_ERROR); self._halo("kappa")
+                it_div += 1
         e.run(PH_FORCE)
         e.run(PH_VISC_COLOR)
         if self.surface:
@@ -315,11 +392,25 @@ class SlabDriver:
         e.run(PH_SURFACE); self._halo("vel_nbr")
         e.run(PH_WARM_CORRECT); self._halo("vel_nbr")
         e.run(PH_DEN_ERROR_SET); self._halo("kappa")
-        for k in range(self.d):
-            e.run(PH_DEN_CORRECT); self._halo("vel_nbr")
-            e.run(PH_DEN_ERROR_ACC)
-            if k + 1 < self.d:
+        if ad is None:
+            for k in range(self.d):
+                e.run(PH_DEN_CORRECT); self._halo("vel_nbr")
+                e.run(PH_DEN_ERROR_ACC)
+                if k + 1 < self.d:
+                    self._halo("kappa")
+            it_den = self.d
+        else:       # DFSPHSolver.cu:187-208
+            limit = np.float32(ad["den_thr"]) * np.float32(ad["n_global"]) * np.float32(ad["rho0"])
+            it_den, total = 0, np.float32(3.4028235e38)
+            while (it_den < 2 or total > limit) and it_den < ad["max_iter"]:
+                e.run(PH_DEN_CORRECT); self._halo("vel_nbr")
+                it_den += 1
+                if it_den >= 2:
+                    total = self._global_error(PH_DEN_ERROR_ACC)
+                else:
+                    e.run(PH_DEN_ERROR_ACC)
                 self._halo("kappa")
+        self.iters = (it_div, it_den)
         e.run(PH_ADVECT)
 
     def owned_state(self):
@@ -356,7 +447,15 @@ def build_slab(make_engine, scene_params, fluid, boundary_sorted, boundary_mass,
     engine = make_engine(Pl, cap, np.ascontiguousarray(boundary_sorted[bsel]), np.ascontiguousarray(boundary_mass[bsel]))
     surface = P.surface_tension > EPS or P.air_pressure > EPS
     nbrs = Neighbors(rank, world)
-    drv = SlabDriver(engine, nbrs, x0, x1, gy, gz, cl, P.dfsph_fixed_div, P.dfsph_fixed_den, surface)
+    solver = {0: "wcsph", 1: "dfsph"}.get(P.solver)
+    if solver is None:
+        raise NotImplementedError("the slab driver covers WCSPH and DFSPH")
+    adaptive = None
+    if solver == "dfsph" and (P.dfsph_fixed_div < 0 or P.dfsph_fixed_den < 0):
+        adaptive = dict(n_global=len(fluid), rho0=P.rho0, div_thr=P.dfsph_divergence_thr, den_thr=P.dfsph_density_thr,
+                        max_iter=P.dfsph_max_iter)
+    drv = SlabDriver(engine, nbrs, x0, x1, gy, gz, cl, P.dfsph_fixed_div, P.dfsph_fixed_den, surface, solver=solver,
+                     adaptive=adaptive)
     sel = (col >= x0) & (col < x1)
     drv.load_initial(engine.to_device(np.ascontiguousarray(mine)),
                      None if velocity is None else engine.to_device(np.ascontiguousarray(velocity[sel])))

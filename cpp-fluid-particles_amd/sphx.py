@@ -16,10 +16,11 @@ LIB_PATH = os.environ.get("SPHX_LIB", os.path.join(_HERE, "libsphx.so"))
 WCSPH, DFSPH, PBD = 0, 1, 2
 
 (F_POS, F_VEL, F_DENSITY, F_PRESSURE, F_MASS, F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID, F_BPOS,
- F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3, F_VEL4, F_CG4) = range(20)
+ F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3, F_VEL4, F_CG4, F_PTERM) = range(21)
 
 (PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
- PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT) = range(12)
+ PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE,
+ PH_W_PRESSURE) = range(16)
 
 _INT_FIELDS = (F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID)
 _VEC_FIELDS = (F_POS, F_VEL, F_BPOS, F_POS_LAST, F_BUF3)
@@ -29,7 +30,7 @@ EXPORTS = [
     "sphx_scene_params", "sphx_scene_counts", "sphx_scene_fill", "sphx_create", "sphx_destroy",
     "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
-    "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_set_count", "sphx_use_stream",
+    "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest",
 ]
 
@@ -96,6 +97,8 @@ def lib():
         L.sphx_generate_dots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sphx_run_phase.argtypes = [C.c_void_p, C.c_int]
         L.sphx_set_count.argtypes = [C.c_void_p, C.c_int]
+        L.sphx_run_phase_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.sphx_error_total_fixed.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.sphx_use_stream.argtypes = [C.c_void_p]
         L.sphx_cell_columns.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
@@ -178,6 +181,14 @@ class System:
 
     def run_phase(self, phase):
         _check(lib().sphx_run_phase(self._h, phase))
+
+    def run_phase_reduce(self, phase, lo, hi):
+        _check(lib().sphx_run_phase_reduce(self._h, phase, lo, hi))
+
+    def error_total_fixed(self):
+        v = C.c_longlong()
+        _check(lib().sphx_error_total_fixed(self._h, C.byref(v)))
+        return v.value
 
     def device_ptr(self, field):
         p = C.c_void_p()

@@ -39,6 +39,14 @@ public:
     // raw device pointers of the float4 mirrors the sweeps gather from (halo exchange targets)
     void* engineVel4() const;
     void* engineCg4() const;
+    void* enginePterm() const;
+    // one stage of the fused WCSPH schedule (SPHX_PH_W_* and SPHX_PH_ADVECT of sphx_c.h), for
+    // distributed drivers that refresh halo fields between stages
+    void runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& fluids,
+                       const std::shared_ptr<SPHParticles>& boundaries, const DArray<int>& cellStartFluid,
+                       const DArray<int>& cellStartBoundary, float3 spaceSize, int3 cellSize, float cellLength,
+                       float radius, float dt, float rho0, float rhoB, float stiff, float visc, float3 G,
+                       float surfaceTensionIntensity, float airPressure);
     // call after writing boundary positions/masses through raw pointers
     void invalidateBoundary();
 

@@ -40,6 +40,10 @@ public:
                   float surfaceTensionIntensity, float airPressure, bool reduce = false);
     int lastDivergenceIterations() const { return lastDiv; }
     int lastDensityIterations() const { return lastDen; }
+    // distributed adaptive mode: restrict the |error| total to [lo, hi) and read it as the raw integer
+    void setErrorSumRange(int lo, int hi) { sumLo = lo; sumHi = hi; }
+    long long readErrorTotalFixed();
+    void noteIterations(int div, int den) { lastDiv = div; lastDen = den; }
     const DArray<float>& getAlpha() const { return alpha; }
     const DArray<float>& getStiffness() const { return bufferFloat; }
     const DArray<float>& getError() const { return error; }
@@ -66,6 +70,7 @@ private:
                                float cellLength, float radius, float dt, float errorThreshold,
                                int maxIter);
     float readErrorTotal();
+    int sumLo = 0, sumHi = 0x7fffffff;   // particles entering the |error| total (slab drivers: owned range)
 
     DArray<float> alpha;
     DArray<float> bufferFloat;     // stiffness kappa

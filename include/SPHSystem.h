@@ -57,6 +57,8 @@ public:
               float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
               float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
     void phase(int p);
+    void phaseReduce(int p, int sumLo, int sumHi);   // error stages with the |error| total over [lo, hi)
+    long long errorTotalFixed();
     const DArray<int>& getCellStartFluid() const { return cellStartFluid; }
     const DArray<int>& getCellStartBoundary() const { return cellStartBoundary; }
     BaseSolver* getSolver() const { return _solver.get(); }

@@ -88,6 +88,7 @@ typedef enum sphx_field {
     SPHX_F_BUF3,           /* float[3n]  BasicSPHSolver::bufferFloat3 (colour gradient)*/
     SPHX_F_VEL4,           /* float[4n]  engine mirror of vel (x,y,z,0), what sweeps gather    */
     SPHX_F_CG4,            /* float[4n]  engine mirror of the colour gradient                  */
+    SPHX_F_PTERM,          /* float[n]   p / max(EPS, rho^2), the neighbour term of the pressure force */
     SPHX_F_COUNT_
 } sphx_field;
 
@@ -136,9 +137,19 @@ typedef enum sphx_phase {
     SPHX_PH_DEN_ERROR_SET,    /* density error, warm = kappa                    (writes kappa)     */
     SPHX_PH_DEN_CORRECT,      /* density correction                             (writes vel)       */
     SPHX_PH_DEN_ERROR_ACC,    /* density error, warm += kappa                   (writes kappa)     */
-    SPHX_PH_ADVECT            /* pos += dt vel, box clamp                                           */
+    SPHX_PH_ADVECT,           /* pos += dt vel, box clamp                                           */
+    /* WCSPH stages (BasicSPHSolver, fused schedule of BasicSPHSolver.cu:237-260) */
+    SPHX_PH_W_SEARCH,         /* neighbour search, pack + gravity kick, neighbour rows              */
+    SPHX_PH_W_PROPS,          /* viscosity delta-v, colour gradient, density, pressure (writes cg, pterm) */
+    SPHX_PH_W_SURFACE,        /* vel += deltaV, surface tension + air pressure                      */
+    SPHX_PH_W_PRESSURE        /* pressure force                                                     */
 } sphx_phase;
 int  sphx_run_phase(sphx_system *sys, int phase);
+/* adaptive DFSPH across processes: the error stages (DIV_ERROR, DEN_ERROR_ACC) accumulate the exact
+ * 2^-32 fixed-point |error| sum over particles [lo, hi) only (a slab's owned range) when reduce != 0;
+ * sphx_error_total_fixed returns that integer so the driver can all-reduce it (order-independent). */
+int  sphx_run_phase_reduce(sphx_system *sys, int phase, int lo, int hi);
+int  sphx_error_total_fixed(sphx_system *sys, long long *total);
 /* number of fluid particles in use (<= the n_fluid capacity given to sphx_create); slab drivers
  * change it every step as particles migrate between processes                                   */
 int  sphx_set_count(sphx_system *sys, int n_fluid);

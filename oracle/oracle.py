@@ -66,6 +66,8 @@ def lib():
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_run_phase.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_count.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_error_total_fixed.restype = C.c_longlong
+        L.oracle_error_total_fixed.argtypes = [C.c_void_p, C.c_int, C.c_int]
         assert L.oracle_sizeof_params() == C.sizeof(Params)
         _lib = L
     return _lib
@@ -129,6 +131,9 @@ class System:
 
     def run_phase(self, phase):
         assert lib().oracle_run_phase(self._h, phase) == 0
+
+    def error_total_fixed(self, lo, hi):
+        return int(lib().oracle_error_total_fixed(self._h, lo, hi))
 
     def iters(self):
         a, b = C.c_int(), C.c_int()

@@ -696,7 +696,7 @@ float oracle_step(oracle_sys *s)
 /* Stage-wise DFSPH step (same stage numbering as sphx_phase in include/sphx_c.h), used by the
  * world_size-2 gloo tests of the slab driver with this oracle standing in for the HIP engine. */
 enum { PH_SEARCH = 0, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
-       PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT };
+       PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE, PH_W_PRESSURE };
 int oracle_run_phase(oracle_sys *s, int phase)
 {
     const oracle_params *P = &s->P;
@@ -721,9 +721,28 @@ int oracle_run_phase(oracle_sys *s, int phase)
         for (int i = 0; i < s->n; ++i) s->warm[i] = s->warm[i] + s->kappa[i];
         break;
     case PH_ADVECT: k_advect(s); s->steps++; break;
+    case PH_W_SEARCH:
+        neighbor_search(s, s->pos, s->vel, s->p2c, s->ids, s->n, s->csF);
+        k_force(s);
+        break;
+    case PH_W_PROPS: k_viscosity(s); if (surface) k_color_grad(s); k_density(s); k_pressure(s); break;
+    case PH_W_SURFACE: if (surface) k_surface(s); break;
+    case PH_W_PRESSURE: k_pressure_force(s); break;
     default: return -1;
     }
     return 0;
+}
+
+/* exact fixed-point |error| sum over particles [lo, hi) (a slab's owned range), D2 */
+long long oracle_error_total_fixed(const oracle_sys *s, int lo, int hi)
+{
+    long long acc = 0;
+    for (int i = lo; i < hi && i < s->n; ++i) {
+        float e = fabsf(s->error[i]) * 4294967296.0f;
+        if (!(e < 4.0e18f)) e = 4.0e18f;
+        acc += (long long)e;
+    }
+    return acc;
 }
 
 void oracle_destroy(oracle_sys *s)
@@ -816,6 +835,8 @@ int oracle_set(oracle_sys *s, int field, const void *src, long long bytes)
     case OF_KAPPA: dst = s->kappa; want = 4LL * s->n; break;
     case OF_BUF3: dst = s->buf3; want = 12LL * s->n; break;
     case OF_BMASS: dst = s->bmass; want = 4LL * s->nb; break;
+    case OF_DENSITY: dst = s->density; want = 4LL * s->n; break;
+    case OF_PRESSURE: dst = s->pressure; want = 4LL * s->n; break;
     default: return -1;
     }
     if (bytes != want) return -1;

@@ -9,6 +9,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
 
 
+def configure(P, E, solver, adaptive):
+    P.solver = E.DFSPH if solver == "dfsph" else E.WCSPH
+    if solver == "dfsph" and not adaptive:
+        P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3
+    P.dt = 0.001
+
+
 def splash(n, P, seed):
     rng = np.random.default_rng(seed)
     lo = 0.03 * P.space[0]
@@ -19,7 +26,7 @@ def splash(n, P, seed):
     return pos, vel
 
 
-def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed):
+def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver="dfsph", adaptive=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,9 +42,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed):
         torch.cuda.set_device(0)
         E.use_stream(torch.cuda.current_stream().cuda_stream)
         P, fluid, boundary = E.scene(nx)
-    P.solver = E.DFSPH
-    P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3
-    P.dt = 0.001
+    configure(P, E, solver, adaptive)
     pos, vel = splash(len(fluid), P, seed)
     bsys = E.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
     bpos, bmass = bsys.get(E.F_BPOS), bsys.get(E.F_BMASS)
@@ -58,6 +63,6 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed):
         prev = ids
     ids, p, v, d = drv.owned_state()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), ids=ids, pos=p, vel=v, density=d, cuts=np.array(cuts),
-             migrated=np.array(migrated))
+             migrated=np.array(migrated), iters=np.array(drv.iters))
     dist.barrier()
     dist.destroy_process_group()

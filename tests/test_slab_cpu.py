@@ -16,11 +16,9 @@ def _free_port():
     return p
 
 
-def _single_domain(oracle, nx, steps, seed):
+def _single_domain(oracle, nx, steps, seed, solver="dfsph", adaptive=False, want_iters=False):
     P, fluid, boundary = oracle.scene(nx)
-    P.solver = oracle.DFSPH
-    P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3
-    P.dt = 0.001
+    slab_worker.configure(P, oracle, solver, adaptive)
     pos, vel = slab_worker.splash(len(fluid), P, seed)
     s = oracle.System(P, pos, boundary, ctor_step=False)
     ids = s.get(oracle.F_ID)
@@ -29,15 +27,17 @@ def _single_domain(oracle, nx, steps, seed):
         s.step()
     ids = s.get(oracle.F_ID)
     order = np.argsort(ids)
-    return s.get(oracle.F_POS)[order], s.get(oracle.F_VEL)[order], s.get(oracle.F_DENSITY)[order]
+    out = (s.get(oracle.F_POS)[order], s.get(oracle.F_VEL)[order], s.get(oracle.F_DENSITY)[order])
+    return out + (s.iters(),) if want_iters else out
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_driver_matches_single_domain(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,solver,adaptive", [(2, "dfsph", False), (3, "dfsph", False), (2, "wcsph", False),
+                                                   (3, "dfsph", True)])
+def test_slab_driver_matches_single_domain(oracle, tmp_path, world, solver, adaptive):
     import torch.multiprocessing as mp
     nx, steps, seed = 12, 6, 17
-    mp.spawn(slab_worker.run, args=(world, _free_port(), "gloo", "oracle", nx, steps, str(tmp_path), seed), nprocs=world,
-             join=True)
+    mp.spawn(slab_worker.run, args=(world, _free_port(), "gloo", "oracle", nx, steps, str(tmp_path), seed, solver, adaptive),
+             nprocs=world, join=True)
     parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     ids = np.concatenate([p["ids"] for p in parts])
     pos = np.concatenate([p["pos"] for p in parts]); vel = np.concatenate([p["vel"] for p in parts])
@@ -45,9 +45,12 @@ def test_slab_driver_matches_single_domain(oracle, tmp_path, world):
     n = len(ids)
     assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.int32)), "every particle owned exactly once"
     order = np.argsort(ids)
-    rp, rv, rd = _single_domain(oracle, nx, steps, seed)
+    rp, rv, rd, it = _single_domain(oracle, nx, steps, seed, solver, adaptive, want_iters=True)
     assert_bit_equal(pos[order], rp, "slab pos"); assert_bit_equal(vel[order], rv, "slab vel")
     assert_bit_equal(den[order], rd, "slab density")
+    if adaptive:
+        assert all(tuple(p["iters"]) == it for p in parts), "adaptive iteration counts equal the single-domain ones"
+        assert it[0] >= 1 and it[1] >= 2
     assert sum(int(p["migrated"]) for p in parts) > 0, "the test must exercise migration across cuts"
 
 
