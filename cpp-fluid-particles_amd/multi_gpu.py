@@ -501,7 +501,8 @@ def run_slab_bench(args, rank, world, local_rank):
     wall = float(wall.item())
     bpp = 420 + 92 * args.div_iters + 104 * args.den_iters + 72
     steps_per_s = args.steps / wall
-    return {
+    halo_s = drv.timers.get("halo", 0.0) if drv.timers else None
+    result = {
         "metric": "simulation steps/sec, DFSPH dam-break", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -514,3 +515,6 @@ def run_slab_bench(args, rank, world, local_rank):
                    "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
         "roofline": None,
     }
+    dist.barrier()
+    dist.destroy_process_group()
+    return result

@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$PWD; export TMPDIR=/tmp; cd /tmp
 OUT=$R/gpurun_out/pmc_lite; rm -rf $OUT; mkdir -p $OUT
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/p1 -- python $R/tools_pmc_lite.py > $OUT/p1.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE TA_TA_BUSY_sum --kernel-trace --output-format csv -d $OUT/p2 -- python $R/tools_pmc_lite.py > $OUT/p2.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/p1 -- python $R/tools/pmc_lite_target.py > $OUT/p1.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE TA_TA_BUSY_sum --kernel-trace --output-format csv -d $OUT/p2 -- python $R/tools/pmc_lite_target.py > $OUT/p2.log 2>&1
 cd $R
 python - <<'PY'
 import csv, glob, collections

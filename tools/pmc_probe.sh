@@ -2,7 +2,7 @@
 # PMC passes for the 1M DFSPH probe; condensed per-kernel averages for the sweep kernels
 R=$PWD; export TMPDIR=/tmp; cd /tmp
 OUT=$R/gpurun_out/pmc_probe; rm -rf $OUT; mkdir -p $OUT
-run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python $R/tools_probe.py dfsph1m > $OUT/$1.log 2>&1; }
+run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python $R/tools/probe_step.py dfsph1m > $OUT/$1.log 2>&1; }
 run p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 run p2 "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32"
 run p3 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"

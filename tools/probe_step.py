@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp-fluid-particles_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
 which = sys.argv[1:] or ["wcsph263k", "dfsph1m", "pbd1m"]
 cfg = {"wcsph263k": (56, sphx.WCSPH), "dfsph1m": (88, sphx.DFSPH), "pbd1m": (88, sphx.PBD), "dfsph10m": (190, sphx.DFSPH)}
