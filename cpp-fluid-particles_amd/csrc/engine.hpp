@@ -28,7 +28,8 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 //   aux3         : second float3 scratch (viscosity delta-v while bufferFloat3 holds the colour
 //                  gradient in the fused sweeps)
 // kFlagTiles: LDS-streamed tiles (sph_device.hpp, entry format 2)
-enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4 };
+// kFlagLinearTiles: launch tiles in array order instead of the (y-chunk, x) schedule
+enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4, kFlagLinearTiles = 8 };
 
 struct SweepCache {
     explicit SweepCache(int num);
@@ -43,6 +44,10 @@ struct SweepCache {
     bool allowPacked = true;                 // false for slab systems (their halo refresh targets the plain arrays)
     DArray<int> nbrCount;
     DArray<int> tileFmt;                     // per 64-particle tile: entry format of its rows (0 or 2)
+    DArray<int> tileOrder;                   // launch schedule of the tiles (wave_tile)
+    DArray<int> tileKey;                     // bucket of each tile while the schedule is built
+    std::unique_ptr<DArray<int>> tileBuckets; // histogram / cursors of the (y-chunk, x) buckets
+    bool orderValid = false;
     std::unique_ptr<DArray<int>> nbr;        // allocated on first use
     std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
     int nb = 0;
@@ -66,7 +71,8 @@ struct SweepCache {
     // pack and apply the gravity kick vel += dv in one pass (only valid right after a re-sort)
     void packFluidKick(const SPHParticles& fluids, float3 dv);
     void packBoundary(const SPHParticles& boundaries);
-    void invalidatePositions() { fluidValid = false; listValid = false; }
+    void invalidatePositions() { fluidValid = false; listValid = false; orderValid = false; }
+    void ensureTileOrder();
     // build the neighbour rows for the current positions (no-op when valid or disabled)
     void ensureList(const DArray<int>& csF, const DArray<int>& csB);
     SweepCtx ctx(const DArray<int>& csF, const DArray<int>& csB) const;

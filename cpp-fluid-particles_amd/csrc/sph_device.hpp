@@ -310,8 +310,21 @@ struct SweepCtx {
     float4* cg4;                            // 16-byte aligned mirror of the colour gradient
     float4* posf;                           // (x, y, z, scalar field): position AND the neighbour scalar in one gather
     const int* massUniform;                 // device flag: 1 when every fluid particle has the mass of particle 0
+    const int* tileOrder;                   // schedule: the tile each launched wave works on (nullptr: identity)
+    int numTiles;
     int n;
 };
+
+// The tile (64 consecutive particles) this wave works on.  Launch order is a free choice — results
+// do not depend on it — so tiles are ordered by (y-chunk, x) rather than the array's x-major order:
+// each XCD then walks along x inside one y-chunk and the x+-1 neighbour layers of that chunk stay
+// in its 4 MB L2 (at 10 M particles a full x-layer is ~3 MB per array and would not).
+__device__ __forceinline__ int wave_tile(const SweepCtx& c)
+{
+    const int lt = logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6);
+    if (lt >= c.numTiles) return -1;
+    return c.tileOrder ? c.tileOrder[lt] : lt;
+}
 
 // The 18 neighbour ranges of a tile, one per lane (lanes 0..8 fluid, 9..17 boundary; r = 3*(dx+1) +
 // (dy+1)), with each range's offset inside the LDS stage of its dx group (fluid dy=-1,0,1 first,

@@ -30,8 +30,9 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op o
 {
     __shared__ BlockLds<Op, STREAM> lds;
     const int wave = threadIdx.x >> 6;
-    const int i = logical_block() * kWideBlock + threadIdx.x;
-    if (((i >> 6) << 6) >= n) return;      // whole wave past the end (wave-uniform)
+    const int tile = wave_tile(op.c);
+    if (tile < 0) return;                  // whole wave past the end (wave-uniform)
+    const int i = tile * kTile + (int)(threadIdx.x & 63);
     op(i, i < n, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
 }
 template <class Op>
@@ -229,8 +230,9 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
 {
     __shared__ BlockLds<OpDfsphHead, STREAM> lds;
     const int wave = threadIdx.x >> 6;
-    const int i = logical_block() * kWideBlock + threadIdx.x;
-    if (((i >> 6) << 6) >= n) return;
+    const int tile = wave_tile(o.c);
+    if (tile < 0) return;
+    const int i = tile * kTile + (int)(threadIdx.x & 63);
     const bool valid = i < n;
     long long fixed = 0;
     OpDfsphHead::Body b{o, (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
@@ -273,8 +275,9 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate
 {
     __shared__ BlockLds<OpRate, STREAM> lds;
     const int wave = threadIdx.x >> 6;
-    const int i = logical_block() * kWideBlock + threadIdx.x;
-    if (((i >> 6) << 6) >= n) return;
+    const int tile = wave_tile(o.c);
+    if (tile < 0) return;
+    const int i = tile * kTile + (int)(threadIdx.x & 63);
     const bool valid = i < n;
     long long fixed = 0;
     OpRate::Body b{o, valid ? o.vel[i] : v3(0, 0, 0), 0.0f};
