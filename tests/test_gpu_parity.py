@@ -149,6 +149,25 @@ def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
         compare(sphx, oracle, gs, os_, names, "flags %d cap %s solver %d step %d" % (flags, cap, solver, s + 1))
 
 
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_tile_schedule_is_only_a_schedule(sphx, oracle, solver, monkeypatch):
+    """the (y-chunk, x) launch order of the 64-particle tiles (normally enabled for large scenes
+    only) is forced on: results must not change"""
+    monkeypatch.setenv("SPHX_FORCE_TILE_ORDER", "1")
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = solver; P.pbd_iters = 3; P.dt = 0.001
+    pos, vel = _splash_state(len(fluid), P, 70 + solver)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    ids = gs.get(sphx.F_ID)
+    gs.set(sphx.F_VEL, vel[ids]); os_.set(oracle.F_VEL, vel[ids])
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else []) + (FIELDS_PBD if solver == 2 else [])
+    for s in range(4):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, names, "tile schedule solver %d step %d" % (solver, s + 1))
+
+
 def test_dfsph_fixed_iterations_and_graph_replay(sphx, oracle):
     """fixed (v=1, d=4) mode: step_n replays a captured hipGraph; results equal eager stepping."""
     def tweak(P):
