@@ -262,6 +262,7 @@ static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
     case SPHX_F_VEL4: if (h->wcsph) { p = h->wcsph->engineVel4(); sz = 16 * n; } else known = false; break;
     case SPHX_F_CG4: if (h->wcsph) { p = h->wcsph->engineCg4(); sz = 16 * n; } else known = false; break;
     case SPHX_F_PTERM: if (h->wcsph) { p = h->wcsph->enginePterm(); sz = 4 * n; } else known = false; break;
+    case SPHX_F_POS4: if (h->wcsph) { p = h->wcsph->enginePos4(); sz = 16 * n; } else known = false; break;
     default: known = false; break;
     }
     if (!known) return SPHX_ERR_INVALID;

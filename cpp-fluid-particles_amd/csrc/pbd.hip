@@ -5,6 +5,7 @@
 // surface effects, gravity, then predict.  XSPH writes to a separate buffer (Jacobi) instead of
 // the reference's racy in-place update.
 #include "PBDSolver.h"
+#include "sphx_c.h"
 #include "engine.hpp"
 #include "sweep_ops.hpp"
 
@@ -157,5 +158,83 @@ void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_pt
         launch_kick_remember_advect(fluids->getPosPtr(), fluids->getVelPtr(), fluidPosLast.addr(),
                                     make_float3(dt * G.x, dt * G.y, dt * G.z), dt, spaceSize, num);
         invalidatePositions();
+    }
+}
+
+// One stage of the schedule above, for distributed drivers (multi_gpu.py): the cuts sit where a
+// sweep reads what an earlier one wrote for the neighbours (lambda, moved positions, velocities,
+// colour gradient).  Always the fused tail; same kernels, same order as step().
+void PBDSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
+                         const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float3 spaceSize,
+                         int3 cellSize, float cellLength, float radius, float dt, float rho0, float rhoB, float3 G,
+                         float surfaceTensionIntensity, float airPressure)
+{
+    SweepCache& c = cache();
+    c.allowTiles = false;
+    const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
+    const int num = (int)fluids->size();
+    if (phase == SPHX_PH_P_SEARCH) {
+        invalidatePositions();
+        updateNeighborhood(fluids);
+        posLastInitialized = true;
+        c.setup(cellSize, cellLength, radius);
+        c.packFluid(*fluids);
+        c.packBoundary(*boundaries);
+        return;
+    }
+    if (phase == SPHX_PH_P_VELOCITY) {
+        ScopedKernel t("pbd_velocity");
+        launch_velocity_from_displacement(fluids->getVelPtr(), c.vel4w(), fluids->getPosPtr(), fluidPosLast.addr(), dt, num);
+        return;
+    }
+    if (phase == SPHX_PH_P_TAIL) {
+        ScopedKernel t("kick_remember_advect");
+        launch_kick_remember_advect(fluids->getPosPtr(), fluids->getVelPtr(), fluidPosLast.addr(),
+                                    make_float3(dt * G.x, dt * G.y, dt * G.z), dt, spaceSize, num);
+        invalidatePositions();
+        return;
+    }
+    c.setup(cellSize, cellLength, radius);
+    c.packFluid(*fluids);
+    c.packBoundary(*boundaries);
+    c.ensureList(cellStartFluid, cellStartBoundary);   // rebuilt whenever positions moved since the last build
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+    DArray<float3>& cg = colorGradientBuffer();
+    switch (phase) {
+    case SPHX_PH_P_LAMBDA: {
+        ScopedKernel t("pbd_lambda");
+        launch_op(OpLambda{ctx, fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation}, num);
+        break;
+    }
+    case SPHX_PH_P_DELTA: {
+        {
+            ScopedKernel t("pbd_delta_pos");
+            launch_op(OpDeltaPos{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true}, num);
+        }
+        ScopedKernel t("pbd_apply_clamp");
+        launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num);
+        c.listValid = false;
+        break;
+    }
+    case SPHX_PH_P_XSPH: {
+        if (surface) {
+            ScopedKernel t("xsph_color");
+            launch_op(OpXsph<true>{ctx, fluids->getVelPtr(), bufferFloat3.addr(), cg.addr(), xSPH_c, rho0, rhoB}, num);
+        } else {
+            ScopedKernel t("xsph");
+            launch_op(OpXsph<false>{ctx, fluids->getVelPtr(), bufferFloat3.addr(), nullptr, xSPH_c, rho0, 0.0f}, num);
+            launch_copy3_mirror(fluids->getVelPtr(), c.vel4w(), bufferFloat3.addr(), num);
+        }
+        break;
+    }
+    case SPHX_PH_P_SURFACE: {
+        if (surface) {
+            ScopedKernel t("surface_tension");
+            launch_op(OpSurface{ctx, cg.addr(), bufferFloat3.addr(), nullptr, fluids->getVelPtr(), rho0, surfaceTensionIntensity,
+                                airPressure, dt}, num);
+        }
+        break;
+    }
+    default: throw "PBDSolver::runPhase: unknown stage";
     }
 }

@@ -9,6 +9,7 @@
 #include <iostream>
 
 #include "DFSPHSolver.h"
+#include "PBDSolver.h"
 #include "SPHSystem.h"
 #include "sphx_c.h"
 #include "engine.hpp"
@@ -283,6 +284,15 @@ long long SPHSystem::errorTotalFixed()
 
 void SPHSystem::phase(int p)
 {
+    if (p >= SPHX_PH_P_SEARCH) {
+        auto* pbd = dynamic_cast<PBDSolver*>(_solver.get());
+        if (!pbd) throw "SPHSystem::phase: PBD stages need a PBDSolver";
+        if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, cellStartFluid);
+        pbd->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
+                      _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphG, _sphSurfaceTensionIntensity, _sphAirPressure);
+        if (p == SPHX_PH_P_TAIL) _graph->stepsRun++;
+        return;
+    }
     if (p >= SPHX_PH_W_SEARCH || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";

@@ -1,4 +1,4 @@
-"""multi_gpu.py — x-slab domain decomposition of the DFSPH step over torch.distributed (RCCL on GPUs).
+"""multi_gpu.py — x-slab domain decomposition of SPHSystem::step() over torch.distributed (RCCL on GPUs).
 
 One process per GPU.  The linear cell id runs x slowest, so rank r's slab of cell columns
 [x0, x1) plus its one-cell halos x0-1 and x1 is ONE contiguous range of the globally cell-sorted
@@ -27,8 +27,12 @@ DFSPH runs with fixed iteration counts or adaptively (the reference's loops, SUR
 termination sum is an exact integer, each rank sums its owned particles and a 1-word
 all-reduce gives every rank the identical total, so iteration counts equal the single-device ones.
 WCSPH uses four stages and two halo refreshes (colour gradient, pressure term).
+PBD sweeps run on positions that moved after binning: a particle binned in an edge
+column may sit one column further out when it is swept, so PBD slabs keep TWO ghost columns per side
+(still one contiguous range) and refresh lambda and the position mirror inside every Jacobi iteration,
+then the velocity mirror and the colour gradient: 2 * iters + 2 refreshes per step.
 
-Status this round: DFSPH and WCSPH (PBD not yet); static cut planes chosen from the initial particle
+Status this round: all three solvers; static cut planes chosen from the initial particle
 histogram; halo refreshes are not yet overlapped with interior work.  The driver is engine-agnostic: the HIP
 engine is used on GPUs, and the CPU tests plug in the oracle to exercise this file under gloo.
 """
@@ -41,7 +45,7 @@ import torch.distributed as dist
 
 (PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
  PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE,
- PH_W_PRESSURE) = range(16)
+ PH_W_PRESSURE, PH_P_SEARCH, PH_P_LAMBDA, PH_P_DELTA, PH_P_VELOCITY, PH_P_XSPH, PH_P_SURFACE, PH_P_TAIL) = range(23)
 
 EPS = 1e-6
 
@@ -54,8 +58,10 @@ def cell_column(x, cell_length):
     return (x.astype(np.float32) / np.float32(cell_length)).astype(np.int32)
 
 
-def choose_cuts(columns, gx, world):
-    """cut planes x_0=0 < x_1 < ... < x_world=gx balancing particle counts; every slab >= 2 columns"""
+def choose_cuts(columns, gx, world, min_width=2):
+    """cut planes x_0=0 < x_1 < ... < x_world=gx balancing particle counts; every slab >= min_width columns
+    (ghost width + 1: a particle that moves one column must be deliverable by its last owner to every
+    rank that needs it, owner or ghost holder, with neighbour messages only)"""
     hist = np.bincount(np.clip(columns, 0, gx - 1), minlength=gx).astype(np.int64)
     cdf = np.cumsum(hist)
     total = int(cdf[-1])
@@ -63,12 +69,12 @@ def choose_cuts(columns, gx, world):
     for r in range(1, world):
         target = total * r / world
         x = int(np.searchsorted(cdf, target, side="left")) + 1
-        x = max(x, cuts[-1] + 2)
-        x = min(x, gx - 2 * (world - r))
+        x = max(x, cuts[-1] + min_width)
+        x = min(x, gx - min_width * (world - r))
         cuts.append(x)
     cuts.append(gx)
     for a, b in zip(cuts[:-1], cuts[1:]):
-        if b - a < 2:
+        if b - a < min_width:
             raise ValueError("domain too narrow for %d slabs: cuts %s" % (world, cuts))
     return cuts
 
@@ -143,6 +149,7 @@ class HipSlabEngine:
 
     def __init__(self, sphx, params, cap, boundary_pos, boundary_mass, device):
         self.sphx, self.cap, self.device = sphx, cap, device
+        self.count = cap
         self.sys = sphx.System(params, np.zeros((cap, 3), np.float32), boundary_pos, ctor_step=False)
         if len(boundary_pos):
             self.sys.set(sphx.F_BMASS, np.ascontiguousarray(boundary_mass, np.float32))
@@ -158,12 +165,17 @@ class HipSlabEngine:
         if params.solver == sphx.DFSPH:
             self.f["warm"] = view(sphx.F_WARM, 1)
             self.f["kappa"] = view(sphx.F_KAPPA, 1)
+        if params.solver == sphx.PBD:
+            self.f["pos_last"] = view(sphx.F_POS_LAST, 3)
+            self.f["lambda"] = view(sphx.F_LAMBDA, 1)
+            self.f["pos_nbr"] = view(sphx.F_POS4, 4)      # (x, y, z, mass): what the sweeps gather
         self.pressure_halo = ["pterm"]     # what the pressure-force stage reads from neighbours
         self.cell_start = torch.as_tensor(_DevView(self.sys.device_ptr(sphx.F_CELLSTART_F), (self.C + 1,), "<i4"),
                                           device=device)
 
     def set_count(self, n):
         self.sys.set_count(n)
+        self.count = n
 
     def run(self, phase):
         self.sys.run_phase(phase)
@@ -210,6 +222,10 @@ class OracleSlabEngine:
         if params.solver == O.DFSPH:
             self.map["warm"] = O.F_WARM
             self.map["kappa"] = O.F_KAPPA
+        if params.solver == O.PBD:
+            self.map["pos_last"] = O.F_POS_LAST
+            self.map["lambda"] = O.F_LAMBDA
+            self.map["pos_nbr"] = O.F_POS
         self.pressure_halo = ["pressure", "density"]
         self.count = cap
 
@@ -254,13 +270,17 @@ class OracleSlabEngine:
 # ------------------------------------------------------------------------------------ the driver
 class SlabDriver:
     def __init__(self, engine, nbrs, x0, x1, gy, gz, cell_length, div_iters, den_iters, surface, timers=None,
-                 solver="dfsph", adaptive=None):
-        """adaptive: None, or dict(n_global, rho0, div_thr, den_thr, max_iter) for the reference's loops"""
+                 solver="dfsph", adaptive=None, ghost=1, pbd_iters=0):
+        """adaptive: None, or dict(n_global, rho0, div_thr, den_thr, max_iter) for the reference's loops;
+        ghost: ghost cell columns per side (1; PBD: 2, its sweeps run on positions that moved after binning)"""
         self.solver, self.adaptive = solver, adaptive
+        self.g, self.pbd_iters, self.steps_done = ghost, pbd_iters, 0
+        # per-particle state that travels with a particle besides pos, vel, id
+        self.extras = {"dfsph": [("warm", 1)], "pbd": [("pos_last", 3)]}.get(solver, [])
         self.iters = (0, 0)
         self.e, self.nb = engine, nbrs
         self.x0, self.x1, self.L = x0, x1, gy * gz
-        self.gxl = (x1 - x0) + 2
+        self.gxl = (x1 - x0) + 2 * ghost
         self.cl = cell_length
         self.v, self.d, self.surface = div_iters, den_iters, surface
         self.owned = (0, 0)
@@ -278,20 +298,26 @@ class SlabDriver:
         e.write("vel", 0, vel if vel is not None else torch.zeros_like(pos))
         if e.has("warm"):
             e.write("warm", 0, torch.zeros(n, dtype=torch.float32, device=pos.device))
+        if e.has("pos_last"):
+            e.write("pos_last", 0, pos)        # PBDSolver.h:56-60: the first step records the positions
         self.owned = (0, n)
 
     def _exchange_particles(self):
-        e = self.e
+        e, g = self.e, self.g
         o0, o1 = self.owned
         pos, vel = e.read("pos", o0, o1), e.read("vel", o0, o1)
         ids = e.read("ids", o0, o1)
-        warm = e.read("warm", o0, o1) if e.has("warm") else torch.zeros(o1 - o0, dtype=torch.float32, device=pos.device)
+        cols = [pos, vel, ids.view(torch.float32).unsqueeze(1)]
+        for name, comps in self.extras:
+            t = e.read(name, o0, o1)
+            cols.append(t if comps > 1 else t.unsqueeze(1))
         col = e.columns(o0, o1, self.cl)
         if o1 > o0 and (int(col.min()) < self.x0 - 1 or int(col.max()) > self.x1):
             raise RuntimeError("a particle crossed more than one cell column in one step")
-        payload = torch.cat([pos, vel, ids.view(torch.float32).unsqueeze(1), warm.unsqueeze(1)], dim=1)   # [m, 8]
-        to_left = payload[col <= self.x0] if self.nb.left is not None else None
-        to_right = payload[col >= self.x1 - 1] if self.nb.right is not None else None
+        payload = torch.cat(cols, dim=1)                                   # [m, 7 + extras]
+        width = payload.shape[1]
+        to_left = payload[col <= self.x0 + g - 1] if self.nb.left is not None else None
+        to_right = payload[col >= self.x1 - g] if self.nb.right is not None else None
         dev = payload.device
         # message sizes first
         cnt_send_l = torch.tensor([0 if to_left is None else to_left.shape[0]], dtype=torch.int64, device=dev)
@@ -300,8 +326,8 @@ class SlabDriver:
         cnt_recv_r = torch.zeros(1, dtype=torch.int64, device=dev)
         self.nb.exchange(cnt_send_l, cnt_send_r, cnt_recv_l, cnt_recv_r)
         nl, nr = int(cnt_recv_l.item()), int(cnt_recv_r.item())
-        from_left = torch.empty((nl, 8), dtype=torch.float32, device=dev)
-        from_right = torch.empty((nr, 8), dtype=torch.float32, device=dev)
+        from_left = torch.empty((nl, width), dtype=torch.float32, device=dev)
+        from_right = torch.empty((nr, width), dtype=torch.float32, device=dev)
         self.nb.exchange(to_left, to_right, from_left, from_right)
         pre = torch.cat([from_left, payload, from_right], dim=0)
         n = pre.shape[0]
@@ -310,14 +336,16 @@ class SlabDriver:
         e.write("pos", 0, pre[:, 0:3])
         e.write("vel", 0, pre[:, 3:6])
         e.write("ids", 0, pre[:, 6].contiguous().view(torch.int32))
-        if e.has("warm"):
-            e.write("warm", 0, pre[:, 7].contiguous())
+        at = 7
+        for name, comps in self.extras:
+            e.write(name, 0, pre[:, at:at + comps] if comps > 1 else pre[:, at].contiguous())
+            at += comps
         e.set_count(n)
 
     def _update_layers(self):
-        L, g = self.L, self.gxl
-        c = self.e.cell_starts([L, 2 * L, (g - 2) * L, (g - 1) * L, g * L])
-        # [0,c0) left ghosts, [c0,c1) first owned layer, [c2,c3) last owned layer, [c3,c4) right ghosts
+        L, g, w = self.L, self.gxl, self.g
+        c = self.e.cell_starts([w * L, 2 * w * L, (g - 2 * w) * L, (g - w) * L, g * L])
+        # [0,c0) left ghosts, [c0,c1) first w owned layers, [c2,c3) last w owned layers, [c3,c4) right ghosts
         self.layers = c
         self.owned = (c[0], c[3])
 
@@ -364,9 +392,32 @@ class SlabDriver:
         e.run(PH_W_PRESSURE)
         e.run(PH_ADVECT)
 
+    def _step_pbd(self):
+        """PBDSolver::step (PBDSolver.cu:34-79).  The k-th call equals the k-th SPHSystem::step() of the
+        single-device system counting its constructor step, which for PBD only sorts the particles and
+        records their positions (PBDSolver.cu:45-49)."""
+        e = self.e
+        self._exchange_particles()
+        e.run(PH_P_SEARCH)
+        self._update_layers()
+        self.steps_done += 1
+        if self.steps_done == 1:
+            return
+        for _ in range(self.pbd_iters):
+            e.run(PH_P_LAMBDA); self._halo("lambda")
+            e.run(PH_P_DELTA); self._halo("pos_nbr")
+        e.run(PH_P_VELOCITY); self._halo("vel_nbr")
+        e.run(PH_P_XSPH)
+        if self.surface:
+            self._halo("cg_nbr")
+        e.run(PH_P_SURFACE)
+        e.run(PH_P_TAIL)
+
     def step(self):
         if self.solver == "wcsph":
             return self._step_wcsph()
+        if self.solver == "pbd":
+            return self._step_pbd()
         e = self.e
         ad = self.adaptive
         self._exchange_particles()
@@ -430,32 +481,31 @@ def build_slab(make_engine, scene_params, fluid, boundary_sorted, boundary_mass,
     P = scene_params
     gx, gy, gz = P.cells[0], P.cells[1], P.cells[2]
     cl = P.cell_length
+    solver = {0: "wcsph", 1: "dfsph", 2: "pbd"}[P.solver]
+    ghost = 2 if solver == "pbd" else 1
     col = cell_column(fluid[:, 0], cl)
-    cuts = choose_cuts(col, gx, world)
+    cuts = choose_cuts(col, gx, world, min_width=ghost + 1)
     x0, x1 = cuts[rank], cuts[rank + 1]
     mine = fluid[(col >= x0) & (col < x1)]
     bcol = cell_column(boundary_sorted[:, 0], cl)
-    bsel = (bcol >= x0 - 1) & (bcol <= x1)
+    bsel = (bcol >= x0 - ghost) & (bcol <= x1 + ghost - 1)
     counts = [int(((col >= a) & (col < b)).sum()) for a, b in zip(cuts[:-1], cuts[1:])]
     cap = int(max(counts) * capacity_factor) + 4096
     Pl = type(P)()
     for name, _ in P._fields_:
         setattr(Pl, name, getattr(P, name))
-    Pl.cells[0] = (x1 - x0) + 2
-    Pl.reserved[1] = x0 - 1          # global column of local column 0
+    Pl.cells[0] = (x1 - x0) + 2 * ghost
+    Pl.reserved[1] = x0 - ghost      # global column of local column 0
     Pl.reserved[2] = 1               # slab system (also when the offset is 0)
     engine = make_engine(Pl, cap, np.ascontiguousarray(boundary_sorted[bsel]), np.ascontiguousarray(boundary_mass[bsel]))
     surface = P.surface_tension > EPS or P.air_pressure > EPS
     nbrs = Neighbors(rank, world)
-    solver = {0: "wcsph", 1: "dfsph"}.get(P.solver)
-    if solver is None:
-        raise NotImplementedError("the slab driver covers WCSPH and DFSPH")
     adaptive = None
     if solver == "dfsph" and (P.dfsph_fixed_div < 0 or P.dfsph_fixed_den < 0):
         adaptive = dict(n_global=len(fluid), rho0=P.rho0, div_thr=P.dfsph_divergence_thr, den_thr=P.dfsph_density_thr,
                         max_iter=P.dfsph_max_iter)
     drv = SlabDriver(engine, nbrs, x0, x1, gy, gz, cl, P.dfsph_fixed_div, P.dfsph_fixed_den, surface, solver=solver,
-                     adaptive=adaptive)
+                     adaptive=adaptive, ghost=ghost, pbd_iters=P.pbd_iters)
     sel = (col >= x0) & (col < x1)
     drv.load_initial(engine.to_device(np.ascontiguousarray(mine)),
                      None if velocity is None else engine.to_device(np.ascontiguousarray(velocity[sel])))
@@ -466,6 +516,11 @@ def build_slab(make_engine, scene_params, fluid, boundary_sorted, boundary_mass,
 
 
 # ------------------------------------------------------------------------------------ bench entry
+def engine_count(drv):
+    """particles the engine currently sweeps over (owned + ghost copies)"""
+    return int(drv.e.count)
+
+
 def run_slab_bench(args, rank, world, local_rank):
     """bench.py --gpus N (N > 1): the same global workload split into N x-slabs (strong scaling)."""
     import sphx
@@ -476,8 +531,11 @@ def run_slab_bench(args, rank, world, local_rank):
     if not dist.is_initialized():
         dist.init_process_group("nccl", device_id=device)
     P, fluid, boundary = sphx.scene(args.nx)
-    P.solver = sphx.DFSPH
-    P.dfsph_fixed_div, P.dfsph_fixed_den = args.div_iters, args.den_iters
+    solver_name = getattr(args, "solver", "dfsph")
+    P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver_name]
+    P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, getattr(args, "pbd_iters", 4)
+    if P.solver == sphx.WCSPH:
+        P.dt = 0.001
     # global boundary masses from a boundary-only whole-domain system (SPHSystem.cu:69-71)
     bsys = sphx.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
     bpos, bmass = bsys.get(sphx.F_BPOS), bsys.get(sphx.F_BMASS)
@@ -489,32 +547,59 @@ def run_slab_bench(args, rank, world, local_rank):
     drv, cuts, counts = build_slab(make_engine, P, fluid, bpos, bmass, rank, world)
     n_total = len(fluid)
     drv.step()                                   # = the constructor step of the single-device path
+    if P.solver == sphx.PBD:
+        drv.step()                               # PBD: the constructor step only records positions
     for _ in range(args.warmup):
         drv.step()
+    # live roofline leg (rank 0's slab): hipEvents around every launch of the dominant kernel on the
+    # stream the engine launches on (torch's current stream, handed over with sphx_use_stream)
+    span = "density_error"
+    if rank == 0 and P.solver == sphx.DFSPH:
+        sphx.kernel_timer(True, span)
+    active_sum = 0
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
+        active_sum += engine_count(drv)
     torch.cuda.synchronize(); dist.barrier()
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall = float(wall.item())
-    bpp = 420 + 92 * args.div_iters + 104 * args.den_iters + 72
+    if P.solver == sphx.DFSPH:
+        bpp = 420 + 92 * args.div_iters + 104 * args.den_iters + 72
+        what = "DFSPH(%d div + %d density iters, fixed)" % (args.div_iters, args.den_iters)
+    elif P.solver == sphx.WCSPH:
+        bpp, what = 396, "WCSPH"
+    else:
+        bpp, what = 300 + 104 * P.pbd_iters + 72, "PBD(%d Jacobi iters)" % P.pbd_iters
     steps_per_s = args.steps / wall
     halo_s = drv.timers.get("halo", 0.0) if drv.timers else None
     result = {
-        "metric": "simulation steps/sec, DFSPH dam-break", "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
+        "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, DFSPH(%d div + %d density iters, fixed), dt=%g"
-                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), args.div_iters, args.den_iters, P.dt),
-                   "particles": n_total, "decomposition": "%d x-slabs, cuts %s, initial particles per slab %s, one-cell halos over RCCL p2p"
-                                                          % (world, cuts, counts),
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g"
+                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt),
+                   "particles": n_total, "decomposition": "%d x-slabs, cuts %s, initial particles per slab %s, %d-cell halos over RCCL p2p"
+                                                          % (world, cuts, counts, drv.g),
                    "step_algorithmic_bytes_per_particle": bpp,
                    "step_algorithmic_GBps": bpp * n_total * steps_per_s / 1e9,
                    "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
         "roofline": None,
     }
+    if rank == 0 and P.solver == sphx.DFSPH:
+        spans = sphx.kernel_timer_collect()
+        sphx.kernel_timer(False)
+        if span in spans and spans[span][1] > 0:
+            tot_ms, launches = spans[span]
+            avg_ms = tot_ms / launches
+            per_launch = 44.0 * active_sum / args.steps        # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s'), rank 0's slab incl. ghosts" % span,
+                                  "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                                  "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                                  "algorithmic_bytes_per_launch": per_launch}
     dist.barrier()
     dist.destroy_process_group()
     return result

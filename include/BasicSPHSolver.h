@@ -40,6 +40,7 @@ public:
     void* engineVel4() const;
     void* engineCg4() const;
     void* enginePterm() const;
+    void* enginePos4() const;
     // one stage of the fused WCSPH schedule (SPHX_PH_W_* and SPHX_PH_ADVECT of sphx_c.h), for
     // distributed drivers that refresh halo fields between stages
     void runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& fluids,

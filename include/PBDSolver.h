@@ -32,6 +32,12 @@ public:
     // engine extension (snapshot restore): the last positions were written through the raw pointer
     void markPosLastInitialized() { posLastInitialized = true; }
     const DArray<float>& getLambda() const { return bufferFloat; }
+    // one stage of the PBD schedule (SPHX_PH_P_* of sphx_c.h), for distributed drivers that refresh
+    // halo fields between stages
+    void runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const std::shared_ptr<SPHParticles>& boundaries,
+                  const DArray<int>& cellStartFluid, const DArray<int>& cellStartBoundary, float3 spaceSize,
+                  int3 cellSize, float cellLength, float radius, float dt, float rho0, float rhoB, float3 G,
+                  float surfaceTensionIntensity, float airPressure);
 
 protected:
     void predict(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize);

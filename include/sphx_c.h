@@ -89,6 +89,7 @@ typedef enum sphx_field {
     SPHX_F_VEL4,           /* float[4n]  engine mirror of vel (x,y,z,0), what sweeps gather    */
     SPHX_F_CG4,            /* float[4n]  engine mirror of the colour gradient                  */
     SPHX_F_PTERM,          /* float[n]   p / max(EPS, rho^2), the neighbour term of the pressure force */
+    SPHX_F_POS4,           /* float[4n]  engine mirror of pos (x,y,z,mass), what sweeps gather (PBD halo target) */
     SPHX_F_COUNT_
 } sphx_field;
 
@@ -142,7 +143,18 @@ typedef enum sphx_phase {
     SPHX_PH_W_SEARCH,         /* neighbour search, pack + gravity kick, neighbour rows              */
     SPHX_PH_W_PROPS,          /* viscosity delta-v, colour gradient, density, pressure (writes cg, pterm) */
     SPHX_PH_W_SURFACE,        /* vel += deltaV, surface tension + air pressure                      */
-    SPHX_PH_W_PRESSURE        /* pressure force                                                     */
+    SPHX_PH_W_PRESSURE,       /* pressure force                                                     */
+    /* PBD schedule (PBDSolver.cu:34-79): P_SEARCH, pbd_iters x [P_LAMBDA, P_DELTA], P_VELOCITY, P_XSPH,
+     * P_SURFACE, P_TAIL.  PBD sweeps run on positions that moved after binning, so a slab keeps TWO
+     * ghost columns per side; refresh lambda after P_LAMBDA, the position mirror (SPHX_F_POS4) after
+     * P_DELTA, the velocity mirror after P_VELOCITY and the colour gradient mirror after P_XSPH. */
+    SPHX_PH_P_SEARCH,         /* neighbour search, last positions follow the sort, pack             */
+    SPHX_PH_P_LAMBDA,         /* neighbour rows for the current positions, density + lambda (writes lambda) */
+    SPHX_PH_P_DELTA,          /* delta-p sweep, pos += delta-p, box clamp       (writes pos mirror) */
+    SPHX_PH_P_VELOCITY,       /* vel = (pos - pos_last) / dt                    (writes vel mirror) */
+    SPHX_PH_P_XSPH,           /* XSPH viscosity (+ colour gradient)             (writes cg)        */
+    SPHX_PH_P_SURFACE,        /* surface tension + air pressure                                     */
+    SPHX_PH_P_TAIL            /* gravity, remember positions, predict (advect + clamp)              */
 } sphx_phase;
 int  sphx_run_phase(sphx_system *sys, int phase);
 /* adaptive DFSPH across processes: the error stages (DIV_ERROR, DEN_ERROR_ACC) accumulate the exact

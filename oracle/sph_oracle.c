@@ -696,7 +696,8 @@ float oracle_step(oracle_sys *s)
 /* Stage-wise DFSPH step (same stage numbering as sphx_phase in include/sphx_c.h), used by the
  * world_size-2 gloo tests of the slab driver with this oracle standing in for the HIP engine. */
 enum { PH_SEARCH = 0, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
-       PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE, PH_W_PRESSURE };
+       PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE, PH_W_PRESSURE,
+       PH_P_SEARCH, PH_P_LAMBDA, PH_P_DELTA, PH_P_VELOCITY, PH_P_XSPH, PH_P_SURFACE, PH_P_TAIL };
 int oracle_run_phase(oracle_sys *s, int phase)
 {
     const oracle_params *P = &s->P;
@@ -728,6 +729,26 @@ int oracle_run_phase(oracle_sys *s, int phase)
     case PH_W_PROPS: k_viscosity(s); if (surface) k_color_grad(s); k_density(s); k_pressure(s); break;
     case PH_W_SURFACE: if (surface) k_surface(s); break;
     case PH_W_PRESSURE: k_pressure_force(s); break;
+    /* PBDSolver::step (PBDSolver.cu:34-79) cut at the points where a sweep reads what a previous
+     * one wrote for the neighbours */
+    case PH_P_SEARCH:
+        neighbor_search(s, s->pos, s->vel, s->p2c, s->ids, s->n, s->csF);
+        resort_f3(s, s->pos_last);
+        s->pos_last_init = 1;
+        break;
+    case PH_P_LAMBDA: k_density_lambda(s); break;
+    case PH_P_DELTA: k_delta_pos(s); k_apply_dpos(s); break;
+    case PH_P_VELOCITY:
+        for (int i = 0; i < s->n; ++i) s->vel[i] = div3s(sub3(s->pos[i], s->pos_last[i]), P->dt);
+        break;
+    case PH_P_XSPH: k_xsph(s); if (surface) k_color_grad(s); break;
+    case PH_P_SURFACE: if (surface) k_surface(s); break;
+    case PH_P_TAIL:
+        k_force(s);
+        memcpy(s->pos_last, s->pos, sizeof(f3) * (size_t)s->n);
+        k_advect(s);
+        s->steps++;
+        break;
     default: return -1;
     }
     return 0;
@@ -831,6 +852,8 @@ int oracle_set(oracle_sys *s, int field, const void *src, long long bytes)
     case OF_POS: dst = s->pos; want = 12LL * s->n; break;
     case OF_VEL: dst = s->vel; want = 12LL * s->n; break;
     case OF_WARM: dst = s->warm; want = 4LL * s->n; break;
+    case OF_POS_LAST: dst = s->pos_last; want = 12LL * s->n; s->pos_last_init = 1; break;
+    case OF_LAMBDA: dst = s->lambda; want = 4LL * s->n; break;
     case OF_ID: dst = s->ids; want = 4LL * s->n; break;
     case OF_KAPPA: dst = s->kappa; want = 4LL * s->n; break;
     case OF_BUF3: dst = s->buf3; want = 12LL * s->n; break;

@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
 
 
 def configure(P, E, solver, adaptive):
-    P.solver = E.DFSPH if solver == "dfsph" else E.WCSPH
+    P.solver = {"dfsph": E.DFSPH, "wcsph": E.WCSPH, "pbd": E.PBD}[solver]
+    P.pbd_iters = 3
     if solver == "dfsph" and not adaptive:
         P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3
     P.dt = 0.001
@@ -24,6 +25,12 @@ def splash(n, P, seed):
     vel = rng.normal(0, 0.6, (n, 3)).astype(np.float32)
     vel[:, 0] += np.where(pos[:, 0] < 0.5 * P.space[0], 2.5, -2.5).astype(np.float32)   # drive flow across the cuts
     return pos, vel
+
+
+def pbd_last_positions(pos, vel, P):
+    """PBD derives velocities from displacements: give the particles the splash velocities by moving
+    the recorded last positions back by dt * vel (same fp32 arithmetic in every process)"""
+    return (pos - np.float32(P.dt) * vel).astype(np.float32)
 
 
 def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver="dfsph", adaptive=False):
@@ -55,8 +62,12 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
     drv, cuts, counts = M.build_slab(make, P, pos, bpos, bmass, rank, world, capacity_factor=2.0, velocity=vel)
     migrated = 0
     prev = None
-    for _ in range(steps):
+    for k in range(steps):
         drv.step()
+        if solver == "pbd" and k == 0:      # after the recording step (PBDSolver.cu:45-49)
+            o0, o1 = drv.owned
+            own = drv.e.read("ids", o0, o1).cpu().numpy()
+            drv.e.write("pos_last", o0, drv.e.to_device(np.ascontiguousarray(pbd_last_positions(pos, vel, P)[own])))
         ids = drv.owned_state()[0]
         if prev is not None:
             migrated += len(np.setdiff1d(ids, prev))

@@ -23,8 +23,10 @@ def _single_domain(oracle, nx, steps, seed, solver="dfsph", adaptive=False, want
     s = oracle.System(P, pos, boundary, ctor_step=False)
     ids = s.get(oracle.F_ID)
     s.set(oracle.F_VEL, vel[ids])
-    for _ in range(steps):
+    for k in range(steps):
         s.step()
+        if solver == "pbd" and k == 0:
+            s.set(oracle.F_POS_LAST, slab_worker.pbd_last_positions(pos, vel, P)[s.get(oracle.F_ID)])
     ids = s.get(oracle.F_ID)
     order = np.argsort(ids)
     out = (s.get(oracle.F_POS)[order], s.get(oracle.F_VEL)[order], s.get(oracle.F_DENSITY)[order])
@@ -32,7 +34,7 @@ def _single_domain(oracle, nx, steps, seed, solver="dfsph", adaptive=False, want
 
 
 @pytest.mark.parametrize("world,solver,adaptive", [(2, "dfsph", False), (3, "dfsph", False), (2, "wcsph", False),
-                                                   (3, "dfsph", True)])
+                                                   (3, "dfsph", True), (2, "pbd", False), (3, "pbd", False)])
 def test_slab_driver_matches_single_domain(oracle, tmp_path, world, solver, adaptive):
     import torch.multiprocessing as mp
     nx, steps, seed = 12, 6, 17
