@@ -81,8 +81,19 @@ def read_traffic(workload_key):
         return None
 
 
+def emit(result, real_stdout):
+    """the ONE JSON line, on the process's original stdout"""
+    os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+
 def main():
     args = parse()
+    # Everything but the result line goes to stderr: RCCL prints its version banner and the engine its
+    # notices (e.g. PBD's first-step message, PBDSolver.cu:45-49) on the C-level stdout, buffered until
+    # exit, i.e. after a Python print.  stdout carries exactly one line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,7 +113,7 @@ def main():
         from multi_gpu import run_slab_bench        # x-slab decomposition, torch.distributed (RCCL)
         result = run_slab_bench(args, rank, world, local_rank)
         if rank == 0:
-            print(json.dumps(result))
+            emit(result, real_stdout)
         return
 
     sphx.set_device(local_rank)
@@ -175,7 +186,7 @@ def main():
     sim.close()
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, n)
-    print(json.dumps(result))
+    emit(result, real_stdout)
 
 
 if __name__ == "__main__":
