@@ -22,7 +22,7 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 
 // Per-solver packed views of the particle sets and the per-step neighbour list, refreshed when
 // positions move.
-//   posm / bposm : float4 (x, y, z, mass) in cell-sorted order, one 16-byte load per neighbour
+//   posm         : float4 (x, y, z, mass) in cell-sorted order, fluid then boundary, one 16-byte load per neighbour
 //   pterm        : p_j / max(EPS, rho_j^2), the per-particle half of the pressure-force weight
 //   nbr/nbrCount : wave-interleaved compact neighbour rows (sph_device.hpp), `cap` entries/particle
 //   aux3         : second float3 scratch (viscosity delta-v while bufferFloat3 holds the colour
@@ -49,7 +49,11 @@ struct SweepCache {
     std::unique_ptr<DArray<int>> tileBuckets; // histogram / cursors of the (y-chunk, x) buckets
     bool orderValid = false;
     std::unique_ptr<DArray<int>> nbr;        // allocated on first use
-    std::unique_ptr<DArray<float>> bposm;    // 4 floats per boundary particle
+    // Unified neighbour space: posm, posf, vel4 and cg4 hold [capN fluid slots | nbCap boundary slots].
+    // A row entry carries ONE index into it, so a sweep gathers with a uniform base pointer and a
+    // 32-bit offset, with no per-entry pointer select; the boundary tails of vel4 / cg4 stay +0.
+    int capN = 0;                            // fluid slots (the capacity given at construction)
+    int nbCap = 0;                           // boundary slots currently reserved
     int nb = 0;
     int cap = 96;
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)
@@ -71,6 +75,8 @@ struct SweepCache {
     // pack and apply the gravity kick vel += dv in one pass (only valid right after a re-sort)
     void packFluidKick(const SPHParticles& fluids, float3 dv);
     void packBoundary(const SPHParticles& boundaries);
+    // make room for `count` boundary slots (contents of the fluid part are kept; pointers change)
+    void reserveBoundary(int count);
     void invalidatePositions() { fluidValid = false; listValid = false; orderValid = false; }
     void ensureTileOrder();
     // build the neighbour rows for the current positions (no-op when valid or disabled)
@@ -82,7 +88,7 @@ struct SweepCache {
     float4* vel4w() const { return reinterpret_cast<float4*>(vel4.addr()); }
     float4* cg4w() const { return reinterpret_cast<float4*>(cg4.addr()); }
     float4* posfw() const { return reinterpret_cast<float4*>(posf.addr()); }
-    const float4* boundary4() const { return reinterpret_cast<const float4*>(bposm->addr()); }
+    const float4* boundary4() const { return fluid4() + capN; }
 };
 
 inline unsigned int blocks_for(int n, int block = 256) { return n > 0 ? (unsigned int)((n - 1) / block + 1) : 1u; }

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 }
 
 SweepCache::SweepCache(int num)
-    : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
+    : n(num), capN(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2))
 {
@@ -412,16 +412,33 @@ void SweepCache::packFluidKick(const SPHParticles& fluids, float3 dv)
     listValid = false;
 }
 
+void SweepCache::reserveBoundary(int count)
+{
+    if (count <= nbCap) return;
+    const unsigned int len = 4u * (unsigned)(capN + count);
+    auto grow = [&](DArray<float>& a) {
+        DArray<float> t(len);                                   // zero-filled
+        ew_copy(t.addr(), a.addr(), sizeof(float) * 4u * (size_t)capN);
+        a.swap(t);
+    };
+    grow(posm); grow(posf); grow(vel4); grow(cg4);
+    nbCap = count;
+    boundaryValid = false;
+    listValid = false;
+}
+
 void SweepCache::packBoundary(const SPHParticles& boundaries)
 {
     const int count = (int)boundaries.size();
     if (boundaryValid && boundaryKey == (const void*)boundaries.getPosPtr() && nb == count) return;
-    if (!bposm || nb != count) bposm.reset(new DArray<float>(4u * (unsigned)(count > 0 ? count : 1)));
+    reserveBoundary(count);
     nb = count;
     ScopedKernel t("pack_boundary");
-    if (count > 0)
-        k_pack4<<<blocks_for(count), 256, 0, stream()>>>(reinterpret_cast<float4*>(bposm->addr()), boundaries.getPosPtr(),
-                                                          boundaries.getMassPtr(), count);
+    if (count > 0) {
+        // (x, y, z, mass) into the boundary tail of both position arrays (plain and one-gather view)
+        k_pack4<<<blocks_for(count), 256, 0, stream()>>>(fluid4w() + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
+        k_pack4<<<blocks_for(count), 256, 0, stream()>>>(posfw() + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
+    }
     boundaryKey = (const void*)boundaries.getPosPtr();
     boundaryValid = true;
     listValid = false;
@@ -432,7 +449,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     SweepCtx c;
     c.g = g; c.k = k;
     c.csF = csF.addr(); c.posm = fluid4();
-    c.csB = csB.addr(); c.bposm = bposm ? boundary4() : nullptr;
+    c.csB = csB.addr(); c.bposm = boundary4(); c.bOff = capN;
     const bool use = listValid && nbr && !(flags & kFlagNoList);
     if (use) { c.csF = listCsF; c.csB = listCsB; }   // rows (and tile tables) are tied to these tables
     c.nbr = use ? reinterpret_cast<const unsigned int*>(nbr->addr()) : nullptr;
@@ -454,6 +471,7 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     if (listValid || (flags & kFlagNoList) || n <= 0) return;
     const unsigned long long entries = (unsigned long long)((n + 63) / 64) * 64ull * (unsigned long long)cap;
     if (entries > 0xfffffff0ull) { flags |= kFlagNoList; return; }   // beyond DArray's 32-bit length
+    if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; return; }
     if (!nbr) nbr.reset(new DArray<int>((unsigned)entries));
     ensureTileOrder();
     SweepCtx c = ctx(csF, csB);

@@ -285,9 +285,11 @@ __device__ __forceinline__ void sweep27(const GridDesc& g, const KernelConsts& k
 constexpr int kTile = 64;
 constexpr int kWideBlock = 256;     // threads per block: 4 waves = 4 adjacent tiles share a CU
 constexpr int kGroupSlots = 384;    // LDS slots per wave and dx group
-constexpr unsigned int kBoundaryBit = 0x80000000u;       // fmt 0: bit 31 boundary, bit 30 plain-ops, 0..29 index
+// fmt 0: bit 31 boundary, bit 30 plain-ops, bits 29..28 zero, 0..27 index into the unified neighbour
+// space [fluid slots | boundary slots] (so `entry << 4` is the byte offset of a float4 record)
+constexpr unsigned int kBoundaryBit = 0x80000000u;
 constexpr unsigned int kPlainBit = 0x40000000u;
-constexpr unsigned int kIndexMask = 0x3fffffffu;
+constexpr unsigned int kIndexMask = 0x0fffffffu;
 constexpr unsigned int kStreamBoundaryBit = 0x10000000u;  // fmt 2: 30..29 group, 28 boundary, 27 plain-ops, 0..26 slot
 constexpr unsigned int kStreamPlainBit = 0x08000000u;
 constexpr unsigned int kStreamSlotMask = 0x07ffffffu;
@@ -303,7 +305,8 @@ inline unsigned int xcd_grid(int n, int block) { const int nb = n > 0 ? (n - 1) 
 struct SweepCtx {
     GridDesc g; KernelConsts k;
     const int* csF; const float4* posm;     // fluid cell starts, packed (x,y,z,mass)
-    const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass)
+    const int* csB; const float4* bposm;    // boundary cell starts, packed (x,y,z,mass) = posm + bOff
+    int bOff;                               // unified index of boundary particle 0 (= fluid capacity)
     const unsigned int* nbr; const int* nbrCount; int cap;   // nbr == nullptr: direct sweeps only
     const int* tileFmt;                     // per tile entry format (nullptr: all tiles fmt 0)
     float4* vel4;                           // 16-byte aligned mirror of the fluid velocities (one gather)
@@ -418,19 +421,25 @@ template <class Op> __device__ __forceinline__ auto op_packed_impl(const Op& op,
 template <class Op> __device__ __forceinline__ bool op_packed_impl(const Op&, long) { return false; }
 template <class Op> __device__ __forceinline__ bool op_packed_scalar(const Op& op) { return op_packed_impl(op, 0); }
 
-template <class Op>
-__device__ __forceinline__ void fetch_pair(const Op& op, const SweepCtx& c, bool packed, float m0, unsigned int e, float4& pj,
+// 16-byte record at byte offset `off` of a unified array: uniform base + 32-bit lane offset
+__device__ __forceinline__ float4 gather16(const float4* __restrict__ base, unsigned int off)
+{
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+
+template <bool PACKED, class Op>
+__device__ __forceinline__ void fetch_pair(const Op& op, const SweepCtx& c, float m0, unsigned int e, float4& pj,
                                            typename Op::Field& f)
 {
     const bool isB = (e & kBoundaryBit) != 0u;
-    const int idx = (int)(e & kIndexMask);
-    if (packed) {
-        const float4 r = (isB ? c.bposm : c.posf)[idx];
+    const unsigned int off = e << 4;            // the four flag bits shift out
+    if (PACKED) {
+        const float4 r = gather16(c.posf, off); // fluid: (pos, field); boundary: (pos, mass)
         pj = make_float4(r.x, r.y, r.z, isB ? r.w : m0);
         f = scalar_field<typename Op::Field>(isB ? 0.0f : r.w);
     } else {
-        pj = isB ? c.bposm[idx] : c.posm[idx];
-        f = op.stage(isB, idx);
+        pj = gather16(c.posm, off);
+        f = op.stage(isB, (int)(e & kIndexMask));
     }
 }
 
@@ -442,6 +451,45 @@ __device__ __forceinline__ void pair_dispatch(Body& body, const bool plain, cons
 {
     if (__builtin_expect(__any(plain), 0)) body.template pair<false>(f, isB, d, r2, mj, idx);
     else body.template pair<true>(f, isB, d, r2, mj, idx);
+}
+
+// One lane's row.  The chain "row entry -> gather -> arithmetic" is latency-bound when walked one
+// entry at a time (the row streams from HBM, the gathers mostly from L2): kAhead entries and their
+// gathers are issued together, the pair terms are then accumulated strictly in row order.
+#ifndef SPHX_AHEAD
+#define SPHX_AHEAD 4
+#endif
+template <bool PACKED, bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ row, const int cnt,
+                                         const float m0, const bool allPlain, const float3 pi, Body& body)
+{
+    constexpr int kAhead = SPHX_AHEAD;
+    int t = 0;
+    for (; t + kAhead <= cnt; t += kAhead) {
+        unsigned int e[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) e[u] = row[(size_t)(t + u) * 64u];
+        float4 pj[kAhead];
+        typename Op::Field f[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const bool isB = (e[u] & kBoundaryBit) != 0u;
+            if (!WANT_BOUNDARY && isB) continue;
+            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+            pair_dispatch(body, allPlain || (e[u] & kPlainBit) != 0u, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & kIndexMask));
+        }
+    }
+    for (; t < cnt; ++t) {
+        const unsigned int e = row[(size_t)t * 64u];
+        const bool isB = (e & kBoundaryBit) != 0u;
+        if (!WANT_BOUNDARY && isB) continue;
+        float4 pj; typename Op::Field fj;
+        fetch_pair<PACKED, Op>(op, c, m0, e, pj, fj);
+        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+        pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, fj, isB, d, dot3(d, d), pj.w, (int)(e & kIndexMask));
+    }
 }
 
 // The sweep of one particle (all 64 lanes of a wave call it together; `valid` = lane has a particle).
@@ -475,7 +523,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                 const float4* from = isB ? c.bposm : c.posm;
                 for (int t = lane; t < ln; t += kTile) {
                     ldsPos[o + t] = from[s0 + t];
-                    ldsField[o + t] = op.stage(isB, s0 + t);
+                    ldsField[o + t] = op.stage(isB, s0 + t + (isB ? c.bOff : 0));
                 }
             }
             wave_lds_fence();
@@ -495,7 +543,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
         }
         if (valid && !useRow)
             walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
-                body.template pair<false>(op.stage(isB, j), isB, d, r2, mj, j);
+                body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
             });
         return;
     }
@@ -504,47 +552,14 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
     const bool packed = op_packed_scalar<Op>(op) && c.posf && c.massUniform && *c.massUniform != 0;
     const float m0 = packed ? c.posm[0].w : 0.0f;
     if (useRow) {
-        // The chain "row entry -> gather -> arithmetic" is latency-bound when walked one entry at a
-        // time (the row streams from HBM, the gathers mostly from L2).  kAhead entries and their
-        // gathers are issued together so kAhead*3 loads are in flight per lane; the pair terms are
-        // then accumulated strictly in row order.
-#ifndef SPHX_AHEAD
-#define SPHX_AHEAD 4
-#endif
-        constexpr int kAhead = SPHX_AHEAD;
-        int t = 0;
-        for (; t + kAhead <= cnt; t += kAhead) {
-            unsigned int e[kAhead];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) e[u] = row[(size_t)(t + u) * 64u];
-            float4 pj[kAhead];
-            typename Op::Field f[kAhead];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                fetch_pair<Op>(op, c, packed, m0, e[u], pj[u], f[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                const bool isB = (e[u] & kBoundaryBit) != 0u;
-                if (!WANT_BOUNDARY && isB) continue;
-                const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
-                pair_dispatch(body, allPlain || (e[u] & kPlainBit) != 0u, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & kIndexMask));
-            }
-        }
-        for (; t < cnt; ++t) {
-            const unsigned int e = row[(size_t)t * 64u];
-            const bool isB = (e & kBoundaryBit) != 0u;
-            if (!WANT_BOUNDARY && isB) continue;
-            const int idx = (int)(e & kIndexMask);
-            float4 pj; typename Op::Field fj;
-            fetch_pair<Op>(op, c, packed, m0, e, pj, fj);
-            const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-            pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, fj, isB, d, dot3(d, d), pj.w, idx);
-        }
+        // one-gather mode is uniform over the launch: two separate loops, so that each keeps its
+        // single 16-byte gather per neighbour (a merged loop makes the compiler split the loads)
+        if (packed) walk_row<true, WANT_BOUNDARY>(op, c, row, cnt, m0, allPlain, pi, body);
+        else walk_row<false, WANT_BOUNDARY>(op, c, row, cnt, m0, allPlain, pi, body);
         return;
     }
     walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
-        body.template pair<false>(op.stage(isB, j), isB, d, r2, mj, j);
+        body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
     });
 }
 
@@ -593,7 +608,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                 if (Y < 0 || Y >= c.g.gy) continue;
                 const int base = (X * c.g.gy + Y) * c.g.gz;
                 const int fShift = dy < 0 ? fSh[0] : (dy == 0 ? fSh[1] : fSh[2]);
-                const int bShift = dy < 0 ? bSh[0] : (dy == 0 ? bSh[1] : bSh[2]);
+                const int bShift = streamed ? (dy < 0 ? bSh[0] : (dy == 0 ? bSh[1] : bSh[2])) : c.bOff;
                 const unsigned int plainBit = streamed ? kStreamPlainBit : kPlainBit;
                 const unsigned int fTag = streamed ? ((unsigned)g << 29) : 0u;
                 const unsigned int bTag = streamed ? (((unsigned)g << 29) | kStreamBoundaryBit) : kBoundaryBit;
@@ -633,7 +648,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                             const float r2 = dot3(d, d);
                             if (r2 > c.k.tCut) continue;
-                            if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
+                            if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);   // bShift: + bOff (fmt 0)
                             ++cnt;
                         }
                     }

@@ -53,6 +53,17 @@ __device__ __forceinline__ void accumulate_error(long long fixed, unsigned long 
 
 __device__ __forceinline__ float4 f4(const float3 v) { return make_float4(v.x, v.y, v.z, 0.0f); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+// stage(isBoundary, j): j indexes the unified neighbour space [fluid | boundary].
+// float4 fields (vel4, cg4) have a +0 boundary tail, so their load needs no test at all; scalar
+// fields live in solver arrays of fluid length: boundary entries read slot 0 and discard it.  Either
+// way the load is unconditional — a guarded load compiles to an exec-mask branch with
+// `s_waitcnt vmcnt(0)` inside, which serialises the kAhead gathers a lane has in flight.
+__device__ __forceinline__ float4 field4(const float4* __restrict__ a, int j) { return gather16(a, (unsigned int)j << 4); }
+__device__ __forceinline__ float fluid_only(const float* __restrict__ a, bool isB, int j)
+{
+    const float v = a[isB ? 0 : j];
+    return isB ? 0.0f : v;
+}
 // the lane's own position (lanes past the end of the array still take part in wave-wide staging)
 __device__ __forceinline__ float3 own_pos(const SweepCtx& c, int i, bool valid) { return valid ? xyz(c.posm[i]) : v3(0, 0, 0); }
 
@@ -68,7 +79,7 @@ struct OpFluidProps {
     float* density; float* pressure; float* pterm;
     float rho0, rhoB, visc, dt, stiff;
     using Field = float4;   // neighbour velocity
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return (VISC && !isB) ? c.vel4[j] : f4zero(); }
+    __device__ __forceinline__ Field stage(bool, int j) const { return VISC ? field4(c.vel4, j) : f4zero(); }
     struct Body {
         const OpFluidProps& o; float3 vi; float3 a; float3 cg; float cden; float den;
         template <bool FAST>
@@ -116,7 +127,7 @@ struct OpSurface {
     const float3* colorGrad; const float3* velIn; const float3* addend; float3* velOut;
     float rho0, tension, airPressure, dt;
     using Field = float4;   // neighbour colour gradient
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.cg4[j]; }
+    __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.cg4, j); }
     struct Body {
         const OpSurface& o; float dii, li, ml; float3 a;
         template <bool FAST>
@@ -151,7 +162,7 @@ struct OpPressureForce {
     float dt;
     bool packedScalar;      // posf.w holds pterm
     using Field = float;    // neighbour p_j / max(EPS, rho_j^2)
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : pterm[j]; }
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return fluid_only(pterm, isB, j); }
     struct Body {
         const OpPressureForce& o; int i; float pti; float3 a;
         template <bool FAST>
@@ -208,7 +219,7 @@ struct OpDfsphHead {
     const float3* vel; float* density; float* alpha;
     RateOut out;
     using Field = float4;   // neighbour velocity
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return (vel && !isB) ? c.vel4[j] : f4zero(); }
+    __device__ __forceinline__ Field stage(bool, int j) const { return vel ? field4(c.vel4, j) : f4zero(); }
     struct Body {
         const OpDfsphHead& o; float3 vi; float den, sl, e; float3 gs;
         bool withRate;
@@ -260,7 +271,7 @@ struct OpRate {
     const float3* vel; const float* density; const float* alpha;
     RateOut out;
     using Field = float4;   // neighbour velocity
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
+    __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.vel4, j); }
     struct Body {
         const OpRate& o; float3 vi; float e;
         template <bool FAST>
@@ -302,7 +313,7 @@ struct OpCorrect {
     float dt;
     bool packedScalar;      // posf.w currently holds THIS kappa array for every fluid particle
     using Field = float;    // neighbour stiffness
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : kappa[j]; }
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return fluid_only(kappa, isB, j); }
     struct Body {
         const OpCorrect& o; float ki; float3 a;
         template <bool FAST>
@@ -364,7 +375,7 @@ struct OpDeltaPos {
     float rho0;
     bool packedScalar;      // posf.w holds lambda
     using Field = float;    // neighbour lambda
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? 0.0f : lambda[j]; }
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return fluid_only(lambda, isB, j); }
     struct Body {
         const OpDeltaPos& o; float li; float3 a;
         template <bool FAST>
@@ -390,7 +401,7 @@ struct OpXsph {
     const float3* vel; float3* velOut; float3* colorGrad;
     float xsphC, rho0, rhoB;
     using Field = float4;   // neighbour velocity
-    __device__ __forceinline__ Field stage(bool isB, int j) const { return isB ? f4zero() : c.vel4[j]; }
+    __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.vel4, j); }
     struct Body {
         const OpXsph& o; float3 vi; float3 a; float3 cg; float cden;
         template <bool FAST>

@@ -318,6 +318,7 @@ void SPHSystem::initialise(float sphM0, bool runStep)
     const int cells = _cellSize.x * _cellSize.y * _cellSize.z;
     _grid.reset(new GridScratch(std::max(std::max((int)_fluids->capacity(), (int)_boundaries->capacity()), 1), cells));
     _graph.reset(new StepGraph());
+    if (auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get())) w->reserveBoundary((int)_boundaries->capacity());
     neighborSearch(_boundaries, cellStartBoundary);
     computeBoundaryMass();
     ew_fill_float(_fluids->getMassPtr(), sphM0, (int)_fluids->capacity());

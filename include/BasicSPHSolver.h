@@ -41,6 +41,9 @@ public:
     void* engineCg4() const;
     void* enginePterm() const;
     void* enginePos4() const;
+    // reserve the boundary part of the engine's unified neighbour arrays (called once by SPHSystem
+    // before any engine pointer is handed out; otherwise done lazily by the first step)
+    void reserveBoundary(int count);
     // one stage of the fused WCSPH schedule (SPHX_PH_W_* and SPHX_PH_ADVECT of sphx_c.h), for
     // distributed drivers that refresh halo fields between stages
     void runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& fluids,
