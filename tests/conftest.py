@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# The oracle's OpenMP regions are tiny in these tests; on a many-core box (or a CPU-limited container
+# that still reports every host core) a full-width team per region costs far more than the work.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+ORACLE_TEST_THREADS = 16
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
@@ -24,7 +29,8 @@ def sphx():
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as mod
-    mod.lib()
+    L = mod.lib()
+    L.oracle_set_threads(min(L.oracle_max_threads(), ORACLE_TEST_THREADS))
     return mod
 
 

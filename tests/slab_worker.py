@@ -42,6 +42,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
     import multi_gpu as M
     if engine_kind == "oracle":
         from oracle import oracle as E
+        E.lib().oracle_set_threads(min(E.lib().oracle_max_threads(), 4))     # several ranks share the host
         P, fluid, boundary = E.scene(nx)
     else:
         import sphx as E
