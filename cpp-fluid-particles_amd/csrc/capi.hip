@@ -34,6 +34,27 @@ static int fail(int code, const std::string& msg)
     return code;
 }
 
+// No C++ exception may cross the C boundary: the classes signal state errors with `throw "text"`
+// like the reference (PBDSolver.cu:45-49), the runtime may throw std::bad_alloc.
+template <class F>
+static int guarded(const char* where, F&& body)
+{
+    try {
+        return body();
+    } catch (const char* msg) {
+        return fail(SPHX_ERR_STATE, msg);
+    } catch (const std::bad_alloc&) {
+        return fail(SPHX_ERR_HIP, std::string(where) + ": out of host memory");
+    } catch (const std::exception& e) {
+        return fail(SPHX_ERR_STATE, std::string(where) + ": " + e.what());
+    } catch (...) {
+        return fail(SPHX_ERR_STATE, std::string(where) + ": unknown exception");
+    }
+}
+
+static int create_impl(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
+                       sphx_system** out);
+
 extern "C" {
 
 const char* sphx_last_error(void) { return last_error_text().c_str(); }
@@ -133,6 +154,14 @@ int sphx_scene_fill(int nx, float* fluid, float* boundary)
 int sphx_create(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
                 sphx_system** out)
 {
+    return guarded("sphx_create", [&] { return create_impl(P, fluid, n, boundary, nb, run_ctor_step, out); });
+}
+
+}  // extern "C"
+
+static int create_impl(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
+                       sphx_system** out)
+{
     if (!P || !out || n < 0 || nb < 0 || (n && !fluid) || (nb && !boundary)) return fail(SPHX_ERR_INVALID, "sphx_create: bad argument");
     if (P->pow7_mode != 0 || P->xsph_mode != 0) return fail(SPHX_ERR_INVALID, "sphx_create: pow7_mode and xsph_mode must be 0");
     if (P->cells[0] <= 0 || P->cells[1] <= 0 || P->cells[2] <= 0) return fail(SPHX_ERR_INVALID, "sphx_create: bad grid");
@@ -191,6 +220,8 @@ int sphx_create(const sphx_params* P, const float* fluid, int n, const float* bo
     return SPHX_OK;
 }
 
+extern "C" {
+
 int sphx_destroy(sphx_system* h)
 {
     if (!h) return SPHX_OK;
@@ -203,17 +234,21 @@ int sphx_destroy(sphx_system* h)
 int sphx_step(sphx_system* h, float* ms)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "sphx_step: null system");
-    const float t = h->system->step();
-    if (ms) *ms = t;
-    return SPHX_OK;
+    return guarded("sphx_step", [&] {
+        const float t = h->system->step();
+        if (ms) *ms = t;
+        return (int)SPHX_OK;
+    });
 }
 
 int sphx_step_n(sphx_system* h, int n, float* ms_total)
 {
     if (!h || n < 0) return fail(SPHX_ERR_INVALID, "sphx_step_n: bad argument");
-    const float t = h->system->stepN(n);
-    if (ms_total) *ms_total = t;
-    return SPHX_OK;
+    return guarded("sphx_step_n", [&] {
+        const float t = h->system->stepN(n);
+        if (ms_total) *ms_total = t;
+        return (int)SPHX_OK;
+    });
 }
 
 int sphx_counts(const sphx_system* h, int* n, int* nb, int* cells)
