@@ -34,7 +34,7 @@ then the velocity mirror and the colour gradient: 2 * iters + 2 refreshes per st
 
 Status this round: all three solvers; static cut planes chosen from the initial particle
 histogram; halo refreshes are not yet overlapped with interior work.  The driver is engine-agnostic: the HIP
-engine is used on GPUs, and the CPU tests plug in the oracle to exercise this file under gloo.
+engine is the product; the CPU tests plug in a stand-in engine (tests/slab_cpu_engine.py) to exercise this file under gloo.
 """
 import os
 import time
@@ -146,6 +146,7 @@ class _DevView:
 
 class HipSlabEngine:
     """the HIP engine (libsphx.so) on one slab; fields are zero-copy torch views of device memory"""
+    zero_copy = True
 
     def __init__(self, sphx, params, cap, boundary_pos, boundary_mass, device):
         self.sphx, self.cap, self.device = sphx, cap, device
@@ -206,65 +207,6 @@ class HipSlabEngine:
 
     def to_device(self, arr):
         return torch.as_tensor(arr, device=self.device)
-
-
-class OracleSlabEngine:
-    """CPU stand-in used only by the tests: the oracle behind the same interface (copies, no views)"""
-
-    def __init__(self, O, params, cap, boundary_pos, boundary_mass):
-        self.O, self.cap = O, cap
-        self.sys = O.System(params, np.zeros((cap, 3), np.float32), boundary_pos, ctor_step=False)
-        if len(boundary_pos):
-            self.sys.set(O.F_BMASS, np.ascontiguousarray(boundary_mass, np.float32))
-        self.C = self.sys.C
-        self.map = {"pos": O.F_POS, "vel": O.F_VEL, "ids": O.F_ID, "vel_nbr": O.F_VEL, "cg_nbr": O.F_BUF3,
-                    "density": O.F_DENSITY, "pressure": O.F_PRESSURE}
-        if params.solver == O.DFSPH:
-            self.map["warm"] = O.F_WARM
-            self.map["kappa"] = O.F_KAPPA
-        if params.solver == O.PBD:
-            self.map["pos_last"] = O.F_POS_LAST
-            self.map["lambda"] = O.F_LAMBDA
-            self.map["pos_nbr"] = O.F_POS
-        self.pressure_halo = ["pressure", "density"]
-        self.count = cap
-
-    def run_reduce(self, phase, lo, hi):
-        self.sys.run_phase(phase)
-        return self.sys.error_total_fixed(lo, hi)
-
-    def has(self, name):
-        return name in self.map
-
-    def set_count(self, n):
-        self.sys.set_count(n)
-        self.count = n
-
-    def run(self, phase):
-        self.sys.run_phase(phase)
-
-    def read(self, name, lo, hi):
-        self.sys.set_count(self.cap)               # whole-capacity view for the copy
-        out = torch.from_numpy(self.sys.get(self.map[name])[lo:hi].copy())
-        self.sys.set_count(self.count)
-        return out
-
-    def write(self, name, lo, t):
-        self.sys.set_count(self.cap)
-        full = self.sys.get(self.map[name])
-        full[lo:lo + t.shape[0]] = t.numpy()
-        self.sys.set(self.map[name], full)
-        self.sys.set_count(self.count)
-
-    def cell_starts(self, idx):
-        cs = self.sys.get(self.O.F_CELLSTART_F)
-        return [int(cs[i]) for i in idx]
-
-    def columns(self, lo, hi, cell_length):
-        return torch.from_numpy(cell_column(self.read("pos", lo, hi).numpy()[:, 0], cell_length))
-
-    def to_device(self, arr):
-        return torch.as_tensor(arr)
 
 
 # ------------------------------------------------------------------------------------ the driver
@@ -357,13 +299,14 @@ class SlabDriver:
         send_r = e.read(name, c2, c3) if self.nb.right is not None else None
         recv_l = e.read(name, 0, c0) if self.nb.left is not None else None
         recv_r = e.read(name, c3, c4) if self.nb.right is not None else None
-        if isinstance(e, OracleSlabEngine):
+        copies = not getattr(e, "zero_copy", False)      # engines whose read() returns copies need a write-back
+        if copies:
             if recv_l is not None:
                 recv_l = torch.empty_like(recv_l)
             if recv_r is not None:
                 recv_r = torch.empty_like(recv_r)
         self.nb.exchange(send_l, send_r, recv_l, recv_r)
-        if isinstance(e, OracleSlabEngine):
+        if copies:
             if recv_l is not None and recv_l.numel():
                 e.write(name, 0, recv_l)
             if recv_r is not None and recv_r.numel():
@@ -477,7 +420,7 @@ def build_slab(make_engine, scene_params, fluid, boundary_sorted, boundary_mass,
     """cuts the global scene into `world` x-slabs and creates this rank's engine + driver.
     `boundary_sorted`/`boundary_mass`: the GLOBAL boundary set in cell-sorted order with its masses
     (computed by a whole-domain boundary-only system, SPHSystem.cu:69-71).  `make_engine(params,
-    cap, bpos, bmass)` returns a HipSlabEngine or an OracleSlabEngine."""
+    cap, bpos, bmass)` returns the engine (HipSlabEngine; the CPU tests plug in a stand-in with the same interface)."""
     P = scene_params
     gx, gy, gz = P.cells[0], P.cells[1], P.cells[2]
     cl = P.cell_length

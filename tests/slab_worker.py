@@ -7,6 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def configure(P, E, solver, adaptive):
@@ -40,6 +41,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group(backend, rank=rank, world_size=world)
     import multi_gpu as M
+    from slab_cpu_engine import OracleSlabEngine
     if engine_kind == "oracle":
         from oracle import oracle as E
         E.lib().oracle_set_threads(min(E.lib().oracle_max_threads(), 4))     # several ranks share the host
@@ -56,7 +58,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
     bpos, bmass = bsys.get(E.F_BPOS), bsys.get(E.F_BMASS)
     bsys.close()
     if engine_kind == "oracle":
-        make = lambda Pl, cap, bp, bm: M.OracleSlabEngine(E, Pl, cap, bp, bm)
+        make = lambda Pl, cap, bp, bm: OracleSlabEngine(E, Pl, cap, bp, bm)
     else:
         dev = torch.device("cuda", 0)
         make = lambda Pl, cap, bp, bm: M.HipSlabEngine(E, Pl, cap, bp, bm, dev)

@@ -15,6 +15,7 @@ def worker(rank, world, prt, kind, nx, steps, outdir, seed):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(prt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import multi_gpu as M
+    from slab_cpu_engine import OracleSlabEngine
     import slab_worker
     if kind == "oracle":
         from oracle import oracle as E
@@ -27,7 +28,7 @@ def worker(rank, world, prt, kind, nx, steps, outdir, seed):
     bsys = E.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
     bpos, bmass = bsys.get(E.F_BPOS), bsys.get(E.F_BMASS); bsys.close()
     if kind == "oracle":
-        make = lambda Pl, cap, bp, bm: M.OracleSlabEngine(E, Pl, cap, bp, bm)
+        make = lambda Pl, cap, bp, bm: OracleSlabEngine(E, Pl, cap, bp, bm)
     else:
         make = lambda Pl, cap, bp, bm: M.HipSlabEngine(E, Pl, cap, bp, bm, torch.device("cuda", 0))
     drv, cuts, counts = M.build_slab(make, P, pos, bpos, bmass, rank, world, capacity_factor=2.0, velocity=vel)
