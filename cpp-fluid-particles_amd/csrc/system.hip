@@ -73,11 +73,14 @@ struct StepGraph {
     hipGraphExec_t exec = nullptr;
     bool tried = false;
     long stepsRun = 0;       // eager steps so far (lazy allocations happen in the first one)
-    ~StepGraph()
+    unsigned int capturedCount = 0;   // active fluid particles the captured launches were sized for
+    void drop()
     {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr; tried = false;
     }
+    ~StepGraph() { drop(); }
 };
 
 }  // namespace sphx
@@ -433,8 +436,11 @@ float SPHSystem::stepN(int n)
     float extra = 0.0f;
     if (_graph->stepsRun == 0) { extra = step(); --n; if (n == 0) return extra; }
     const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
+    // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
+    if (_graph->tried && _graph->capturedCount != _fluids->size()) _graph->drop();
     if (wantGraph && !_graph->exec && !_graph->tried) {
         _graph->tried = true;
+        _graph->capturedCount = _fluids->size();
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             try { enqueueStep(); } catch (...) { ok = false; }
