@@ -76,7 +76,7 @@ def read_traffic(workload_key):
     try:
         with open(path) as f:
             entry = json.load(f).get(workload_key)
-            return entry["hbm_bytes_per_launch"] if entry else None
+            return entry["hbm_bytes_per_launch"] if entry else None      # provenance: "source" / "measured_on" in that file
     except Exception:
         return None
 
