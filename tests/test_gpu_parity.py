@@ -126,7 +126,7 @@ def test_trajectory_bit_exact_disordered(sphx, oracle, solver):
 
 
 @pytest.mark.parametrize("solver", [0, 1, 2])
-@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (3, None), (4, None), (5, None), (0, "8"), (1, "20"), (4, "8")])
+@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (4, None), (5, None), (0, "8"), (4, "8")])
 def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
     """the fused/unfused schedules (bit 0), the neighbour-list vs direct 27-cell walks (bit 1), the
     LDS-staged tiles vs global gathers (bit 2 = on) and the per-lane overflow fallback of the list (tiny

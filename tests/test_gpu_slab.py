@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,solver,adaptive", [(1, "dfsph", False), (2, "dfsph", False), (3, "dfsph", False),
-                                                   (2, "wcsph", False), (2, "dfsph", True), (1, "pbd", False),
-                                                   (2, "pbd", False), (3, "pbd", False)])
+                                                   (2, "wcsph", False), (2, "dfsph", True), (2, "pbd", False),
+                                                   (3, "pbd", False)])
 def test_hip_slab_driver_matches_single_domain_oracle(oracle, tmp_path, world, solver, adaptive):
     import torch.multiprocessing as mp
     nx, steps, seed = 12, 6, 17
