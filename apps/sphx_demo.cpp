@@ -3,8 +3,12 @@
 // construction, one step per "frame" with the running-average report).  What the reference does in
 // src/main.cpp:54-135 and :300-306, without the GLUT/GL parts.
 //
-//   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--dump file.bin]
+//   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--restart-with wcsph|dfsph|pbd] [--dump file.bin]
 //
+// --restart-with re-initialises the whole scene with another solver after the first run, in the same
+// process — what the reference's keys '1' '2' '3' do (src/main.cpp:225-239 -> initSPHSystem).
+// Status: added after the round's GPU budget was spent; compiles and links, NOT yet run on a GPU.
+// tests/test_gpu_parity.py::test_cpp_api_driver_matches_oracle covers the default path only.
 // --dump writes n, then pos[n*3], density[n] (cell-sorted order) for the parity test.
 #include <hip/hip_runtime.h>
 
@@ -29,13 +33,17 @@ namespace fluid_solver { enum { SPH, DFSPH, PBD }; }
 
 int main(int argc, char** argv)
 {
-    int solverKind = fluid_solver::PBD, nx = 24, steps = 100;
+    int solverKind = fluid_solver::PBD, nx = 24, steps = 100, restartKind = -1;
     std::string dump;
+    auto parseSolver = [](const std::string& v) {
+        return v == "wcsph" ? (int)fluid_solver::SPH : v == "dfsph" ? (int)fluid_solver::DFSPH : (int)fluid_solver::PBD;
+    };
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
         if (k == "--solver" && a + 1 < argc) {
-            const std::string v = argv[++a];
-            solverKind = v == "wcsph" ? fluid_solver::SPH : v == "dfsph" ? fluid_solver::DFSPH : fluid_solver::PBD;
+            solverKind = parseSolver(argv[++a]);
+        } else if (k == "--restart-with" && a + 1 < argc) {
+            restartKind = parseSolver(argv[++a]);
         } else if (k == "--nx" && a + 1 < argc) nx = atoi(argv[++a]);
         else if (k == "--steps" && a + 1 < argc) steps = atoi(argv[++a]);
         else if (k == "--dump" && a + 1 < argc) dump = argv[++a];
@@ -64,6 +72,8 @@ int main(int argc, char** argv)
     const int3 cellSize = make_int3((int)ceilf(spaceSize.x / sphCellLength), (int)ceilf(spaceSize.y / sphCellLength),
                                     (int)ceilf(spaceSize.z / sphCellLength));
 
+    // initSPHSystem(solver), src/main.cpp:73-135: particles, solver and system are rebuilt from scratch
+    auto initSPHSystem = [&](const int kind) -> std::shared_ptr<SPHSystem> {
     // fluid block
     std::vector<float3> pos;
     const float3 origin = make_float3(0.27f * scale, 0.10f * scale, 0.27f * scale);
@@ -88,7 +98,7 @@ int main(int argc, char** argv)
     auto boundaryParticles = std::make_shared<SPHParticles>(pos);
 
     std::shared_ptr<BaseSolver> pSolver;
-    switch (solverKind) {
+    switch (kind) {
     case fluid_solver::PBD: pSolver = std::make_shared<PBDSolver>(fluidParticles->size()); break;
     case fluid_solver::DFSPH: pSolver = std::make_shared<DFSPHSolver>(fluidParticles->size()); break;
     default: pSolver = std::make_shared<BasicSPHSolver>(fluidParticles->size()); break;
@@ -98,14 +108,27 @@ int main(int argc, char** argv)
                                                sphSurfaceTensionIntensity, sphAirPressure, sphG, cellSize);
     printf("particles: %d fluid + %d boundary, grid %dx%dx%d\n", pSystem->fluidSize(), pSystem->boundarySize(), cellSize.x,
            cellSize.y, cellSize.z);
+    return pSystem;
+    };
 
-    float totalTime = 0.0f;
-    for (int frameId = 1; frameId <= steps; ++frameId) {
-        const float milliseconds = pSystem->step();
-        totalTime += milliseconds;
-        if (frameId % 10 == 0 || frameId == steps)
-            printf("Frame %d - %2.2f ms, avg time - %2.2f ms/frame (%3.2f FPS)\n", frameId, milliseconds,
-                   totalTime / float(frameId), float(frameId) * 1000.0f / totalTime);
+    // oneStep() + the running report of src/main.cpp:300-306
+    auto run = [&](const std::shared_ptr<SPHSystem>& system) {
+        float totalTime = 0.0f;
+        for (int frameId = 1; frameId <= steps; ++frameId) {
+            const float milliseconds = system->step();
+            totalTime += milliseconds;
+            if (frameId % 10 == 0 || frameId == steps)
+                printf("Frame %d - %2.2f ms, avg time - %2.2f ms/frame (%3.2f FPS)\n", frameId, milliseconds,
+                       totalTime / float(frameId), float(frameId) * 1000.0f / totalTime);
+        }
+    };
+
+    auto pSystem = initSPHSystem(solverKind);
+    run(pSystem);
+    if (restartKind >= 0) {
+        pSystem.reset();
+        pSystem = initSPHSystem(restartKind);
+        run(pSystem);
     }
 
     if (!dump.empty()) {
