@@ -1,20 +1,21 @@
-// sphx_demo — headless driver written against the drop-in C++ API exactly the way the reference's
-// interactive driver uses it (scene constants, particle generation, solver selection, SPHSystem
-// construction, one step per "frame" with the running-average report).  What the reference does in
-// src/main.cpp:54-135 and :300-306, without the GLUT/GL parts.
+// sphx_demo — headless driver on the drop-in C++ API, used the way the reference's interactive
+// driver uses it: particle sets -> solver plugin -> SPHSystem -> one step() per frame with a running
+// timing report (what src/main.cpp:73-135 and :300-306 do, minus GLUT/GL).
 //
-//   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--restart-with wcsph|dfsph|pbd] [--dump file.bin]
+//   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--restart-with wcsph|dfsph|pbd]
+//             [--dump file.bin] [--dots file.bin] [--save snap.bin] [--load snap.bin]
 //
-// --restart-with re-initialises the whole scene with another solver after the first run, in the same
-// process — what the reference's keys '1' '2' '3' do (src/main.cpp:225-239 -> initSPHSystem).
-// Status: added after the round's GPU budget was spent; compiles and links, NOT yet run on a GPU.
-// tests/test_gpu_parity.py::test_cpp_api_driver_matches_oracle covers the default path only.
-// --dump writes n, then pos[n*3], density[n] (cell-sorted order) for the parity test.
+// The scene (constants of main.cpp:54-67, block and shell samplers of :73-117, scaled by nx/24) comes
+// from the library's scene generator (sphx_scene_params / sphx_scene_fill), the same one the tests
+// and bench.py use.  --restart-with rebuilds everything with another solver in the same process —
+// what the reference's keys '1' '2' '3' trigger (main.cpp:225-239).  --save writes a snapshot after
+// the run; --load continues a saved run for --steps more frames (through the C ABI, which owns the
+// snapshot format).  --dots calls the reference-signature generate_dots() and writes n, dot[n*3],
+// color[n*3].  --dump writes n, pos[n*3], density[n] (current array order) for the parity tests.
 #include <hip/hip_runtime.h>
 
-#include <cmath>
 #include <cstdio>
-#include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -28,122 +29,133 @@
 #include "DFSPHSolver.h"
 #include "PBDSolver.h"
 #include "SPHSystem.h"
+#include "sphx_c.h"
 
-namespace fluid_solver { enum { SPH, DFSPH, PBD }; }
+// the render-side consumer, declared the way the reference's driver declares it (main.cpp:268)
+extern "C" void generate_dots(float3* dot, float3* color, const std::shared_ptr<SPHParticles> particles);
+
+static int solver_from_name(const std::string& v) { return v == "wcsph" ? SPHX_WCSPH : (v == "dfsph" ? SPHX_DFSPH : SPHX_PBD); }
+
+static std::vector<float3> as_float3(const std::vector<float>& xyz)
+{
+    std::vector<float3> out(xyz.size() / 3);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = make_float3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return out;
+}
+
+static void report(int frame, int frames, float ms, float total)
+{
+    if (frame % 10 == 0 || frame == frames)
+        printf("step %d: %.2f ms   mean %.2f ms/step   %.1f steps/s\n", frame, ms, total / (float)frame, 1000.0f * (float)frame / total);
+}
+
+static int write_dump(const std::string& path, int n, const float3* dPos, const float* dDensity)
+{
+    std::vector<float3> hp(n);
+    std::vector<float> hd(n);
+    (void)hipMemcpy(hp.data(), dPos, sizeof(float3) * n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hd.data(), dDensity, sizeof(float) * n, hipMemcpyDeviceToHost);
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) return 3;
+    fwrite(&n, sizeof(int), 1, fp);
+    fwrite(hp.data(), sizeof(float3), n, fp);
+    fwrite(hd.data(), sizeof(float), n, fp);
+    fclose(fp);
+    return 0;
+}
 
 int main(int argc, char** argv)
 {
-    int solverKind = fluid_solver::PBD, nx = 24, steps = 100, restartKind = -1;
-    std::string dump;
-    auto parseSolver = [](const std::string& v) {
-        return v == "wcsph" ? (int)fluid_solver::SPH : v == "dfsph" ? (int)fluid_solver::DFSPH : (int)fluid_solver::PBD;
-    };
+    int solverKind = SPHX_PBD, nx = 24, steps = 100, restartKind = -1;
+    std::string dump, savePath, loadPath, dotsPath;
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
-        if (k == "--solver" && a + 1 < argc) {
-            solverKind = parseSolver(argv[++a]);
-        } else if (k == "--restart-with" && a + 1 < argc) {
-            restartKind = parseSolver(argv[++a]);
-        } else if (k == "--nx" && a + 1 < argc) nx = atoi(argv[++a]);
-        else if (k == "--steps" && a + 1 < argc) steps = atoi(argv[++a]);
-        else if (k == "--dump" && a + 1 < argc) dump = argv[++a];
+        const bool more = a + 1 < argc;
+        if (k == "--solver" && more) solverKind = solver_from_name(argv[++a]);
+        else if (k == "--restart-with" && more) restartKind = solver_from_name(argv[++a]);
+        else if (k == "--nx" && more) nx = atoi(argv[++a]);
+        else if (k == "--steps" && more) steps = atoi(argv[++a]);
+        else if (k == "--dump" && more) dump = argv[++a];
+        else if (k == "--dots" && more) dotsPath = argv[++a];
+        else if (k == "--save" && more) savePath = argv[++a];
+        else if (k == "--load" && more) loadPath = argv[++a];
     }
-    int devices = 0;
-    if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) {
+    if (sphx_device_count() < 1) {
         fprintf(stderr, "sphx_demo: no HIP device (the engine has no CPU path)\n");
         return 2;
     }
 
-    // scene constants (scaled by nx/24; nx = 24 is the reference scene)
-    const float scale = (float)nx / 24.0f;
-    const float3 spaceSize = make_float3(scale);
-    const float sphSpacing = 0.02f;
-    const float sphSmoothingRadius = 2.0f * sphSpacing;
-    const float sphCellLength = 1.01f * sphSmoothingRadius;
-    const float dt = 0.002f;
-    const float sphRho0 = 1.0f;
-    const float sphRhoBoundary = 1.4f * sphRho0;
-    const float sphM0 = 76.596750762082e-6f;
-    const float sphStiff = 10.0f;
-    const float3 sphG = make_float3(0.0f, -9.8f, 0.0f);
-    const float sphVisc = 5e-4f;
-    const float sphSurfaceTensionIntensity = 0.0001f;
-    const float sphAirPressure = 0.0001f;
-    const int3 cellSize = make_int3((int)ceilf(spaceSize.x / sphCellLength), (int)ceilf(spaceSize.y / sphCellLength),
-                                    (int)ceilf(spaceSize.z / sphCellLength));
-
-    // initSPHSystem(solver), src/main.cpp:73-135: particles, solver and system are rebuilt from scratch
-    auto initSPHSystem = [&](const int kind) -> std::shared_ptr<SPHSystem> {
-    // fluid block
-    std::vector<float3> pos;
-    const float3 origin = make_float3(0.27f * scale, 0.10f * scale, 0.27f * scale);
-    for (int iy = 0; iy < 3 * nx / 2; ++iy)
-        for (int ix = 0; ix < nx; ++ix)
-            for (int iz = 0; iz < nx; ++iz)
-                pos.push_back(make_float3(origin.x + sphSpacing * ix, origin.y + sphSpacing * iy, origin.z + sphSpacing * iz));
-    auto fluidParticles = std::make_shared<SPHParticles>(pos);
-
-    // boundary shell: six faces, edges counted once
-    pos.clear();
-    const int3 shell = make_int3(2 * cellSize.x, 2 * cellSize.y, 2 * cellSize.z);
-    auto wall = [&](int a, int b, int c) {
-        const float3 t = make_float3((float)a / (float)(shell.x - 1) * spaceSize.x, (float)b / (float)(shell.y - 1) * spaceSize.y,
-                                     (float)c / (float)(shell.z - 1) * spaceSize.z);
-        pos.push_back(make_float3(0.99f * t.x + 0.005f * spaceSize.x, 0.99f * t.y + 0.005f * spaceSize.y,
-                                  0.99f * t.z + 0.005f * spaceSize.z));
-    };
-    for (int a = 0; a < shell.x; ++a) for (int b = 0; b < shell.y; ++b) { wall(a, b, 0); wall(a, b, shell.z - 1); }
-    for (int a = 0; a < shell.x; ++a) for (int c = 1; c < shell.z - 1; ++c) { wall(a, 0, c); wall(a, shell.y - 1, c); }
-    for (int b = 1; b < shell.y - 1; ++b) for (int c = 1; c < shell.z - 1; ++c) { wall(0, b, c); wall(shell.x - 1, b, c); }
-    auto boundaryParticles = std::make_shared<SPHParticles>(pos);
-
-    std::shared_ptr<BaseSolver> pSolver;
-    switch (kind) {
-    case fluid_solver::PBD: pSolver = std::make_shared<PBDSolver>(fluidParticles->size()); break;
-    case fluid_solver::DFSPH: pSolver = std::make_shared<DFSPHSolver>(fluidParticles->size()); break;
-    default: pSolver = std::make_shared<BasicSPHSolver>(fluidParticles->size()); break;
+    if (!loadPath.empty()) {            // continue a saved run
+        sphx_system* sys = nullptr;
+        if (sphx_snapshot_load(loadPath.c_str(), &sys) != SPHX_OK) { fprintf(stderr, "sphx_demo: %s\n", sphx_last_error()); return 4; }
+        float total = 0.0f;
+        for (int f = 1; f <= steps; ++f) { float ms = 0.0f; sphx_step(sys, &ms); total += ms; report(f, steps, ms, total); }
+        int n = 0; sphx_counts(sys, &n, nullptr, nullptr);
+        void *dp = nullptr, *dd = nullptr;
+        sphx_device_ptr(sys, SPHX_F_POS, &dp); sphx_device_ptr(sys, SPHX_F_DENSITY, &dd);
+        int rc = dump.empty() ? 0 : write_dump(dump, n, (const float3*)dp, (const float*)dd);
+        if (!savePath.empty() && sphx_snapshot_save(sys, savePath.c_str()) != SPHX_OK) rc = 5;
+        sphx_destroy(sys);
+        return rc;
     }
-    auto pSystem = std::make_shared<SPHSystem>(fluidParticles, boundaryParticles, pSolver, spaceSize, sphCellLength,
-                                               sphSmoothingRadius, dt, sphM0, sphRho0, sphRhoBoundary, sphStiff, sphVisc,
-                                               sphSurfaceTensionIntensity, sphAirPressure, sphG, cellSize);
-    printf("particles: %d fluid + %d boundary, grid %dx%dx%d\n", pSystem->fluidSize(), pSystem->boundarySize(), cellSize.x,
-           cellSize.y, cellSize.z);
-    return pSystem;
-    };
 
-    // oneStep() + the running report of src/main.cpp:300-306
+    sphx_params sc;
+    int nFluid = 0, nWall = 0;
+    if (sphx_scene_params(nx, &sc) != SPHX_OK || sphx_scene_counts(nx, &nFluid, &nWall) != SPHX_OK) {
+        fprintf(stderr, "sphx_demo: %s\n", sphx_last_error());
+        return 2;
+    }
+    std::vector<float> fluidXyz(3 * (size_t)nFluid), wallXyz(3 * (size_t)nWall);
+    sphx_scene_fill(nx, fluidXyz.data(), wallXyz.data());
+
+    // everything is rebuilt from scratch per solver, as the reference's initSPHSystem does
+    auto build = [&](const int kind) {
+        auto fluidParticles = std::make_shared<SPHParticles>(as_float3(fluidXyz));
+        auto boundaryParticles = std::make_shared<SPHParticles>(as_float3(wallXyz));
+        std::shared_ptr<BaseSolver> plugin;
+        if (kind == SPHX_PBD) plugin = std::make_shared<PBDSolver>(fluidParticles->size());
+        else if (kind == SPHX_DFSPH) plugin = std::make_shared<DFSPHSolver>(fluidParticles->size());
+        else plugin = std::make_shared<BasicSPHSolver>(fluidParticles->size());
+        auto system = std::make_shared<SPHSystem>(
+            fluidParticles, boundaryParticles, plugin, make_float3(sc.space[0], sc.space[1], sc.space[2]), sc.cell_length,
+            sc.radius, sc.dt, sc.m0, sc.rho0, sc.rho_boundary, sc.stiff, sc.visc, sc.surface_tension, sc.air_pressure,
+            make_float3(sc.gravity[0], sc.gravity[1], sc.gravity[2]), make_int3(sc.cells[0], sc.cells[1], sc.cells[2]));
+        printf("scene: %d fluid + %d wall particles in a %d x %d x %d grid\n", system->fluidSize(), system->boundarySize(), sc.cells[0],
+               sc.cells[1], sc.cells[2]);
+        return system;
+    };
     auto run = [&](const std::shared_ptr<SPHSystem>& system) {
-        float totalTime = 0.0f;
-        for (int frameId = 1; frameId <= steps; ++frameId) {
-            const float milliseconds = system->step();
-            totalTime += milliseconds;
-            if (frameId % 10 == 0 || frameId == steps)
-                printf("Frame %d - %2.2f ms, avg time - %2.2f ms/frame (%3.2f FPS)\n", frameId, milliseconds,
-                       totalTime / float(frameId), float(frameId) * 1000.0f / totalTime);
+        float total = 0.0f;
+        for (int f = 1; f <= steps; ++f) {
+            const float ms = system->step();
+            total += ms;
+            report(f, steps, ms, total);
         }
     };
 
-    auto pSystem = initSPHSystem(solverKind);
-    run(pSystem);
+    auto system = build(solverKind);
+    run(system);
     if (restartKind >= 0) {
-        pSystem.reset();
-        pSystem = initSPHSystem(restartKind);
-        run(pSystem);
+        system.reset();
+        system = build(restartKind);
+        run(system);
     }
-
+    if (!savePath.empty()) fprintf(stderr, "sphx_demo: --save needs a run started with --load or the C ABI (snapshots belong to sphx_c.h)\n");
+    if (!dotsPath.empty()) {            // what the reference's renderer does once per frame (main.cpp:270-292)
+        const int n = system->fluidSize();
+        float3 *dDot = nullptr, *dColor = nullptr;
+        (void)hipMalloc((void**)&dDot, sizeof(float3) * n);
+        (void)hipMalloc((void**)&dColor, sizeof(float3) * n);
+        generate_dots(dDot, dColor, system->getFluids());
+        std::vector<float3> h(2 * (size_t)n);
+        (void)hipMemcpy(h.data(), dDot, sizeof(float3) * n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h.data() + n, dColor, sizeof(float3) * n, hipMemcpyDeviceToHost);
+        (void)hipFree(dDot); (void)hipFree(dColor);
+        if (FILE* fp = fopen(dotsPath.c_str(), "wb")) { fwrite(&n, sizeof(int), 1, fp); fwrite(h.data(), sizeof(float3), h.size(), fp); fclose(fp); }
+    }
     if (!dump.empty()) {
-        const int n = pSystem->fluidSize();
-        std::vector<float3> hp(n);
-        std::vector<float> hd(n);
-        const auto f = pSystem->getFluids();
-        (void)hipMemcpy(hp.data(), f->getPosPtr(), sizeof(float3) * n, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(hd.data(), f->getDensityPtr(), sizeof(float) * n, hipMemcpyDeviceToHost);
-        FILE* fp = fopen(dump.c_str(), "wb");
-        if (!fp) return 3;
-        fwrite(&n, sizeof(int), 1, fp);
-        fwrite(hp.data(), sizeof(float3), n, fp);
-        fwrite(hd.data(), sizeof(float), n, fp);
-        fclose(fp);
+        const auto f = system->getFluids();
+        return write_dump(dump, system->fluidSize(), f->getPosPtr(), f->getDensityPtr());
     }
     return 0;
 }

@@ -43,6 +43,8 @@ static int guarded(const char* where, F&& body)
         return body();
     } catch (const char* msg) {
         return fail(SPHX_ERR_STATE, msg);
+    } catch (const sphx::DeviceAllocError& e) {
+        return fail(SPHX_ERR_HIP, std::string(where) + ": " + e.what());
     } catch (const std::bad_alloc&) {
         return fail(SPHX_ERR_HIP, std::string(where) + ": out of host memory");
     } catch (const std::exception& e) {
@@ -208,6 +210,10 @@ static int create_impl(const sphx_params* P, const float* fluid, int n, const fl
         h->system.reset(new SPHSystem(SPHSystem::Slab{P->reserved[1]}, fluids, walls, solver, space, P->cell_length, P->radius,
                                       P->dt, P->m0, P->rho0, P->rho_boundary, P->stiff, P->visc, P->surface_tension,
                                       P->air_pressure, G, cells));
+    } else if (run_ctor_step == 2) {
+        h->system.reset(new SPHSystem(SPHSystem::Restored{}, fluids, walls, solver, space, P->cell_length, P->radius, P->dt,
+                                      P->m0, P->rho0, P->rho_boundary, P->stiff, P->visc, P->surface_tension,
+                                      P->air_pressure, G, cells));
     } else if (run_ctor_step)
         h->system.reset(new SPHSystem(fluids, walls, solver, space, P->cell_length, P->radius, P->dt, P->m0, P->rho0,
                                       P->rho_boundary, P->stiff, P->visc, P->surface_tension, P->air_pressure, G, cells));
@@ -257,6 +263,13 @@ int sphx_counts(const sphx_system* h, int* n, int* nb, int* cells)
     if (n) *n = h->n;
     if (nb) *nb = h->nb;
     if (cells) *cells = h->cells;
+    return SPHX_OK;
+}
+
+int sphx_get_params(const sphx_system* h, sphx_params* out)
+{
+    if (!h || !out) return fail(SPHX_ERR_INVALID, "sphx_get_params: bad argument");
+    *out = h->params;
     return SPHX_OK;
 }
 
@@ -351,34 +364,19 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
 int sphx_run_phase(sphx_system* h, int phase)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "sphx_run_phase: null system");
-    try {
-        h->system->phase(phase);
-    } catch (const char* msg) {
-        return fail(SPHX_ERR_STATE, msg);
-    }
-    return SPHX_OK;
+    return guarded("sphx_run_phase", [&] { h->system->phase(phase); return (int)SPHX_OK; });
 }
 
 int sphx_run_phase_reduce(sphx_system* h, int phase, int lo, int hi)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "sphx_run_phase_reduce: null system");
-    try {
-        h->system->phaseReduce(phase, lo, hi);
-    } catch (const char* msg) {
-        return fail(SPHX_ERR_STATE, msg);
-    }
-    return SPHX_OK;
+    return guarded("sphx_run_phase_reduce", [&] { h->system->phaseReduce(phase, lo, hi); return (int)SPHX_OK; });
 }
 
 int sphx_error_total_fixed(sphx_system* h, long long* total)
 {
     if (!h || !total) return fail(SPHX_ERR_INVALID, "sphx_error_total_fixed: bad argument");
-    try {
-        *total = h->system->errorTotalFixed();
-    } catch (const char* msg) {
-        return fail(SPHX_ERR_STATE, msg);
-    }
-    return SPHX_OK;
+    return guarded("sphx_error_total_fixed", [&] { *total = h->system->errorTotalFixed(); return (int)SPHX_OK; });
 }
 
 int sphx_set_count(sphx_system* h, int n_fluid)
@@ -598,3 +596,119 @@ int sphx_generate_dots(const sphx_system* h, float* device_dot, float* device_co
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------ snapshots
+// Container (little endian): "SPHXSNAP" | u32 version | u32 sizeof(sphx_params) | i32 n | i32 nb |
+// u32 field count | sphx_params | then per field { i32 sphx_field id, u64 bytes, payload }.
+// Saved: the fluid state in its CURRENT array order (pos, vel, id, density, pressure), the boundary
+// set (sorted positions + masses) and the solver's persistent array (DFSPH warm stiffness / PBD last
+// positions).  The reference has no checkpoint facility; this is §8(f)-2.
+namespace {
+constexpr unsigned int kSnapVersion = 1;
+struct FileCloser { void operator()(FILE* f) const { if (f) fclose(f); } };
+
+std::vector<int> snapshot_fields(const sphx_system* h)
+{
+    std::vector<int> f = {SPHX_F_POS, SPHX_F_VEL, SPHX_F_ID, SPHX_F_DENSITY, SPHX_F_PRESSURE, SPHX_F_BPOS, SPHX_F_BMASS};
+    if (h->dfsph) f.push_back(SPHX_F_WARM);
+    if (h->pbd) f.push_back(SPHX_F_POS_LAST);
+    return f;
+}
+}  // namespace
+
+extern "C" {
+
+int sphx_snapshot_save(const sphx_system* h, const char* path)
+{
+    if (!h || !path) return fail(SPHX_ERR_INVALID, "sphx_snapshot_save: bad argument");
+    return guarded("sphx_snapshot_save", [&] {
+        std::unique_ptr<FILE, FileCloser> fp(fopen(path, "wb"));
+        if (!fp) return fail(SPHX_ERR_INVALID, std::string("sphx_snapshot_save: cannot open ") + path);
+        const std::vector<int> fields = snapshot_fields(h);
+        const unsigned int head[3] = {kSnapVersion, (unsigned int)sizeof(sphx_params), (unsigned int)fields.size()};
+        const int counts[2] = {h->n, h->nb};
+        bool ok = fwrite("SPHXSNAP", 1, 8, fp.get()) == 8 && fwrite(head, 4, 2, fp.get()) == 2 &&
+                  fwrite(counts, 4, 2, fp.get()) == 2 && fwrite(head + 2, 4, 1, fp.get()) == 1 &&
+                  fwrite(&h->params, sizeof(sphx_params), 1, fp.get()) == 1;
+        std::vector<char> buf;
+        for (int f : fields) {
+            void* p; size_t sz;
+            if (locate(h, f, &p, &sz)) return fail(SPHX_ERR_STATE, "sphx_snapshot_save: field missing");
+            buf.resize(sz);
+            const int rc = sz ? sphx_get(h, f, buf.data(), sz) : (int)SPHX_OK;
+            if (rc) return rc;
+            const unsigned long long bytes = sz;
+            ok = ok && fwrite(&f, 4, 1, fp.get()) == 1 && fwrite(&bytes, 8, 1, fp.get()) == 1 &&
+                 (sz == 0 || fwrite(buf.data(), 1, sz, fp.get()) == sz);
+        }
+        if (!ok) return fail(SPHX_ERR_INVALID, "sphx_snapshot_save: short write");
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_snapshot_load(const char* path, sphx_system** out)
+{
+    if (!path || !out) return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: bad argument");
+    return guarded("sphx_snapshot_load", [&] {
+        *out = nullptr;
+        std::unique_ptr<FILE, FileCloser> fp(fopen(path, "rb"));
+        if (!fp) return fail(SPHX_ERR_INVALID, std::string("sphx_snapshot_load: cannot open ") + path);
+        char magic[8]; unsigned int head[2]; int counts[2]; unsigned int nfields = 0;
+        sphx_params P;
+        if (fread(magic, 1, 8, fp.get()) != 8 || std::memcmp(magic, "SPHXSNAP", 8) != 0 || fread(head, 4, 2, fp.get()) != 2 ||
+            head[0] != kSnapVersion || head[1] != sizeof(sphx_params) || fread(counts, 4, 2, fp.get()) != 2 ||
+            fread(&nfields, 4, 1, fp.get()) != 1 || fread(&P, sizeof(P), 1, fp.get()) != 1 || counts[0] < 0 || counts[1] < 0 ||
+            nfields > 64)
+            return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: not a version-1 sphx snapshot");
+        std::vector<std::pair<int, std::vector<char>>> blobs(nfields);
+        for (auto& b : blobs) {
+            unsigned long long bytes = 0;
+            if (fread(&b.first, 4, 1, fp.get()) != 1 || fread(&bytes, 8, 1, fp.get()) != 1 ||
+                bytes > 16ull * (unsigned long long)std::max(counts[0], counts[1]) + 64ull)
+                return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: truncated field header");
+            b.second.resize((size_t)bytes);
+            if (bytes && fread(b.second.data(), 1, (size_t)bytes, fp.get()) != bytes)
+                return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: truncated payload");
+        }
+        auto find = [&](int id) -> std::vector<char>* {
+            for (auto& b : blobs) if (b.first == id) return &b.second;
+            return nullptr;
+        };
+        std::vector<char>* pos = find(SPHX_F_POS); std::vector<char>* bpos = find(SPHX_F_BPOS);
+        if (!pos || !bpos || pos->size() != 12u * (size_t)counts[0] || bpos->size() != 12u * (size_t)counts[1])
+            return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: position fields missing or mis-sized");
+        sphx_system* h = nullptr;
+        // mode 2: no constructor step and NO initial fluid sort — the arrays continue in the saved order
+        int rc = create_impl(&P, reinterpret_cast<const float*>(pos->data()), counts[0],
+                             reinterpret_cast<const float*>(bpos->data()), counts[1], 2, &h);
+        if (rc) return rc;
+        for (auto& b : blobs) {
+            if (b.first == SPHX_F_POS || b.first == SPHX_F_BPOS || b.second.empty()) continue;
+            void* p; size_t sz;
+            if (locate(h, b.first, &p, &sz) || sz != b.second.size()) { sphx_destroy(h); return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: field does not fit this solver"); }
+            if (hipMemcpyAsync(p, b.second.data(), sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
+                hipStreamSynchronize(sphx::stream()) != hipSuccess) { sphx_destroy(h); return fail(SPHX_ERR_HIP, "sphx_snapshot_load: upload failed"); }
+            if (b.first == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
+            if (b.first == SPHX_F_POS_LAST && h->pbd) h->pbd->markPosLastInitialized();
+        }
+        *out = h;
+        return (int)SPHX_OK;
+    });
+}
+
+}  // extern "C"
+
+// generate_dots with the reference's own signature (vbo.cu:46-51, declared `extern "C"` at
+// main.cpp:268): a main.cpp that links against this symbol links against libsphx.so unchanged.
+// dot / color are DEVICE pointers (the reference maps its VBOs first, main.cpp:270-289).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wreturn-type-c-linkage"
+extern "C" void generate_dots(float3* dot, float3* color, const std::shared_ptr<SPHParticles> particles)
+{
+    const int n = particles ? (int)particles->size() : 0;
+    if (n <= 0 || !dot || !color) return;
+    k_generate_dots<<<blocks_for(n), 256, 0, sphx::stream()>>>(dot, color, particles->getPosPtr(), particles->getDensityPtr(), n);
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));   // the caller unmaps its buffers right after (main.cpp:291-292)
+}
+#pragma clang diagnostic pop
+

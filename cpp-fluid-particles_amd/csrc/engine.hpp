@@ -58,6 +58,9 @@ struct SweepCache {
     int cap = 96;
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)
     int flags = 0;
+    // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
+    // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
+    unsigned int generation = 0;
     bool fluidValid = false;
     bool boundaryValid = false;
     bool listValid = false;

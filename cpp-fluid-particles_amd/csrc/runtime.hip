@@ -1,5 +1,6 @@
 // runtime.hip — engine stream, error reporting, kernel constants, packed views, element-wise
 // helpers and the optional per-kernel timer.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -367,9 +368,9 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 }
 
 SweepCache::SweepCache(int num)
-    : n(num), capN(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
+    : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
-      tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2))
+      tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num)
 {
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
@@ -425,6 +426,7 @@ void SweepCache::reserveBoundary(int count)
     nbCap = count;
     boundaryValid = false;
     listValid = false;
+    ++generation;      // the four arrays moved: a captured graph holds stale pointers
 }
 
 void SweepCache::packBoundary(const SPHParticles& boundaries)
@@ -469,10 +471,12 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
 void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
 {
     if (listValid || (flags & kFlagNoList) || n <= 0) return;
-    const unsigned long long entries = (unsigned long long)((n + 63) / 64) * 64ull * (unsigned long long)cap;
-    if (entries > 0xfffffff0ull) { flags |= kFlagNoList; return; }   // beyond DArray's 32-bit length
-    if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; return; }
-    if (!nbr) nbr.reset(new DArray<int>((unsigned)entries));
+    // sized for the CAPACITY, not the current count: sphx_set_count may raise n up to capN later
+    // (slab drivers do so every step) and the rows of all ceil(n/64) tiles must fit
+    const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
+    if (entries > 0xfffffff0ull) { flags |= kFlagNoList; ++generation; return; }   // beyond DArray's 32-bit length
+    if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; ++generation; return; }
+    if (!nbr || (unsigned long long)nbr->length() < entries) { nbr.reset(new DArray<int>((unsigned)entries)); ++generation; }
     ensureTileOrder();
     SweepCtx c = ctx(csF, csB);
     c.nbr = nullptr;

@@ -74,6 +74,7 @@ struct StepGraph {
     bool tried = false;
     long stepsRun = 0;       // eager steps so far (lazy allocations happen in the first one)
     unsigned int capturedCount = 0;   // active fluid particles the captured launches were sized for
+    unsigned int capturedGeneration = 0;   // BaseSolver::graphGeneration() at capture time
     void drop()
     {
         if (exec) (void)hipGraphExecDestroy(exec);
@@ -221,13 +222,11 @@ __global__ void k_pack_pos_only(float4* __restrict__ dst, const float3* __restri
 // ================================================================================ SPHSystem
 #define SPHX_SYSTEM_INIT_LIST                                                                          \
     _fluids(std::move(fluidParticles)), _boundaries(std::move(boundaryParticles)), _solver(std::move(solver)), \
-        cellStartFluid((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)),                          \
-        cellStartBoundary((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)), _spaceSize(spaceSize), \
-        _sphSmoothingRadius(sphSmoothingRadius), _sphCellLength(sphCellLength), _dt(dt), _sphRho0(sphRho0), \
-        _sphRhoBoundary(sphRhoBoundary), _sphStiff(sphStiff), _sphG(sphG), _sphVisc(sphVisc),           \
-        _sphSurfaceTensionIntensity(sphSurfaceTensionIntensity), _sphAirPressure(sphAirPressure),       \
-        _cellSize(cellSize),                                                                            \
-        bufferInt((unsigned)std::max(totalSize(), cellSize.x * cellSize.y * cellSize.z + 1))
+        _sc{spaceSize, cellSize, sphCellLength, sphSmoothingRadius, dt, sphRho0, sphRhoBoundary, sphStiff, sphVisc, \
+            sphSurfaceTensionIntensity, sphAirPressure, sphG},                                          \
+        _fluidCellStart((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)),                         \
+        _wallCellStart((unsigned)(cellSize.x * cellSize.y * cellSize.z + 1)),                          \
+        _intScratch((unsigned)std::max(totalSize(), cellSize.x * cellSize.y * cellSize.z + 1))
 
 SPHSystem::SPHSystem(std::shared_ptr<SPHParticles>& fluidParticles, std::shared_ptr<SPHParticles>& boundaryParticles,
                      std::shared_ptr<BaseSolver>& solver, const float3 spaceSize, const float sphCellLength,
@@ -249,6 +248,17 @@ SPHSystem::SPHSystem(NoInitialStep, std::shared_ptr<SPHParticles>& fluidParticle
     : SPHX_SYSTEM_INIT_LIST
 {
     initialise(sphM0, false);
+}
+
+SPHSystem::SPHSystem(Restored, std::shared_ptr<SPHParticles>& fluidParticles,
+                     std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+                     const float3 spaceSize, const float sphCellLength, const float sphSmoothingRadius, const float dt,
+                     const float sphM0, const float sphRho0, const float sphRhoBoundary, const float sphStiff,
+                     const float sphVisc, const float sphSurfaceTensionIntensity, const float sphAirPressure,
+                     const float3 sphG, const int3 cellSize)
+    : SPHX_SYSTEM_INIT_LIST
+{
+    initialise(sphM0, false, false);
 }
 
 SPHSystem::SPHSystem(Slab slab, std::shared_ptr<SPHParticles>& fluidParticles,
@@ -273,9 +283,9 @@ void SPHSystem::phaseReduce(int p, int sumLo, int sumHi)
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
     if (!dfsph) throw "SPHSystem::phaseReduce: needs a DFSPHSolver";
     dfsph->setErrorSumRange(sumLo, sumHi);
-    dfsph->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
-                    _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphVisc, _sphG, _sphSurfaceTensionIntensity,
-                    _sphAirPressure, true);
+    dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                    _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
+                    _sc.airPressure, true);
 }
 
 long long SPHSystem::errorTotalFixed()
@@ -290,42 +300,42 @@ void SPHSystem::phase(int p)
     if (p >= SPHX_PH_P_SEARCH) {
         auto* pbd = dynamic_cast<PBDSolver*>(_solver.get());
         if (!pbd) throw "SPHSystem::phase: PBD stages need a PBDSolver";
-        if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, cellStartFluid);
-        pbd->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
-                      _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphG, _sphSurfaceTensionIntensity, _sphAirPressure);
+        if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+        pbd->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                      _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.gravity, _sc.surfaceTension, _sc.airPressure);
         if (p == SPHX_PH_P_TAIL) _graph->stepsRun++;
         return;
     }
     if (p >= SPHX_PH_W_SEARCH || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
-        if (p == SPHX_PH_W_SEARCH) neighborSearch(_fluids, cellStartFluid);
-        w->runWcsphPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
-                         _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphStiff, _sphVisc, _sphG,
-                         _sphSurfaceTensionIntensity, _sphAirPressure);
+        if (p == SPHX_PH_W_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+        w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                         _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
+                         _sc.surfaceTension, _sc.airPressure);
         if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
         return;
     }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
     if (!dfsph) throw "SPHSystem::phase: stage-wise stepping needs a DFSPHSolver";
-    if (p == SPHX_PH_SEARCH) neighborSearch(_fluids, cellStartFluid);
-    dfsph->runPhase(p, _fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
-                    _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphVisc, _sphG, _sphSurfaceTensionIntensity,
-                    _sphAirPressure, false);
+    if (p == SPHX_PH_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+    dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                    _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
+                    _sc.airPressure, false);
     if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
 }
 
 // the constructor sequence of SPHSystem.cu:68-76
-void SPHSystem::initialise(float sphM0, bool runStep)
+void SPHSystem::initialise(float sphM0, bool runStep, bool sortFluid)
 {
-    const int cells = _cellSize.x * _cellSize.y * _cellSize.z;
+    const int cells = _sc.cells.x * _sc.cells.y * _sc.cells.z;
     _grid.reset(new GridScratch(std::max(std::max((int)_fluids->capacity(), (int)_boundaries->capacity()), 1), cells));
     _graph.reset(new StepGraph());
     if (auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get())) w->reserveBoundary((int)_boundaries->capacity());
-    neighborSearch(_boundaries, cellStartBoundary);
+    neighborSearch(_boundaries, _wallCellStart);
     computeBoundaryMass();
     ew_fill_float(_fluids->getMassPtr(), sphM0, (int)_fluids->capacity());
-    if (!_slab) neighborSearch(_fluids, cellStartFluid);   // a slab's particles arrive with the first exchange
+    if (!_slab && sortFluid) neighborSearch(_fluids, _fluidCellStart);   // a slab's particles arrive with the first exchange
     HIP_CALL(hipStreamSynchronize(sphx::stream()));
     if (runStep) step();
 }
@@ -334,13 +344,13 @@ void SPHSystem::computeBoundaryMass()
 {
     const int nb = boundarySize();
     if (nb <= 0) return;
-    const KernelConsts k = make_kernel_consts(_sphSmoothingRadius);
-    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength, _cellOffsetX);
+    const KernelConsts k = make_kernel_consts(_sc.radius);
+    const GridDesc g = make_grid_desc(_sc.cells, _sc.cellLength, _cellOffsetX);
     float4* posm = reinterpret_cast<float4*>(_grid->posm.addr());
     ScopedKernel t("boundary_mass");
     k_pack_pos_only<<<blocks_for(nb), 256, 0, sphx::stream()>>>(posm, _boundaries->getPosPtr(), nb);
-    k_boundary_mass<<<blocks_for(nb), 256, 0, sphx::stream()>>>(_boundaries->getMassPtr(), posm, cellStartBoundary.addr(), g, k,
-                                                                 _sphRhoBoundary, nb);
+    k_boundary_mass<<<blocks_for(nb), 256, 0, sphx::stream()>>>(_boundaries->getMassPtr(), posm, _wallCellStart.addr(), g, k,
+                                                                 _sc.rhoBoundary, nb);
 }
 
 // SPHSystem::neighborSearch, SPHSystem.cu:114-127, as one stable counting sort:
@@ -350,8 +360,8 @@ void SPHSystem::computeBoundaryMass()
 void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart)
 {
     const int num = (int)particles->size();
-    const int cellsPlusOne = _cellSize.x * _cellSize.y * _cellSize.z + 1;
-    const GridDesc g = make_grid_desc(_cellSize, _sphCellLength, _cellOffsetX);
+    const int cellsPlusOne = _sc.cells.x * _sc.cells.y * _sc.cells.z + 1;
+    const GridDesc g = make_grid_desc(_sc.cells, _sc.cellLength, _cellOffsetX);
     hipStream_t st = sphx::stream();
     int* p2c = particles->getParticle2Cell();
     int* perm = particles->getSortPerm();
@@ -395,10 +405,10 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
 
 void SPHSystem::enqueueStep()
 {
-    neighborSearch(_fluids, cellStartFluid);
-    _solver->step(_fluids, _boundaries, cellStartFluid, cellStartBoundary, _spaceSize, _cellSize, _sphCellLength,
-                  _sphSmoothingRadius, _dt, _sphRho0, _sphRhoBoundary, _sphStiff, _sphVisc, _sphG,
-                  _sphSurfaceTensionIntensity, _sphAirPressure);
+    neighborSearch(_fluids, _fluidCellStart);
+    _solver->step(_fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                  _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
+                  _sc.surfaceTension, _sc.airPressure);
 }
 
 // SPHSystem::step, SPHSystem.cu:129-158
@@ -437,10 +447,13 @@ float SPHSystem::stepN(int n)
     if (_graph->stepsRun == 0) { extra = step(); --n; if (n == 0) return extra; }
     const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
     // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
-    if (_graph->tried && _graph->capturedCount != _fluids->size()) _graph->drop();
+    // ... and so do host-side invalidations (boundary masses rewritten, arrays regrown, engine switches)
+    if (_graph->tried && (_graph->capturedCount != _fluids->size() || _graph->capturedGeneration != _solver->graphGeneration()))
+        _graph->drop();
     if (wantGraph && !_graph->exec && !_graph->tried) {
         _graph->tried = true;
         _graph->capturedCount = _fluids->size();
+        _graph->capturedGeneration = _solver->graphGeneration();
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             try { enqueueStep(); } catch (...) { ok = false; }

@@ -23,13 +23,14 @@ BasicSPHSolver::BasicSPHSolver(int num) : bufferFloat3((unsigned)num), _cache(ne
 BasicSPHSolver::~BasicSPHSolver() noexcept {}
 
 void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
-void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; }
+void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; _cache->listValid = false; ++_cache->generation; }
+unsigned int BasicSPHSolver::graphGeneration() const { return _cache->generation; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
 void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void* BasicSPHSolver::enginePos4() const { return _cache->posm.addr(); }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
-void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; }
+void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->allowPacked = false; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G

@@ -31,8 +31,11 @@ EXPORTS = [
     "sphx_step", "sphx_step_n", "sphx_counts", "sphx_iters", "sphx_field_bytes", "sphx_get",
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
-    "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest",
+    "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
+    "sphx_get_params",
 ]
+# symbols exported under the reference's own names (vbo.cu:46-51)
+REFERENCE_EXPORTS = ["generate_dots"]
 
 
 class Params(C.Structure):
@@ -101,6 +104,9 @@ def lib():
         L.sphx_error_total_fixed.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.sphx_use_stream.argtypes = [C.c_void_p]
         L.sphx_cell_columns.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.sphx_snapshot_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.sphx_snapshot_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.sphx_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
         L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.sphx_sizeof_params() != C.sizeof(Params):
@@ -270,31 +276,27 @@ def ieee_probe(a, b, c):
 
 
 # ------------------------------------------------------------------------------------ snapshots
-# A snapshot is everything a run needs to continue bit-identically: the scalars, the boundary set,
-# and the fluid state in its current (cell-sorted) order — positions, velocities, original ids and
-# the solver's persistent array (DFSPH warm stiffness / PBD last positions).  The reference has no
-# checkpoint facility; this is the "next" row §8(f)-2.
+# sphx_snapshot_save / sphx_snapshot_load (include/sphx_c.h): everything a run needs to continue
+# bit-identically, in the CURRENT array order; the loader restores that order without re-sorting.
+class _Loaded(System):
+    """a System adopted from sphx_snapshot_load"""
+
+    def __init__(self, handle):
+        self._h = handle
+        n, nb, cells = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().sphx_counts(self._h, C.byref(n), C.byref(nb), C.byref(cells)))
+        self.n, self.nb, self.cells = n.value, nb.value, cells.value
+        P = Params()
+        _check(lib().sphx_get_params(self._h, C.byref(P)))
+        self.params = P
+
+
 def save_snapshot(system, path):
-    P = system.params
-    blob = {"params": np.frombuffer(bytes(P), np.uint8).copy(), "pos": system.get(F_POS), "vel": system.get(F_VEL),
-            "ids": system.get(F_ID), "bpos": system.get(F_BPOS)}
-    if P.solver == DFSPH:
-        blob["warm"] = system.get(F_WARM)
-    if P.solver == PBD:
-        blob["pos_last"] = system.get(F_POS_LAST)
-    np.savez_compressed(path, **blob)
+    _check(lib().sphx_snapshot_save(system._h, os.fsencode(path)))
 
 
 def load_snapshot(path):
-    """returns a System that continues the saved run (no constructor step)"""
-    z = np.load(path)
-    P = Params.from_buffer_copy(z["params"].tobytes())
-    s = System(P, z["pos"], z["bpos"], ctor_step=False)
-    # the constructor re-sorts (an identity permutation for a saved, sorted state) and zeroes velocities
-    s.set(F_VEL, z["vel"])
-    s.set(F_ID, z["ids"])
-    if "warm" in z.files:
-        s.set(F_WARM, z["warm"])
-    if "pos_last" in z.files:
-        s.set(F_POS_LAST, z["pos_last"])
-    return s
+    """returns a System that continues the saved run (no constructor step, no re-sort)"""
+    h = C.c_void_p()
+    _check(lib().sphx_snapshot_load(os.fsencode(path), C.byref(h)))
+    return _Loaded(h)

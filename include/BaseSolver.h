@@ -23,6 +23,9 @@ public:
     // engine extension: true when step() performs no host synchronisation or host-side branching
     // on device results, i.e. when a whole SPHSystem::step() may be captured into a hipGraph.
     virtual bool graphSafe() const { return false; }
+    // changes whenever host-side state a captured graph depends on changed (buffers reallocated,
+    // boundary data rewritten, engine switches); a replaying caller must re-capture
+    virtual unsigned int graphGeneration() const { return 0; }
 
 protected:
     virtual void advect(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize) = 0;

@@ -4,12 +4,24 @@
 // construction, non-copyable, addr(offset) hands out a raw DEVICE pointer, storage released when
 // the last owner goes away.  Backed by hipMalloc; fills and copies run on sphx::stream().
 // Extension: swap() exchanges storage with a same-length array (used for ping-pong buffers).
+// Unlike every other HIP error (printed, execution continues — global.h), a failed allocation throws
+// sphx::DeviceAllocError.
 #pragma once
 
 #include <memory>
+#include <stdexcept>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include "global.h"
+
+namespace sphx {
+// thrown when device memory cannot be obtained: continuing with a null buffer would turn an
+// out-of-memory condition into a GPU fault (the C ABI maps it to SPHX_ERR_HIP)
+struct DeviceAllocError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+}  // namespace sphx
 
 template <typename T>
 class DArray {
@@ -43,7 +55,12 @@ private:
     static std::shared_ptr<T> allocate(unsigned int length)
     {
         void* raw = nullptr;
-        HIP_CALL(hipMalloc(&raw, sizeof(T) * (length ? length : 1u)));
+        const size_t bytes = sizeof(T) * (size_t)(length ? length : 1u);
+        const hipError_t e = hipMalloc(&raw, bytes);
+        if (e != hipSuccess || !raw) {
+            ::sphx::report_hip_error(e, __FILE__, __LINE__);
+            throw ::sphx::DeviceAllocError("DArray: hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
         return std::shared_ptr<T>(static_cast<T*>(raw), [](T* p) { HIP_CALL(hipFree(p)); });
     }
 

@@ -46,6 +46,15 @@ public:
               float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
               float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
               float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
+    // continuation of a saved run (sphx_snapshot_load): the fluid arrays are taken in the order given —
+    // no initial fluid sort, no step — so that the next step() sorts exactly what an uninterrupted run
+    // would have sorted (a stable sort's result depends on the incoming order)
+    struct Restored {};
+    SPHSystem(Restored, std::shared_ptr<SPHParticles>& fluidParticles,
+              std::shared_ptr<SPHParticles>& boundaryParticles, std::shared_ptr<BaseSolver>& solver,
+              float3 spaceSize, float sphCellLength, float sphSmoothingRadius, float dt, float sphM0,
+              float sphRho0, float sphRhoBoundary, float sphStiff, float sphVisc,
+              float sphSurfaceTensionIntensity, float sphAirPressure, float3 sphG, int3 cellSize);
     // slab decompositions: this system covers a sub-grid whose local cell column 0 is global column
     // `cellOffsetX` (cellSize.x = local columns incl. one ghost layer per side); no initial step.
     // phase(p) runs one stage of the DFSPH step (see sphx_phase in sphx_c.h) so that a distributed
@@ -59,36 +68,32 @@ public:
     void phase(int p);
     void phaseReduce(int p, int sumLo, int sumHi);   // error stages with the |error| total over [lo, hi)
     long long errorTotalFixed();
-    const DArray<int>& getCellStartFluid() const { return cellStartFluid; }
-    const DArray<int>& getCellStartBoundary() const { return cellStartBoundary; }
+    const DArray<int>& getCellStartFluid() const { return _fluidCellStart; }
+    const DArray<int>& getCellStartBoundary() const { return _wallCellStart; }
     BaseSolver* getSolver() const { return _solver.get(); }
 
 private:
-    void initialise(float sphM0, bool runStep);
+    void initialise(float sphM0, bool runStep, bool sortFluid = true);
     void computeBoundaryMass();
     void neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart);
     void enqueueStep();   // neighbour search + solver step, no sync
 
+    // who: the two particle sets and the solver plugin (owned; moved in by the constructor)
     std::shared_ptr<SPHParticles> _fluids;
     const std::shared_ptr<SPHParticles> _boundaries;
     std::shared_ptr<BaseSolver> _solver;
-    DArray<int> cellStartFluid;
-    DArray<int> cellStartBoundary;
-    const float3 _spaceSize;
-    const float _sphSmoothingRadius;
-    const float _sphCellLength;
-    const float _dt;
-    const float _sphRho0;
-    const float _sphRhoBoundary;
-    const float _sphStiff;
-    const float3 _sphG;
-    const float _sphVisc;
-    const float _sphSurfaceTensionIntensity;
-    const float _sphAirPressure;
-    const int3 _cellSize;
-    int _cellOffsetX = 0;
-    bool _slab = false;
-    DArray<int> bufferInt;
+    // what: the scalars handed to BaseSolver::step every frame
+    struct Scalars {
+        float3 space; int3 cells; float cellLength, radius, dt, rho0, rhoBoundary, stiff, visc, surfaceTension, airPressure;
+        float3 gravity;
+    };
+    const Scalars _sc;
+    // where: uniform grid tables (C+1 exclusive prefix sums; slot C = out-of-grid bucket) and scratch
+    DArray<int> _fluidCellStart;
+    DArray<int> _wallCellStart;
+    DArray<int> _intScratch;
     std::unique_ptr<sphx::GridScratch> _grid;
     std::unique_ptr<sphx::StepGraph> _graph;
+    int _cellOffsetX = 0;     // slab decompositions: global x index of local cell column 0
+    bool _slab = false;
 };

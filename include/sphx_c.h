@@ -175,6 +175,8 @@ int  sphx_cell_columns(const float *device_xyz, int n, float cell_length, int *d
 
 /* SPHSystem::size/boundarySize (SPHSystem.h:44-55) and grid size */
 int  sphx_counts(const sphx_system *sys, int *n_fluid, int *n_boundary, int *n_cells);
+/* the scalars the system was created with (e.g. after sphx_snapshot_load) */
+int  sphx_get_params(const sphx_system *sys, sphx_params *out);
 /* iteration counts of the last DFSPH step (the values DFSPHSolver.cu:49,65 compute and drop) */
 int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iters);
 
@@ -211,8 +213,19 @@ int  sphx_ieee_probe(const float *a, const float *b, const float *c, int n,
 int  sphx_fastmath_selftest(float radius, unsigned long long samples, unsigned int *mismatches3, int *enabled2);
 
 /* generate_dots (vbo.cu:26-51): position copy + density colour ramp into caller device
- * buffers dot[3n], color[3n] (the render-side consumer of the path).                          */
+ * buffers dot[3n], color[3n] (the render-side consumer of the path).  The library also exports the
+ * reference's own symbol `extern "C" void generate_dots(float3*, float3*, const std::shared_ptr<
+ * SPHParticles>)` (vbo.cu:46-51; C++ callers declare it as main.cpp:268 does).                  */
 int  sphx_generate_dots(const sphx_system *sys, float *device_dot, float *device_color);
+
+/* State snapshots (checkpoint / resume and fixture I/O; the reference has none).
+ * save: positions, velocities, ids, density, pressure in the CURRENT array order, the boundary set with
+ * its masses, and the solver's persistent array (DFSPH warm stiffness / PBD last positions), in one
+ * little-endian file.  load: creates a system that continues the saved run bit-identically: the
+ * arrays are restored in the saved order and NOT re-sorted, so the next step's stable cell sort sees
+ * exactly what the uninterrupted run would have seen.                                            */
+int  sphx_snapshot_save(const sphx_system *sys, const char *path);
+int  sphx_snapshot_load(const char *path, sphx_system **out);
 
 #ifdef __cplusplus
 }

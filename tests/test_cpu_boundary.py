@@ -24,6 +24,8 @@ def test_library_exports_every_declared_symbol(sphx):
     for nm in names:
         assert hasattr(L, nm), "libsphx.so does not export %s declared in include/sphx_c.h" % nm
     assert sorted(sphx.EXPORTS) == names, "sphx.py EXPORTS out of date with include/sphx_c.h"
+    for nm in sphx.REFERENCE_EXPORTS:       # the reference's own extern "C" symbol (vbo.cu:46-51)
+        assert hasattr(L, nm), "libsphx.so does not export the reference symbol %s" % nm
 
 
 def test_param_block_layouts_match(sphx, oracle):

@@ -302,22 +302,232 @@ def test_exact_fast_paths_match_ieee_operators(sphx, radius):
         assert enabled == [1, 1], "the reference radius must run on the fast paths"
 
 
-@pytest.mark.parametrize("solver", [1, 2])
-def test_snapshot_resume_is_bit_identical(sphx, tmp_path, solver):
-    """save after k steps, reload, continue: equals the uninterrupted run (incl. DFSPH warm start
-    and PBD last positions)"""
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_snapshot_resume_matches_oracle(sphx, oracle, tmp_path, solver):
+    """save after k steps of a disordered splash (particles change cells every step, so the arrays are
+    NOT in sorted order when saved), reload through the C ABI, continue: equals the ORACLE's
+    uninterrupted run bit for bit (incl. DFSPH warm start, adaptive iteration counts, PBD last positions)"""
     P, fluid, boundary = sphx.scene(12)
-    P.solver = solver; P.pbd_iters = 3
-    a = sphx.System(P, fluid, boundary)
+    P.solver = solver; P.pbd_iters = 3; P.dt = 0.001
+    pos, vel = _splash_state(len(fluid), P, 90 + solver)
+    Po = same_params(oracle.Params(), P)
+    a = sphx.System(P, pos, boundary, ctor_step=False)
+    o = oracle.System(Po, pos, boundary, ctor_step=False)
+    ids = a.get(sphx.F_ID)
+    a.set(sphx.F_VEL, vel[ids]); o.set(oracle.F_VEL, vel[ids])
     for _ in range(4):
-        a.step()
-    path = str(tmp_path / "snap.npz")
+        a.step(); o.step()
+    assert np.count_nonzero(np.diff(a.get(sphx.F_CELL)) < 0) > 0, "the saved state must be out of cell order"
+    path = str(tmp_path / "snap.bin")
     sphx.save_snapshot(a, path)
+    saved = {f: a.get(f) for f in (sphx.F_POS, sphx.F_VEL, sphx.F_ID, sphx.F_DENSITY)}
+    a.close()
     b = sphx.load_snapshot(path)
+    assert b.n == len(fluid) and b.params.solver == solver
+    for f, v in saved.items():
+        assert_bit_equal(b.get(f), v, "restored field %d" % f)
+    names = ["POS", "VEL", "DENSITY", "PRESSURE", "ID", "CELL", "CELLSTART_F"] + (FIELDS_DFSPH if solver == 1 else []) + \
+            (FIELDS_PBD if solver == 2 else [])
+    for s_ in range(3):
+        b.step(); o.step()
+        compare(sphx, oracle, b, o, names, "resumed solver %d step %d" % (solver, s_ + 1))
+        if solver == 1:
+            assert b.iters() == o.iters()
+
+
+def _size_independent_checks(sphx, s, P, n_expect):
+    n = s.n
+    assert n == n_expect
+    ids = s.get(sphx.F_ID)
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.int32)), "ids must stay a permutation"
+    cs = s.get(sphx.F_CELLSTART_F)
+    assert cs[0] == 0 and np.all(np.diff(cs) >= 0) and cs[-1] == n
+    pos = s.get(sphx.F_POS); den = s.get(sphx.F_DENSITY); vel = s.get(sphx.F_VEL)
+    assert np.isfinite(pos).all() and np.isfinite(den).all() and np.isfinite(vel).all()
+    assert pos.min() >= 0 and pos.max() <= 0.99 * P.space[0] + 1e-6
+    return pos, vel, den
+
+
+def test_full_size_properties_wcsph_263k(sphx):
+    """BASELINE config 2 (263,424 particles, WCSPH, dt = 0.001): size-independent properties."""
+    P, fluid, boundary = sphx.scene(56)
+    P.solver = sphx.WCSPH; P.dt = 0.001
+    s = sphx.System(P, fluid, boundary)
+    s.step_n(5)
+    pos, vel, den = _size_independent_checks(sphx, s, P, 263424)
+    k = 6                                     # ctor step + 5
+    assert abs(vel[:, 1].mean() + k * 9.8 * P.dt) < 0.25 * k * 9.8 * P.dt      # free fall dominates
+    assert 0.70 < den.mean() < 0.85 and den.max() < 1.3
+    pr = s.get(sphx.F_PRESSURE)
+    assert pr.min() >= 0.0                     # Tait pressure is clamped at zero (BasicSPHSolver.cu:110)
+    # the lattice is symmetric under x <-> z: mean displacement in x and z must agree to rounding
+    disp = pos[np.argsort(s.get(sphx.F_ID))] - fluid
+    assert abs(disp[:, 0].mean() - disp[:, 2].mean()) < 1e-6
+
+
+def test_full_size_properties_pbd_1m(sphx):
+    """BASELINE config 4 (1,022,208 particles, PBD, 4 Jacobi iterations + XSPH): properties."""
+    P, fluid, boundary = sphx.scene(88)
+    P.solver = sphx.PBD; P.pbd_iters = 4
+    s = sphx.System(P, fluid, boundary)        # the constructor step only records positions (PBDSolver.cu:45-49)
+    assert np.all(s.get(sphx.F_DENSITY) == 0.0)
+    s.step_n(4)
+    pos, vel, den = _size_independent_checks(sphx, s, P, 1022208)
+    assert 0.70 < den.mean() < 0.90
+    # PBD velocity = displacement / dt of the last step (PBDSolver.cu:55-60) + XSPH + surface + gravity:
+    # the mean fall speed after 4 real steps is 4 g dt to within the constraint corrections
+    assert abs(vel[:, 1].mean() + 4 * 9.8 * P.dt) < 0.3 * 4 * 9.8 * P.dt
+    last = s.get(sphx.F_POS_LAST)
+    assert np.isfinite(last).all() and np.abs(pos - last).max() < 0.05
+
+
+def test_10m_path_smoke(sphx):
+    """BASELINE config 5's particle count on one device (10,288,500 particles, DFSPH v=1, d=4): the
+    index arithmetic above 2^31 bytes, the automatic (y-chunk, x) tile schedule and the row storage at
+    this size are exercised by a test, not only by bench.py"""
+    P, fluid, boundary = sphx.scene(190)
+    P.solver = sphx.DFSPH; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    s = sphx.System(P, fluid, boundary)
+    s.step_n(2)
+    pos, vel, den = _size_independent_checks(sphx, s, P, 10288500)
+    assert abs(vel[:, 1].mean() + 3 * 9.8 * P.dt) < 0.2 * 3 * 9.8 * P.dt
+    assert 0.70 < den.mean() < 0.85
+    # interior lattice particles all have the same neighbourhood: their densities agree to rounding noise
+    mid = (np.abs(pos[:, 0] - 0.5 * P.space[0]) < 0.3) & (np.abs(pos[:, 2] - 0.5 * P.space[2]) < 0.3) & \
+          (np.abs(pos[:, 1] - 0.4 * P.space[1]) < 0.3)
+    assert mid.sum() > 1000 and np.ptp(den[mid]) < 1e-4
+    s.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_raised_count_rows_fit_capacity(sphx, solver):
+    """sphx_set_count may raise the active count after the neighbour rows were first built (slab
+    drivers do every step): the row storage is sized for the capacity, so the result equals the
+    direct 27-cell walk (engine flag 2 = no rows) bit for bit"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = solver; P.dt = 0.001
+    if solver == 1:
+        P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 2
+    pos, vel = _splash_state(len(fluid), P, 120 + solver)
+    out = []
+    for flags in (0, 2):
+        Q = P.copy(); Q.reserved[0] = flags
+        s = sphx.System(Q, pos, boundary, ctor_step=False)
+        ids = s.get(sphx.F_ID)
+        s.set(sphx.F_VEL, vel[ids])
+        s.set_count(s.n // 3)
+        s.step()                      # rows first built for a third of the particles
+        s.set_count(s.n)
+        s.step(); s.step_n(2)
+        out.append([s.get(f) for f in (sphx.F_POS, sphx.F_VEL, sphx.F_DENSITY, sphx.F_ID)])
+        s.close()
+    for a, b, nm in zip(out[0], out[1], ["pos", "vel", "density", "id"]):
+        assert_bit_equal(a, b, "raised count " + nm)
+
+
+def test_graph_follows_host_side_invalidation(sphx):
+    """a captured hipGraph must not survive host-side changes: rewriting the boundary masses after
+    step_n (snapshot restore does) has to reach the replayed steps exactly as it reaches eager ones;
+    a changed active count re-captures as well"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.DFSPH; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 2
+    a = sphx.System(P, fluid, boundary); b = sphx.System(P, fluid, boundary)
+    a.step_n(3)
     for _ in range(3):
-        a.step(); b.step()
-    for f in (sphx.F_POS, sphx.F_VEL, sphx.F_DENSITY, sphx.F_ID):
-        assert_bit_equal(b.get(f), a.get(f), "resume field %d" % f)
+        b.step()
+    bm = a.get(sphx.F_BMASS) * np.float32(1.5)
+    a.set(sphx.F_BMASS, bm); b.set(sphx.F_BMASS, bm)
+    a.step_n(3)
+    for _ in range(3):
+        b.step()
+    for f in (sphx.F_POS, sphx.F_VEL, sphx.F_DENSITY):
+        assert_bit_equal(a.get(f), b.get(f), "after BMASS rewrite, field %d" % f)
+    a.set_count(a.n - 64); b.set_count(b.n - 64)
+    a.step_n(2)
+    b.step(); b.step()
+    for f in (sphx.F_POS, sphx.F_VEL, sphx.F_DENSITY):
+        assert_bit_equal(a.get(f)[: a.n - 64], b.get(f)[: b.n - 64], "after count change, field %d" % f)
+
+
+def test_exceptions_do_not_cross_the_c_boundary(sphx):
+    """C++ exceptions thrown inside the engine (`throw "text"` like the reference's PBD first step,
+    PBDSolver.cu:45-49) come back as status codes with text, from every guarded entry point"""
+    import ctypes as C
+    P, fluid, boundary = sphx.scene(8)
+    P.solver = sphx.WCSPH
+    s = sphx.System(P, fluid, boundary, ctor_step=False)
+    L = sphx.lib()
+    rc = L.sphx_run_phase(s._h, sphx.PH_P_LAMBDA)          # a PBD stage on a WCSPH system
+    assert rc == -4 and b"PBD" in L.sphx_last_error()
+    rc = L.sphx_run_phase_reduce(s._h, sphx.PH_DEN_ERROR_ACC, 0, 10)
+    assert rc == -4 and b"DFSPH" in L.sphx_last_error()
+    tot = C.c_longlong()
+    assert L.sphx_error_total_fixed(s._h, C.byref(tot)) == -4
+    assert L.sphx_run_phase(s._h, 999) == -4
+    s.step()                                                # the system is still usable
+    assert np.isfinite(s.get(sphx.F_POS)).all()
+    Q = P.copy(); Q.solver = 7
+    h = C.c_void_p()
+    assert L.sphx_create(C.byref(Q), fluid.ctypes.data, len(fluid), boundary.ctypes.data, len(boundary), 1, C.byref(h)) == -1
+    assert L.sphx_snapshot_load(b"/nonexistent/snap.bin", C.byref(h)) == -1
+
+
+def test_demo_solver_hot_swap_and_reference_generate_dots(oracle, tmp_path):
+    """apps/sphx_demo --restart-with rebuilds the scene with another solver in the same process (the
+    reference's keys '1' '2' '3', main.cpp:225-239): the second run must equal a fresh oracle run.
+    --dots goes through the reference-signature `extern "C" generate_dots` (vbo.cu:46-51)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "sphx_demo")
+    subprocess.check_call(["make", "-C", os.path.join(root, "apps")], stdout=subprocess.DEVNULL)
+    out, dots = str(tmp_path / "dump.bin"), str(tmp_path / "dots.bin")
+    subprocess.check_call([exe, "--solver", "pbd", "--restart-with", "dfsph", "--nx", "12", "--steps", "5", "--dump", out,
+                           "--dots", dots], stdout=subprocess.DEVNULL)
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    pos = np.frombuffer(raw[4:4 + 12 * n], np.float32).reshape(n, 3)
+    den = np.frombuffer(raw[4 + 12 * n:], np.float32)
+    P, fluid, boundary = oracle.scene(12)
+    P.solver = oracle.DFSPH
+    o = oracle.System(P, fluid, boundary)
+    for _ in range(5):
+        o.step()
+    assert_bit_equal(pos, o.get(oracle.F_POS), "hot-swapped run pos")
+    assert_bit_equal(den, o.get(oracle.F_DENSITY), "hot-swapped run density")
+    raw = open(dots, "rb").read()
+    assert int(np.frombuffer(raw[:4], np.int32)[0]) == n
+    dc = np.frombuffer(raw[4:], np.float32).reshape(2, n, 3)
+    assert_bit_equal(dc[0], pos, "generate_dots positions")
+    water, foam, dense = np.float32([0.34, 0.46, 0.7]), np.float32([0.9, 0.9, 0.9]), np.float32([1.0, 0.4, 0.7])
+    w1 = np.clip((den - np.float32(0.75)) * np.float32(4.0), 0, 1)[:, None]
+    w2 = np.minimum((den * den - np.float32(1.0)) * np.float32(4.0), np.float32(1.0))[:, None]
+    want = np.where((den < 0.75)[:, None], water, np.where((den < 1.0)[:, None], w1 * foam + (1 - w1) * water,
+                                                           (1 - w2) * foam + w2 * dense)).astype(np.float32)
+    assert np.allclose(dc[1], want, rtol=0, atol=1e-6)
+
+
+def test_demo_snapshot_continue(sphx, oracle, tmp_path):
+    """the demo continues a snapshot (--load) and its dump equals the oracle's uninterrupted run"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "sphx_demo")
+    subprocess.check_call(["make", "-C", os.path.join(root, "apps")], stdout=subprocess.DEVNULL)
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.DFSPH
+    a = sphx.System(P, fluid, boundary)
+    for _ in range(30):
+        a.step()
+    snap, out = str(tmp_path / "s.bin"), str(tmp_path / "d.bin")
+    sphx.save_snapshot(a, snap)
+    a.close()
+    subprocess.check_call([exe, "--load", snap, "--steps", "4", "--dump", out], stdout=subprocess.DEVNULL)
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    Po = same_params(oracle.Params(), P)
+    o = oracle.System(Po, fluid, boundary)
+    for _ in range(34):
+        o.step()
+    assert_bit_equal(np.frombuffer(raw[4:4 + 12 * n], np.float32).reshape(n, 3), o.get(oracle.F_POS), "continued pos")
 
 
 def test_generate_dots_colour_ramp(sphx):
