@@ -72,7 +72,8 @@ struct StepGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool tried = false;
-    long stepsRun = 0;       // eager steps so far (lazy allocations happen in the first one)
+    long stepsRun = 0;       // steps so far
+    long warmSteps = 0;      // eager steps that ran the solver's full schedule (its lazy allocations are done after one)
     unsigned int capturedCount = 0;   // active fluid particles the captured launches were sized for
     unsigned int capturedGeneration = 0;   // BaseSolver::graphGeneration() at capture time
     void drop()
@@ -419,10 +420,12 @@ float SPHSystem::step()
     HIP_CALL(hipEventCreate(&start));
     HIP_CALL(hipEventCreate(&stop));
     HIP_CALL(hipEventRecord(start, st));
+    const bool fullSchedule = _solver->graphSafe();   // e.g. false for PBD's first call, which only records positions
     try {
         enqueueStep();
         HIP_CALL(hipStreamSynchronize(st));
         CHECK_KERNEL();
+        if (fullSchedule) _graph->warmSteps++;
     } catch (const char* s) {
         std::cout << s << "\n";
     } catch (...) {
@@ -444,7 +447,10 @@ float SPHSystem::stepN(int n)
     if (n <= 0) return 0.0f;
     hipStream_t st = sphx::stream();
     float extra = 0.0f;
-    if (_graph->stepsRun == 0) { extra = step(); --n; if (n == 0) return extra; }
+    // a capture must not contain allocations: the engine's lazily created buffers (neighbour rows, tile
+    // buckets) appear during the first step that runs the solver's full schedule, so that one is eager
+    while (n > 0 && (_graph->stepsRun == 0 || (_solver->graphSafe() && _graph->warmSteps == 0))) { extra += step(); --n; }
+    if (n == 0) return extra;
     const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
     // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
     // ... and so do host-side invalidations (boundary masses rewritten, arrays regrown, engine switches)

@@ -1,0 +1,627 @@
+// ubench_sweep.hip — stand-alone micro-benchmark behind DESIGN.md's choice of sweep structure.
+//
+// Question it answers on a real MI355X: with the neighbour rows given, what bounds a DFSPH-style
+// sweep — the divergent 16-byte global gathers (vector-memory address/tag pipe), LDS reads of the same
+// records staged per block, the row stream, or the VALU work per pair?  It runs the SAME pair
+// arithmetic (the engine's own kGradW from csrc/sph_device.hpp in "exact" mode, an rsq/rcp + FMA form
+// in "tol" mode) through three data paths:
+//   G32   rows of 32-bit global indices, wave-interleaved dword stream, 4 entries in flight (the r01 engine)
+//   G32c  same indices, but 4 entries per lane stored contiguously (one dwordx4 row load per 4 pairs)
+//   L16   256-particle (or 128) blocks stage their 9 neighbour ranges in LDS with coalesced loads; rows are
+//         16-bit LDS slots, 8 per lane per 16-byte chunk; pairs read ds_read_b128
+// each with one gathered record per pair ("1f": position+scalar, the correction sweeps) or two ("2f":
+// position+mass and velocity, the rate sweeps).  Results of all paths are compared (exact: bitwise).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+//         -fno-gpu-flush-denormals-to-zero -I cpp-fluid-particles_amd/csrc -I include tools/ubench_sweep.hip -o ubench_sweep
+//   ./ubench_sweep [nx=88] [reps=20]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sph_device.hpp"
+
+using namespace sphx;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int kCap = 64;          // row capacity (entries) of the benchmark scene
+constexpr int kChunk = 8;         // 16-bit entries per 16-byte row chunk
+
+struct Consts { KernelConsts k; float twoOverR, gradScale; };   // gradScale = 1 / (PI R^5)
+
+// ---- pair arithmetic ---------------------------------------------------------------------------------
+// exact: the engine's formulas on its validated fast paths (bit-exact IEEE results)
+__device__ __forceinline__ float pair_exact(const Consts& c, float3 pi, float3 vi, float4 pj, float4 vj)
+{
+    const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+    const float r2 = dot3(d, d);
+    const float3 g = kGradW<true>(d, q_of<true>(sqrt_sel<true>(r2), c.k), c.k);
+    return pj.w * dot3(sub3(vi, v3(vj.x, vj.y, vj.z)), g);
+}
+// tolerance: v_rsq / v_rcp and fused multiply-adds
+__device__ __forceinline__ float pair_tol(const Consts& c, float3 pi, float3 vi, float4 pj, float4 vj)
+{
+    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float r = r2 * __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    const float q = r * c.twoOverR;
+    const float poly = (q > 1.0f) ? __builtin_fmaf(__builtin_fmaf(-3.0f, q, 12.0f), q, -12.0f) : __builtin_fmaf(9.0f, q, -12.0f) * q;
+    const float s = poly * c.gradScale * __builtin_amdgcn_rcpf(q + kEps);
+    const float dv = __builtin_fmaf(vi.z - vj.z, dz, __builtin_fmaf(vi.y - vj.y, dy, (vi.x - vj.x) * dx));
+    return pj.w * s * dv;
+}
+template <bool EXACT>
+__device__ __forceinline__ float pair_term(const Consts& c, float3 pi, float3 vi, float4 pj, float4 vj)
+{
+    return EXACT ? pair_exact(c, pi, vi, pj, vj) : pair_tol(c, pi, vi, pj, vj);
+}
+
+// ---- G32: the r01 engine's data path -----------------------------------------------------------------
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_g32(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                             const unsigned int* __restrict__ rows, const int* __restrict__ cnt,
+                                             float* __restrict__ out, int n, int numTiles)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int i = tile * 64 + (int)(threadIdx.x & 63);
+    if (i >= n) return;
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const unsigned int* row = rows + ((size_t)tile * kCap) * 64u + (unsigned)(i & 63);
+    const int m = cnt[i];
+    float e = 0.0f;
+    int t = 0;
+    for (; t + 4 <= m; t += 4) {
+        unsigned int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) idx[u] = row[(size_t)(t + u) * 64u];
+        float4 pj[4], vj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+    }
+    for (; t < m; ++t) {
+        const unsigned int idx = row[(size_t)t * 64u];
+        const float4 pj = gather16(posm, idx << 4);
+        const float4 vj = TWO ? gather16(vel4, idx << 4) : make_float4(pj.w, 0.f, 0.f, 0.f);
+        e += pair_term<EXACT>(c, pi, vi, pj, vj);
+    }
+    out[i] = e;
+}
+
+// ---- G32c: chunked 32-bit rows (one dwordx4 per 4 pairs), rows padded with the dummy particle n ---------
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_g32c(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                              const uint4* __restrict__ rows, const int* __restrict__ tileChunks4,
+                                              float* __restrict__ out, int n, int numTiles, int cap4)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = min(tile * 64 + lane, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const uint4* row = rows + ((size_t)tile * cap4) * 64u + (unsigned)lane;
+    const int chunks = tileChunks4[tile];
+    float e = 0.0f;
+    uint4 nxt = row[0];
+    for (int ch = 0; ch < chunks; ++ch) {
+        const uint4 cur = nxt;
+        if (ch + 1 < chunks) nxt = row[(size_t)(ch + 1) * 64u];
+        const unsigned int idx[4] = {cur.x, cur.y, cur.z, cur.w};
+        float4 pj[4], vj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+    }
+    if (tile * 64 + lane < n) out[i] = e;
+}
+
+// ---- G32i: position and velocity interleaved in ONE array of 32-byte records: the two gathers of a pair hit
+// the same 128-byte line ------------------------------------------------------------------------------------------
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_g32i(Consts c, const float4* __restrict__ pv, const uint4* __restrict__ rows,
+                                              const int* __restrict__ tileChunks4, float* __restrict__ out, int n, int numTiles, int cap4)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = min(tile * 64 + lane, n - 1);
+    const float4 self = pv[2 * i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = pv[2 * i + 1];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const uint4* row = rows + ((size_t)tile * cap4) * 64u + (unsigned)lane;
+    const int chunks = tileChunks4[tile];
+    float e = 0.0f;
+    uint4 nxt = row[0];
+    for (int ch = 0; ch < chunks; ++ch) {
+        const uint4 cur = nxt;
+        if (ch + 1 < chunks) nxt = row[(size_t)(ch + 1) * 64u];
+        const unsigned int idx[4] = {cur.x, cur.y, cur.z, cur.w};
+        float4 pj[4], vj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pj[u] = gather16(pv, idx[u] << 5);
+            vj[u] = TWO ? gather16(pv, (idx[u] << 5) + 16u) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+    }
+    if (tile * 64 + lane < n) out[i] = e;
+}
+
+// ---- G32o: G32c with a tile schedule (which tile each launched wave works on) and a block size -------------
+template <int T, bool EXACT, bool TWO>
+__global__ void __launch_bounds__(T) k_g32o(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                            const uint4* __restrict__ rows, const int* __restrict__ tileChunks4,
+                                            const int* __restrict__ tileOrder, float* __restrict__ out, int n, int numTiles, int cap4)
+{
+    const int lt = logical_block() * (T / 64) + (int)(threadIdx.x >> 6);
+    if (lt >= numTiles) return;
+    const int tile = tileOrder[lt];
+    const int lane = threadIdx.x & 63;
+    const int i = min(tile * 64 + lane, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const uint4* row = rows + ((size_t)tile * cap4) * 64u + (unsigned)lane;
+    const int chunks = tileChunks4[tile];
+    float e = 0.0f;
+    uint4 nxt = row[0];
+    for (int ch = 0; ch < chunks; ++ch) {
+        const uint4 cur = nxt;
+        if (ch + 1 < chunks) nxt = row[(size_t)(ch + 1) * 64u];
+        const unsigned int idx[4] = {cur.x, cur.y, cur.z, cur.w};
+        float4 pj[4], vj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+    }
+    if (tile * 64 + lane < n) out[i] = e;
+}
+
+// ---- L16: block-staged neighbour ranges in LDS, 16-bit slot rows ------------------------------------------
+struct BlockRanges { int start[9]; int len[9]; int base[9]; int total; };
+
+template <int T, bool EXACT, bool TWO>
+__global__ void __launch_bounds__(T) k_l16(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                           const uint4* __restrict__ rows, const int* __restrict__ tileChunks,
+                                           const BlockRanges* __restrict__ ranges, float* __restrict__ out, int n, int numTiles,
+                                           int slots)
+{
+    extern __shared__ float4 lds[];
+    float4* lpos = lds;
+    float4* lvel = lds + slots;
+    constexpr int kWaves = T / 64;
+    const int blk = logical_block();
+    const int tile0 = blk * kWaves;
+    if (tile0 >= numTiles) return;
+    const BlockRanges& R = ranges[blk];
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+        const int s0 = R.start[r], ln = R.len[r], b0 = R.base[r];
+        for (int t = threadIdx.x; t < ln; t += T) {
+            lpos[b0 + t] = posm[s0 + t];
+            if (TWO) lvel[b0 + t] = vel4[s0 + t];
+        }
+    }
+    if (threadIdx.x == 0) {                     // the padding slot: zero mass, far away, zero field
+        lpos[R.total] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
+        if (TWO) lvel[R.total] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int tile = tile0 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = min(tile * 64 + lane, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const uint4* row = rows + ((size_t)tile * (kCap / kChunk)) * 64u + (unsigned)lane;
+    const int chunks = tileChunks[tile];
+    float e = 0.0f;
+    uint4 nxt = row[0];
+    for (int ch = 0; ch < chunks; ++ch) {
+        const uint4 cur = nxt;
+        if (ch + 1 < chunks) nxt = row[(size_t)(ch + 1) * 64u];
+        const unsigned int w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 pj[4], vj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int word = w[h * 2 + (u >> 1)];
+                const unsigned int slot = (u & 1) ? (word >> 16) : (word & 0xffffu);
+                pj[u] = lpos[slot];
+                vj[u] = TWO ? lvel[slot] : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+        }
+    }
+    if (tile * 64 + lane < n) out[i] = e;
+}
+
+// ---- host: scene, grid, rows ---------------------------------------------------------------------------
+static float bits_to_float(unsigned int b) { float f; memcpy(&f, &b, 4); return f; }
+
+int main(int argc, char** argv)
+{
+    const int nx = argc > 1 ? atoi(argv[1]) : 88;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const float spacing = 0.02f, R = 0.04f, cellLength = 1.01f * R, scale = nx / 24.0f;
+    const int ny = 3 * nx / 2, nz = nx;
+    const int n = nx * ny * nz;
+    const int gx = (int)ceilf(scale / cellLength), gy = gx, gz = gx, C = gx * gy * gz;
+    printf("scene: %d x %d x %d = %d particles, grid %d^3, R = %g\n", nx, ny, nz, n, gx, R);
+
+    // jittered lattice (deterministic): positions as in the dam-break block, +-4 %% of the spacing
+    std::vector<float4> P0(n);
+    std::vector<int> cell(n);
+    unsigned int rng = 12345u;
+    auto jitter = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.08f * spacing; };
+    {
+        int q = 0;
+        for (int iy = 0; iy < ny; ++iy) for (int ix = 0; ix < nx; ++ix) for (int iz = 0; iz < nz; ++iz, ++q) {
+            P0[q] = make_float4(0.27f * scale + spacing * ix + jitter(), 0.10f * scale + spacing * iy + jitter(),
+                                0.27f * scale + spacing * iz + jitter(), 76.596750762082e-6f);
+            const int cx = (int)(P0[q].x / cellLength), cy = (int)(P0[q].y / cellLength), cz = (int)(P0[q].z / cellLength);
+            cell[q] = (cx * gy + cy) * gz + cz;
+        }
+    }
+    std::vector<int> cs(C + 2, 0), order(n);
+    for (int q = 0; q < n; ++q) cs[cell[q] + 1]++;
+    for (int k = 0; k < C + 1; ++k) cs[k + 1] += cs[k];
+    {
+        std::vector<int> cur(cs.begin(), cs.begin() + C + 1);
+        for (int q = 0; q < n; ++q) order[cur[cell[q]]++] = q;
+    }
+    std::vector<float4> posm(n + 1), vel4(n + 1);
+    std::vector<int> scell(n);
+    for (int q = 0; q < n; ++q) {
+        posm[q] = P0[order[q]]; scell[q] = cell[order[q]];
+        rng = rng * 1664525u + 1013904223u;
+        vel4[q] = make_float4(jitter() * 50.f, -0.04f + jitter() * 50.f, jitter() * 50.f, 0.0f);
+    }
+    posm[n] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);   // dummy record for padded rows
+    vel4[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int numTiles = (n + 63) / 64;
+    const float tCut = R * R;
+    // global rows (visit order dx, dy, dz, ascending index), capacity kCap
+    std::vector<unsigned int> rowsG((size_t)numTiles * kCap * 64, 0u);
+    std::vector<uint4> rowsGc((size_t)numTiles * (kCap / 4) * 64, make_uint4(n, n, n, n));
+    std::vector<int> cnt(n, 0), tileChunks(numTiles, 0);
+    std::vector<std::vector<int>> nbr(n);
+    long long pairs = 0; int maxCnt = 0;
+#pragma omp parallel for reduction(+ : pairs) reduction(max : maxCnt) schedule(dynamic, 4096)
+    for (int i = 0; i < n; ++i) {
+        const int c0 = scell[i], cz = c0 % gz, cy = (c0 / gz) % gy, cx = c0 / (gz * gy);
+        std::vector<int>& my = nbr[i];
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            const int X = cx + dx, Y = cy + dy, Z = cz + dz;
+            if (X < 0 || X >= gx || Y < 0 || Y >= gy || Z < 0 || Z >= gz) continue;
+            const int cc = (X * gy + Y) * gz + Z;
+            for (int j = cs[cc]; j < cs[cc + 1]; ++j) {
+                if (j == i) continue;
+                const float ddx = posm[i].x - posm[j].x, ddy = posm[i].y - posm[j].y, ddz = posm[i].z - posm[j].z;
+                if (ddx * ddx + ddy * ddy + ddz * ddz <= tCut) my.push_back(j);
+            }
+        }
+        pairs += (long long)my.size();
+        maxCnt = std::max(maxCnt, (int)my.size());
+    }
+    if (maxCnt > kCap) { printf("row capacity %d exceeded (%d)\n", kCap, maxCnt); return 1; }
+    for (int i = 0; i < n; ++i) {
+        const int tile = i >> 6, lane = i & 63, m = (int)nbr[i].size();
+        cnt[i] = m;
+        tileChunks[tile] = std::max(tileChunks[tile], (m + kChunk - 1) / kChunk);
+        for (int t = 0; t < m; ++t) {
+            rowsG[((size_t)tile * kCap + t) * 64 + lane] = (unsigned)nbr[i][t];
+            unsigned int* w = reinterpret_cast<unsigned int*>(&rowsGc[((size_t)tile * (kCap / 4) + t / 4) * 64 + lane]);
+            w[t & 3] = (unsigned)nbr[i][t];
+        }
+    }
+    double waveIters = 0;
+    for (int t = 0; t < numTiles; ++t) waveIters += tileChunks[t] * kChunk;
+    printf("pairs: %lld (%.1f per particle), max %d; wave-iterations per tile %.1f (padding x%.2f)\n", pairs, (double)pairs / n,
+           maxCnt, waveIters / numTiles, waveIters * 64.0 / pairs);
+
+    // block ranges + 16-bit slot rows for T = 256 and T = 128
+    struct L16Set { int T; std::vector<BlockRanges> ranges; std::vector<uint4> rows; int slots; };
+    L16Set sets[2];
+    for (int v = 0; v < 2; ++v) {
+        L16Set& S = sets[v];
+        S.T = v == 0 ? 256 : 128;
+        const int blocks = (n + S.T - 1) / S.T;
+        S.ranges.resize(blocks);
+        S.rows.assign((size_t)numTiles * (kCap / kChunk) * 64, make_uint4(0, 0, 0, 0));
+        S.slots = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const int i0 = b * S.T, i1 = std::min(n, i0 + S.T);
+            const int idF = scell[i0], idL = scell[i1 - 1];
+            BlockRanges& Rg = S.ranges[b];
+            int base = 0;
+            for (int r = 0; r < 9; ++r) {
+                const int off = ((r / 3 - 1) * gy + (r % 3 - 1)) * gz;
+                const int lo = std::max(idF + off - 1, 0), hi = std::min(idL + off + 1, C - 1);
+                Rg.start[r] = 0; Rg.len[r] = 0; Rg.base[r] = base;
+                if (lo <= hi) { Rg.start[r] = cs[lo]; Rg.len[r] = cs[hi + 1] - cs[lo]; }
+                base += Rg.len[r];
+            }
+            Rg.total = base;
+            S.slots = std::max(S.slots, base + 1);
+            for (int i = i0; i < i1; ++i) {
+                const int c0 = scell[i], cy = (c0 / gz) % gy, cx = c0 / (gz * gy);
+                const int tile = i >> 6, lane = i & 63, m = cnt[i];
+                unsigned short* w = nullptr;
+                for (int t = 0; t < tileChunks[tile] * kChunk; ++t) {
+                    if ((t % kChunk) == 0) w = reinterpret_cast<unsigned short*>(&S.rows[((size_t)tile * (kCap / kChunk) + t / kChunk) * 64 + lane]);
+                    int slot = Rg.total;           // padding
+                    if (t < m) {
+                        const int j = nbr[i][t];
+                        const int cj = scell[j], jy = (cj / gz) % gy, jx = cj / (gz * gy);
+                        const int r = (jx - cx + 1) * 3 + (jy - cy + 1);
+                        slot = Rg.base[r] + (j - Rg.start[r]);
+                        if (j < Rg.start[r] || j >= Rg.start[r] + Rg.len[r]) { printf("range bug\n"); return 1; }
+                    }
+                    w[t % kChunk] = (unsigned short)slot;
+                }
+            }
+        }
+        if (S.slots > 65535) { printf("slots overflow\n"); return 1; }
+        printf("L16 T=%d: max staged slots per block %d (%.1f KB per field)\n", S.T, S.slots, S.slots * 16.0 / 1024);
+    }
+
+    // constants
+    Consts c;
+    memset(&c, 0, sizeof(c));
+    c.k.R = R; c.k.wA = 0.25f / (kPi * R * R * R); c.k.rcpR = 1.0f / R; c.k.fastQ = 1; c.k.fastDiv = 1; c.k.q2Free = 1; c.k.tCut = tCut;
+    c.twoOverR = 2.0f / R; c.gradScale = 1.0f / (kPi * R * R * R * R * R);
+    (void)bits_to_float;
+
+    // device buffers
+    float4 *dPos, *dVel; unsigned int* dRowsG; uint4 *dRowsGc, *dRowsL[2]; int *dCnt, *dTileChunks; BlockRanges* dRanges[2]; float* dOut;
+    CK(hipMalloc(&dPos, sizeof(float4) * (n + 1))); CK(hipMalloc(&dVel, sizeof(float4) * (n + 1)));
+    CK(hipMalloc(&dRowsG, sizeof(unsigned int) * rowsG.size())); CK(hipMalloc(&dRowsGc, sizeof(uint4) * rowsGc.size()));
+    CK(hipMalloc(&dCnt, sizeof(int) * n)); CK(hipMalloc(&dTileChunks, sizeof(int) * numTiles)); CK(hipMalloc(&dOut, sizeof(float) * n));
+    CK(hipMemcpy(dPos, posm.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dVel, vel4.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dRowsG, rowsG.data(), sizeof(unsigned int) * rowsG.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dRowsGc, rowsGc.data(), sizeof(uint4) * rowsGc.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dCnt, cnt.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dTileChunks, tileChunks.data(), sizeof(int) * numTiles, hipMemcpyHostToDevice));
+    int* dTileChunks4;
+    {
+        std::vector<int> t4(numTiles);
+        for (int t = 0; t < numTiles; ++t) t4[t] = tileChunks[t] * 2;
+        CK(hipMalloc(&dTileChunks4, sizeof(int) * numTiles));
+        CK(hipMemcpy(dTileChunks4, t4.data(), sizeof(int) * numTiles, hipMemcpyHostToDevice));
+    }
+    for (int v = 0; v < 2; ++v) {
+        CK(hipMalloc(&dRowsL[v], sizeof(uint4) * sets[v].rows.size()));
+        CK(hipMalloc(&dRanges[v], sizeof(BlockRanges) * sets[v].ranges.size()));
+        CK(hipMemcpy(dRowsL[v], sets[v].rows.data(), sizeof(uint4) * sets[v].rows.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(dRanges[v], sets[v].ranges.data(), sizeof(BlockRanges) * sets[v].ranges.size(), hipMemcpyHostToDevice));
+    }
+    float4* dPV;
+    {
+        std::vector<float4> pv(2 * (size_t)(n + 1));
+        for (int q = 0; q <= n; ++q) { pv[2 * (size_t)q] = posm[q]; pv[2 * (size_t)q + 1] = vel4[q]; }
+        CK(hipMalloc(&dPV, sizeof(float4) * pv.size()));
+        CK(hipMemcpy(dPV, pv.data(), sizeof(float4) * pv.size(), hipMemcpyHostToDevice));
+    }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
+    std::vector<float> ref[2][2], got(n);
+    auto run = [&](const char* name, int exact, int two, auto&& launch) {
+        CK(hipMemsetAsync(dOut, 0, sizeof(float) * n, st));
+        for (int w = 0; w < 3; ++w) launch();
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        CK(hipMemcpy(got.data(), dOut, sizeof(float) * n, hipMemcpyDeviceToHost));
+        std::vector<float>& rf = ref[exact][two];
+        const char* verdict = "reference";
+        if (rf.empty()) rf = got;
+        else {
+            long long diffBits = 0; double maxRel = 0;
+            for (int i = 0; i < n; ++i) {
+                if (memcmp(&got[i], &rf[i], 4) != 0) ++diffBits;
+                const double den = std::max(1e-12, (double)fabsf(rf[i]));
+                maxRel = std::max(maxRel, fabs((double)got[i] - rf[i]) / den);
+            }
+            static char buf[96];
+            snprintf(buf, sizeof(buf), "%lld values differ bitwise, max rel %.2e", diffBits, maxRel);
+            verdict = buf;
+        }
+        printf("%-40s %8.3f ms   %7.1f Gpair/s   alg %6.1f GB/s (44 B/particle)   [%s]\n", name, ms, pairs / ms * 1e-6,
+               44.0 * n / ms * 1e-6, verdict);
+    };
+
+    const unsigned gridG = xcd_grid(n, 256);
+    for (int exact = 1; exact >= 0; --exact) {
+        for (int two = 1; two >= 0; --two) {
+            char nm[64];
+            auto tag = [&](const char* path) { snprintf(nm, sizeof(nm), "%s %s %s", path, exact ? "exact" : "tol", two ? "2f" : "1f"); return nm; };
+#define PICK(KERNEL, ...)                                                                                   \
+    do {                                                                                                    \
+        if (exact) { if (two) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); } \
+        else { if (two) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); }      \
+    } while (0)
+            run(tag("G32 "), exact, two, [&] { PICK(k_g32, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsG, dCnt, dOut, n, numTiles); });
+            run(tag("G32c"), exact, two, [&] { PICK(k_g32c, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
+            run(tag("G32i"), exact, two, [&] { PICK(k_g32i, dim3(gridG), dim3(256), 0, st, c, dPV, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
+            for (int v = 0; v < (argc > 5 ? 2 : 0); ++v) {
+                const int T = sets[v].T, slots = sets[v].slots + 1;
+                const size_t ldsBytes = (size_t)slots * 16 * (two ? 2 : 1);
+                const unsigned grid = xcd_grid(n, T);
+                snprintf(nm, sizeof(nm), "L16 T=%d %s %s (%zu KB)", T, exact ? "exact" : "tol", two ? "2f" : "1f", ldsBytes / 1024);
+#define LAUNCH_L(TT, EX, TW) hipLaunchKernelGGL((k_l16<TT, EX, TW>), dim3(grid), dim3(TT), ldsBytes, st, c, dPos, dVel, dRowsL[v], dTileChunks, dRanges[v], dOut, n, numTiles, slots)
+                auto launch = [&] {
+                    if (T == 256) { if (exact) { if (two) LAUNCH_L(256, true, true); else LAUNCH_L(256, true, false); } else { if (two) LAUNCH_L(256, false, true); else LAUNCH_L(256, false, false); } }
+                    else { if (exact) { if (two) LAUNCH_L(128, true, true); else LAUNCH_L(128, true, false); } else { if (two) LAUNCH_L(128, false, true); else LAUNCH_L(128, false, false); } }
+                };
+                if (ldsBytes > 64 * 1024) {
+                    const void* fn = T == 256 ? (exact ? (two ? (const void*)k_l16<256, true, true> : (const void*)k_l16<256, true, false>)
+                                                        : (two ? (const void*)k_l16<256, false, true> : (const void*)k_l16<256, false, false>))
+                                              : (exact ? (two ? (const void*)k_l16<128, true, true> : (const void*)k_l16<128, true, false>)
+                                                        : (two ? (const void*)k_l16<128, false, true> : (const void*)k_l16<128, false, false>));
+                    CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+                }
+                run(nm, exact, two, launch);
+#undef LAUNCH_L
+            }
+#undef PICK
+        }
+    }
+
+    // ---- tile schedules: which tiles share a CU's L1 / an XCD's L2 at the same time ---------------------------
+    if (argc > 4) {
+        std::vector<int> order(numTiles);
+        int* dOrder; CK(hipMalloc(&dOrder, sizeof(int) * numTiles));
+        auto spread3 = [](unsigned long long v) { unsigned long long r = 0; for (int b = 0; b < 20; ++b) r |= ((v >> b) & 1ull) << (3 * b); return r; };
+        for (int sched = 0; sched < 5; ++sched) {
+            static const char* names[5] = {"linear", "ychunk8", "morton(x,y,z/8)", "morton(x,y,z/16)", "brick 2x2 cols"};
+            std::vector<std::pair<unsigned long long, int>> keyed(numTiles);
+            for (int t = 0; t < numTiles; ++t) {
+                const int c0 = scell[std::min(n - 1, t * 64)], cz = c0 % gz, cy = (c0 / gz) % gy, cx = c0 / (gz * gy);
+                unsigned long long key = (unsigned long long)t;
+                if (sched == 1) key = ((unsigned long long)(cy / ((gy + 7) / 8)) * gx + cx) * (unsigned long long)numTiles + t;
+                if (sched == 2) key = (spread3(cx) << 2) | (spread3(cy) << 1) | spread3(cz / 8);
+                if (sched == 3) key = (spread3(cx) << 2) | (spread3(cy) << 1) | spread3(cz / 16);
+                if (sched == 4) key = (((unsigned long long)(cx / 2) * gy + (cy / 2)) * gz + cz / 8) * 4ull + (cx & 1) * 2 + (cy & 1);
+                keyed[t] = {key, t};
+            }
+            std::stable_sort(keyed.begin(), keyed.end());
+            for (int t = 0; t < numTiles; ++t) order[t] = keyed[t].second;
+            CK(hipMemcpy(dOrder, order.data(), sizeof(int) * numTiles, hipMemcpyHostToDevice));
+            for (int bs = 0; bs < 3; ++bs) {
+                const int T = bs == 0 ? 256 : (bs == 1 ? 512 : 1024);
+                const unsigned grid = xcd_grid(n, T);
+                for (int exact = 1; exact >= 0; --exact)
+                    for (int two = 1; two >= 0; --two) {
+                        ref[exact][two].clear();
+                        char nm[80];
+                        snprintf(nm, sizeof(nm), "%s T=%d %s %s", names[sched], T, exact ? "exact" : "tol", two ? "2f" : "1f");
+#define LO(TT, EX, TW) hipLaunchKernelGGL((k_g32o<TT, EX, TW>), dim3(grid), dim3(TT), 0, st, c, dPos, dVel, dRowsGc, dTileChunks4, dOrder, dOut, n, numTiles, kCap / 4)
+#define LO2(TT) do { if (exact) { if (two) LO(TT, true, true); else LO(TT, true, false); } else { if (two) LO(TT, false, true); else LO(TT, false, false); } } while (0)
+                        run(nm, exact, two, [&] { if (T == 256) LO2(256); else if (T == 512) LO2(512); else LO2(1024); });
+#undef LO2
+#undef LO
+                    }
+            }
+        }
+    }
+
+    // ---- address-pattern probes: what does one divergent 16-byte gather instruction cost? ------------------
+    // Same kernel (G32c, tolerance arithmetic), synthetic rows of exactly 32 entries per lane:
+    //   same      every lane of the wave reads ONE record                      (pure issue cost)
+    //   contig    lane l reads record base + l                                  (8 cache lines of 128 B)
+    //   win80     every lane reads a pseudo-random record of an 80-record window around the tile (11 lines)
+    //   cell24    lanes of the same cell (groups of 8) share a 24-record window (what phase-aligned rows give)
+    //   real      the scene's rows as they are
+    //   aligned   the scene's rows with every (dx,dy) run padded to the wave's longest run, so all lanes are in
+    //             the same run at the same time
+    if (argc > 3 && argv[3][0] == 'p') {
+        const int capP = 96, cap4 = capP / 4;
+        std::vector<uint4> rows((size_t)numTiles * cap4 * 64);
+        std::vector<int> chunks4(numTiles);
+        uint4* dRows; int* dChunks;
+        CK(hipMalloc(&dRows, sizeof(uint4) * rows.size())); CK(hipMalloc(&dChunks, sizeof(int) * numTiles));
+        auto hash = [](unsigned int a, unsigned int b, unsigned int c3) { unsigned int v = a * 0x9E3779B1u ^ b * 0x85EBCA77u ^ c3 * 0xC2B2AE3Du; v ^= v >> 15; v *= 0x2C1B3C6Du; v ^= v >> 12; return v; };
+        for (int probe = 0; probe < 6; ++probe) {
+            static const char* names[6] = {"same", "contig", "win80", "cell24", "real", "aligned"};
+            std::fill(rows.begin(), rows.end(), make_uint4(n, n, n, n));
+            double iters = 0;
+            for (int tile = 0; tile < numTiles; ++tile) {
+                const int i0 = tile * 64;
+                int len = 32;
+                if (probe == 4) len = tileChunks[tile] * kChunk;
+                std::vector<int> off(10, 0);
+                if (probe == 5) {
+                    for (int r = 0; r < 9; ++r) {
+                        int mx = 0;
+                        for (int l = 0; l < 64 && i0 + l < n; ++l) {
+                            const int i = i0 + l, c0 = scell[i], cy = (c0 / gz) % gy, cx = c0 / (gz * gy);
+                            int k = 0;
+                            for (int j : nbr[i]) { const int cj = scell[j]; if ((cj / (gz * gy) - cx + 1) * 3 + ((cj / gz) % gy - cy + 1) == r) ++k; }
+                            mx = std::max(mx, k);
+                        }
+                        off[r + 1] = off[r] + mx;
+                    }
+                    len = (off[9] + 3) / 4 * 4;
+                    if (len > capP) { printf("aligned rows exceed capacity\n"); return 1; }
+                }
+                chunks4[tile] = len / 4;
+                iters += len;
+                for (int l = 0; l < 64; ++l) {
+                    const int i = std::min(i0 + l, n - 1);
+                    std::vector<unsigned int> e(len, (unsigned)n);
+                    if (probe == 0) for (int t = 0; t < len; ++t) e[t] = (unsigned)std::min(n - 1, i0 + (int)(hash(tile, t, 0) % 64));
+                    if (probe == 1) for (int t = 0; t < len; ++t) e[t] = (unsigned)std::min(n - 1, std::max(0, i0 + l + (int)(hash(tile, t, 0) % 17) - 8));
+                    if (probe == 2) for (int t = 0; t < len; ++t) e[t] = (unsigned)std::min(n - 1, std::max(0, i0 - 8 + (int)(hash(tile, t, l) % 80)));
+                    if (probe == 3) for (int t = 0; t < len; ++t) e[t] = (unsigned)std::min(n - 1, std::max(0, i0 + (l / 8) * 8 - 8 + (int)(hash(tile, t, l) % 24)));
+                    if (probe == 4) for (int t = 0; t < cnt[i] && i0 + l < n; ++t) e[t] = (unsigned)nbr[i][t];
+                    if (probe == 5 && i0 + l < n) {
+                        const int c0 = scell[i], cy = (c0 / gz) % gy, cx = c0 / (gz * gy);
+                        std::vector<int> fill(9, 0);
+                        for (int j : nbr[i]) {
+                            const int cj = scell[j], r = (cj / (gz * gy) - cx + 1) * 3 + ((cj / gz) % gy - cy + 1);
+                            e[off[r] + fill[r]++] = (unsigned)j;
+                        }
+                    }
+                    for (int t = 0; t < len; ++t) reinterpret_cast<unsigned int*>(&rows[((size_t)tile * cap4 + t / 4) * 64 + l])[t & 3] = e[t];
+                }
+            }
+            CK(hipMemcpy(dRows, rows.data(), sizeof(uint4) * rows.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dChunks, chunks4.data(), sizeof(int) * numTiles, hipMemcpyHostToDevice));
+            for (int exact = 1; exact >= 0; --exact)
+                for (int two = 1; two >= 0; --two) {
+                    ref[exact][two].clear();
+                    char nm[64];
+                    snprintf(nm, sizeof(nm), "probe %-7s %s %s", names[probe], exact ? "exact" : "tol", two ? "2f" : "1f");
+                    float msBefore = 0; (void)msBefore;
+                    run(nm, exact, two, [&] {
+                        if (exact) { if (two) hipLaunchKernelGGL((k_g32c<true, true>), dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRows, dChunks, dOut, n, numTiles, cap4);
+                                     else hipLaunchKernelGGL((k_g32c<true, false>), dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRows, dChunks, dOut, n, numTiles, cap4); }
+                        else { if (two) hipLaunchKernelGGL((k_g32c<false, true>), dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRows, dChunks, dOut, n, numTiles, cap4);
+                               else hipLaunchKernelGGL((k_g32c<false, false>), dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRows, dChunks, dOut, n, numTiles, cap4); }
+                    });
+                }
+            printf("   (%s: %.1f wave-iterations per tile)\n", names[probe], iters / numTiles);
+        }
+    }
+    return 0;
+}
