@@ -4,14 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric "simulation steps/sec ... DFSPH dam-break at stated N", config 5):
-the 10,288,500-particle dam break (190 x 285 x 190 block, 920k boundary particles), DFSPHSolver
+the 10,288,500-particle dam break (190 x 285 x 190 block, 917k boundary particles), DFSPHSolver
 with fixed 1 divergence + 4 density iterations, dt = 0.002, fp32.  It fits one GPU, so N = 1 runs
 the whole domain on one device and N > 1 splits the same domain into x-slabs (strong scaling).
 A "step" is one SPHSystem::step(): neighbour search + solver step.  Inputs are resident in HBM
 before the timed region (the scene is uploaded by the constructor).
 
-Prints ONE JSON line (rank 0).  Extra legs: `roofline` (dominant kernel, live hipEvent timing over
-the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0 at N=1 only).
+Prints ONE JSON line (rank 0) with, besides the contract's keys:
+  roofline      dominant kernel (density-error sweep), live hipEvent timing over the timed region: HBM fraction from
+                algorithmic bytes, the FP32-VALU fraction from counted pair evaluations (SURVEY.md §8d asks for both),
+                PMC traffic from profiles/traffic.json when that file was measured on THIS source tree
+  steady_state  post-impact legs (ragged cells, wall contact): the 10 M scene under the reference's adaptive iteration
+                control and the 1 M config 3, >= 100 timed steps each, with neighbours-per-particle statistics
+  configs       BASELINE configs 2, 3, 4 (263k WCSPH, 1M DFSPH, 1M PBD) and the reference scene (20,736 particles)
+  cpu_baseline  the CPU oracle on a bounded sample (>= 1 M particles), rank 0 at N = 1 only
 """
 import argparse
 import json
@@ -22,14 +28,25 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
-# algorithmic bytes per particle: whole DFSPH(v,d) step incl. neighbour search,
-# and the density-error sweep alone (R pos12 vel12 mass4 density4 alpha4, W error4 kappa4)
-def step_bytes_per_particle(v, d):
-    return 420 + 92 * v + 104 * d + 72
+FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector (packed) peak
+# algorithmic bytes per particle: whole step incl. neighbour search, and the density-error sweep
+# alone (R pos12 vel12 mass4 density4 alpha4, W error4 kappa4)
 RATE_KERNEL_BYTES_PER_PARTICLE = 44
+# flop model of SURVEY.md §8d for one accepted pair of the rate sweep: gradW ~ 40 (1 sqrt + divisions counted as 1
+# each) + (v_i - v_j).gradW, mass factor and accumulation ~ 10
+RATE_KERNEL_FLOP_PER_PAIR = 50
 DOMINANT_SPAN = "density_error"  # k_rate<DENSITY_MODE>: computeDensityError_CUDA, DFSPHSolver.cu:94-116
+
+
+def step_bytes_per_particle(solver, v, d, k):
+    if solver == "dfsph":
+        return 420 + 92 * v + 104 * d + 72
+    if solver == "wcsph":
+        return 396
+    return 300 + 104 * k + 72
 
 
 def parse():
@@ -43,20 +60,26 @@ def parse():
     ap.add_argument("--den-iters", type=int, default=4)
     ap.add_argument("--pbd-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the steady-state leg and the configs 2-4 legs")
+    ap.add_argument("--settle-steps", type=int, default=300, help="steps advanced before the steady-state leg is timed")
+    ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--force-slab", action="store_true", help="run the x-slab driver even with one rank (debug)")
-    ap.add_argument("--cpu-nx", type=int, default=40, help="bounded CPU sample: nx of the oracle run")
+    ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
 
 
 def cpu_baseline(args, n_bench):
-    """CPU oracle (kind 'port': this repo's restatement of the reference, OpenMP over particles) on a
-    bounded sample of the same workload, scaled linearly in particle count to the bench size."""
+    """CPU oracle (kind 'port': this repo's restatement of the reference, OpenMP over particles; the reference
+    itself cannot be built here — nvcc, Thrust and helper_math.h are absent) on a bounded sample of the same
+    workload, scaled linearly in particle count to the bench size."""
     from oracle import oracle as O
     P, fluid, boundary = O.scene(args.cpu_nx)
     P.solver = {"wcsph": O.WCSPH, "dfsph": O.DFSPH, "pbd": O.PBD}[args.solver]
     P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, args.pbd_iters
+    note("cpu baseline: oracle nx=%d" % args.cpu_nx)
     s = O.System(P, fluid, boundary)          # constructor step = warm-up
+    note("cpu baseline: constructor step done")
     t0 = time.time()
     for _ in range(args.cpu_steps):
         s.step()
@@ -65,25 +88,117 @@ def cpu_baseline(args, n_bench):
     cores = O.lib().oracle_max_threads()
     steps_per_s_at_bench = (1.0 / dt) * (n_s / float(n_bench))
     return {"value": steps_per_s_at_bench, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/sph_oracle.c, %s dam-break nx=%d (%d particles), %d steps at %.3f s/step on %d OpenMP "
-                      "threads, scaled by particle count to %d particles" % (args.solver, args.cpu_nx, n_s, args.cpu_steps,
-                                                                             dt, cores, n_bench)}
+            "note": "port = oracle/sph_oracle.c, this repo's CPU restatement; the reference is not buildable here",
+            "sample": "%s dam-break nx=%d (%d particles), %d steps at %.3f s/step on %d OpenMP threads, scaled by "
+                      "particle count to %d particles" % (args.solver, args.cpu_nx, n_s, args.cpu_steps, dt, cores, n_bench)}
 
 
 def read_traffic(workload_key):
-    """per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes"""
+    """per-launch HBM bytes (and VALU-busy, when recorded) of the dominant kernel from the committed rocprofv3 --pmc
+    passes — only if they were measured on the source tree this library was built from"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
+        from srchash import engine_source_hash
         with open(path) as f:
             entry = json.load(f).get(workload_key)
-            return entry["hbm_bytes_per_launch"] if entry else None      # provenance: "source" / "measured_on" in that file
+        if not entry or entry.get("source_hash") != engine_source_hash():
+            return None, None
+        return entry.get("hbm_bytes_per_launch"), entry.get("valu_busy_frac")
     except Exception:
-        return None
+        return None, None
+
+
+_T0 = time.time()
+
+
+def note(msg):
+    """progress on stderr (stdout carries only the result line)"""
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - _T0, msg))
+    sys.stderr.flush()
 
 
 def emit(result, real_stdout):
     """the ONE JSON line, on the process's original stdout"""
     os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+
+def neighbour_stats(sim):
+    import numpy as np
+    total, longest, hist = sim.row_stats()
+    n = max(int(hist.sum()), 1)
+    cdf = np.cumsum(hist) / float(n)
+    return {"pairs": int(total), "mean": total / float(n), "p50": int(np.searchsorted(cdf, 0.5)),
+            "p99": int(np.searchsorted(cdf, 0.99)), "max": int(longest)}
+
+
+def make_system(sphx, nx, solver, div, den, pbd_iters):
+    P, fluid, boundary = sphx.scene(nx)
+    P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver]
+    P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = div, den, pbd_iters
+    if solver == "wcsph":
+        P.dt = 0.001
+    sim = sphx.System(P, fluid, boundary)     # uploads + constructor step (SPHSystem.cu:69-76)
+    if solver == "pbd":
+        sim.step()                            # PBD: the constructor step only records positions
+    return sim, P
+
+
+def timed_steps(torch, sim, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_events = sim.step_n(steps)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ms_events
+
+
+def settled_leg(sphx, torch, nx, solver, div, den, settle, steps):
+    """advance a fresh system past the impact, then time `steps` steps there"""
+    sim, P = make_system(sphx, nx, solver, div, den, 4)
+    what = "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults: 1e-3 thresholds, <= 20 iterations)"
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (nx, sim.n, what, P.dt), "after_steps": 1 + settle}
+    done, first = 0, None
+    while done < settle:              # in slices, so that a run-away state shows up instead of eating the time budget
+        k = min(50, settle - done)
+        t0 = time.perf_counter()
+        sim.step_n(k)
+        done += k
+        ms = (time.perf_counter() - t0) * 1e3 / k
+        first = first or ms
+        note("settling nx=%d: %d steps, %.2f ms/step" % (nx, done, ms))
+        if ms > 25.0 * first:
+            leg["diverged_after_steps"] = done
+            sim.close()
+            return leg
+    wall, _ = timed_steps(torch, sim, steps)
+    sps = steps / wall
+    if div < 0:
+        div, den = sim.iters()
+        leg["iterations_last_step"] = [div, den]
+    bpp = step_bytes_per_particle(solver, div, den, 4)
+    leg.update({"steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
+                "step_hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS,
+                "neighbours_per_particle": neighbour_stats(sim)})
+    note("post-impact leg nx=%d done: %.2f ms/step" % (nx, wall * 1e3 / steps))
+    sim.close()
+    return leg
+
+
+def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup):
+    """one of the BASELINE configs that are parity-test cases rather than the headline: graph-replayed steps"""
+    sim, P = make_system(sphx, nx, solver, div, den, pbd_iters)
+    sim.step_n(warmup)
+    wall, _ = timed_steps(torch, sim, steps)
+    note("leg nx=%d %s: %.3f ms/step" % (nx, solver, wall * 1e3 / steps))
+    sps = steps / wall
+    if solver == "dfsph" and div < 0:
+        div, den = sim.iters()                  # iteration counts of the last step
+    bpp = step_bytes_per_particle(solver, div, den, pbd_iters)
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (
+               nx, sim.n, {"wcsph": "WCSPH", "dfsph": "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults)", "pbd": "PBD(%d Jacobi)" % pbd_iters}[solver], P.dt),
+           "particles": sim.n, "steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
+           "algorithmic_GBps": bpp * sim.n * sps / 1e9, "hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS}
+    sim.close()
+    return leg
 
 
 def main():
@@ -110,7 +225,7 @@ def main():
     if args.gpus > 1 or args.force_slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        from multi_gpu import run_slab_bench        # x-slab decomposition, torch.distributed (RCCL)
+        from multi_gpu import run_slab_bench        # x-slab decomposition over RCCL
         result = run_slab_bench(args, rank, world, local_rank)
         if rank == 0:
             emit(result, real_stdout)
@@ -118,72 +233,88 @@ def main():
 
     sphx.set_device(local_rank)
     torch.cuda.set_device(local_rank)
-
-    P, fluid, boundary = sphx.scene(args.nx)
-    solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[args.solver]
-    P.solver = solver
-    P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, args.pbd_iters
-    if solver == sphx.WCSPH:
-        P.dt = 0.001
-    sim = sphx.System(P, fluid, boundary)     # uploads + constructor step (SPHSystem.cu:69-76)
+    solver = args.solver
+    note("building the %s nx=%d scene" % (solver, args.nx))
+    sim, P = make_system(sphx, args.nx, solver, args.div_iters, args.den_iters, args.pbd_iters)
     n = sim.n
-    if solver == sphx.PBD:
-        sim.step()                            # PBD: the constructor step only records positions
+    note("constructed, %d particles" % n)
 
-    # warm-up (untimed; also captures the hipGraph used when the live timer is off)
+    # warm-up (untimed)
     if args.warmup > 0:
         sim.step_n(args.warmup)
     torch.cuda.synchronize()
 
-    # timed region: exactly K steps, launched back to back with one sync at the end; the dominant
-    # kernel's launches are bracketed by hipEvents on the engine stream (live roofline leg)
-    span = DOMINANT_SPAN if solver == sphx.DFSPH else ""
+    # timed region: exactly K steps, launched back to back with one sync at the end; the dominant kernel's
+    # launches are bracketed by hipEvents on the engine stream (live roofline leg).  With the event timer on the
+    # steps are launched eagerly rather than replayed from the captured hipGraph: at 10 M particles launch overhead
+    # is < 1 %, and the number stays the contract's "measured over the timed region".
+    span = DOMINANT_SPAN if solver == "dfsph" else ""
     if span:
         sphx.kernel_timer(True, span)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ms_events = sim.step_n(args.steps)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    wall, ms_events = timed_steps(torch, sim, args.steps)
+    note("timed region done: %.2f ms/step" % (wall * 1e3 / args.steps))
     spans = sphx.kernel_timer_collect() if span else {}
     sphx.kernel_timer(False)
+    nb_free_fall = neighbour_stats(sim)
 
     ms_per_step = wall * 1e3 / args.steps
     steps_per_s = args.steps / wall
-    if solver == sphx.DFSPH:
-        bpp = step_bytes_per_particle(args.div_iters, args.den_iters)
-    elif solver == sphx.WCSPH:
-        bpp = 396
-    else:
-        bpp = 300 + 104 * args.pbd_iters + 72
+    bpp = step_bytes_per_particle(solver, args.div_iters, args.den_iters, args.pbd_iters)
+    what = {"dfsph": "DFSPH(%d div + %d density iters, fixed)" % (args.div_iters, args.den_iters),
+            "pbd": "PBD(%d Jacobi iters)" % args.pbd_iters, "wcsph": "WCSPH"}[solver]
     result = {
-        "metric": "simulation steps/sec, DFSPH dam-break" if solver == sphx.DFSPH else "simulation steps/sec, %s dam-break" % args.solver,
+        "metric": "simulation steps/sec, DFSPH dam-break" if solver == "dfsph" else "simulation steps/sec, %s dam-break" % solver,
         "value": steps_per_s, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s%s, dt=%g"
-                               % (args.nx, 3 * args.nx // 2, args.nx, n, sim.nb, args.solver.upper(),
-                                  "(%d div + %d density iters, fixed)" % (args.div_iters, args.den_iters) if solver == sphx.DFSPH
-                                  else ("(%d Jacobi iters)" % args.pbd_iters if solver == sphx.PBD else ""), P.dt),
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic, "
+                               "free-fall / early-impact window" % (args.nx, 3 * args.nx // 2, args.nx, n, sim.nb, what, P.dt),
                    "particles": n, "decomposition": "single device",
                    "step_algorithmic_bytes_per_particle": bpp,
                    "step_algorithmic_GBps": bpp * n * steps_per_s / 1e9,
                    "step_hbm_roofline_frac": bpp * n * steps_per_s / 1e9 / HBM_PEAK_GBPS,
-                   "event_ms_per_step": ms_events / args.steps},
+                   "event_ms_per_step": ms_events / args.steps,
+                   "neighbours_per_particle": nb_free_fall},
     }
     if span and span in spans:
         tot_ms, launches = spans[span]
         avg_ms = tot_ms / launches
         achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
+        traffic, valu_busy = read_traffic("%s_nx%d" % (solver, args.nx))
+        flops = RATE_KERNEL_FLOP_PER_PAIR * nb_free_fall["pairs"] / (avg_ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s')" % span,
                               "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBPS,
-                              "traffic": read_traffic("%s_nx%d" % (args.solver, args.nx)),
+                              "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                               "avg_launch_ms": avg_ms, "launches": launches,
-                              "algorithmic_bytes_per_launch": RATE_KERNEL_BYTES_PER_PARTICLE * n}
+                              "algorithmic_bytes_per_launch": RATE_KERNEL_BYTES_PER_PARTICLE * n,
+                              "valu": {"pairs_per_launch": nb_free_fall["pairs"], "flop_per_pair_model": RATE_KERNEL_FLOP_PER_PAIR,
+                                       "achieved_TFLOPs": flops, "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
+                                       "valu_busy_frac_pmc": valu_busy},
+                              "limiter": "divergent 16-byte neighbour gathers (vector-memory address/L1 line rate), see "
+                                         "profiles/r02_ubench_sweep_structure.txt"}
     else:
         result["roofline"] = None
+
     sim.close()
+    if not args.no_extra_legs:
+        # Post-impact legs (ragged cells, wall contact, 40+ neighbours).  At 10 M particles the column hits the floor
+        # around step 200; with the FIXED (1,4) iteration counts of config 5 the under-converged solve does not survive
+        # that impact (densities and velocities run away within ~50 steps: tools/settle_probe.py), so the
+        # 10 M leg runs the reference's own adaptive iteration control (thresholds 1e-3, at most 20 iterations); the
+        # 1 M config keeps its fixed counts, which do survive.
+        result["steady_state"] = [
+            settled_leg(sphx, torch, args.nx, "dfsph", -1, -1, args.settle_steps, args.steady_steps),
+            settled_leg(sphx, torch, 88, "dfsph", 1, 4, args.settle_steps, args.steady_steps),
+        ]
+    if not args.no_extra_legs:
+        legs = []
+        for nx, sv, steps in ((56, "wcsph", 200), (88, "dfsph", 100), (88, "pbd", 100)):      # BASELINE configs 2, 3, 4
+            legs.append(small_leg(sphx, torch, nx, sv, 1, 4, 4, steps, 10))
+        # the reference's own scene and defaults (20,736 particles; adaptive DFSPH, 20 PBD iterations), next to which
+        # BASELINE.md quotes 4.4 / 23.0 / 11.3 ms per frame on a GTX 1070
+        for sv, steps in (("wcsph", 300), ("dfsph", 100), ("pbd", 100)):
+            legs.append(small_leg(sphx, torch, 24, sv, -1, -1, 20, steps, 10))
+        result["configs"] = legs
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, n)
     emit(result, real_stdout)

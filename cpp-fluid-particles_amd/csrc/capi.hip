@@ -1,5 +1,6 @@
 // capi.hip — the extern "C" boundary declared in include/sphx_c.h, a thin layer over the C++
 // drop-in classes (SPHParticles, the three solvers, SPHSystem).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -19,20 +20,14 @@ void set_error_text(const std::string& s);
 }  // namespace sphx
 using namespace sphx;
 
-struct sphx_system {
-    sphx_params params;
-    std::unique_ptr<SPHSystem> system;
-    BasicSPHSolver* wcsph = nullptr;   // non-owning views of the solver the system owns
-    DFSPHSolver* dfsph = nullptr;
-    PBDSolver* pbd = nullptr;
-    int n = 0, nb = 0, cells = 0;
-};
+#include "capi_internal.hpp"
 
-static int fail(int code, const std::string& msg)
+int sphx_fail(int code, const std::string& msg)
 {
     set_error_text(msg);
     return code;
 }
+static int fail(int code, const std::string& msg) { return sphx_fail(code, msg); }
 
 // No C++ exception may cross the C boundary: the classes signal state errors with `throw "text"`
 // like the reference (PBDSolver.cu:45-49), the runtime may throw std::bad_alloc.
@@ -54,8 +49,6 @@ static int guarded(const char* where, F&& body)
     }
 }
 
-static int create_impl(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
-                       sphx_system** out);
 
 extern "C" {
 
@@ -156,13 +149,13 @@ int sphx_scene_fill(int nx, float* fluid, float* boundary)
 int sphx_create(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
                 sphx_system** out)
 {
-    return guarded("sphx_create", [&] { return create_impl(P, fluid, n, boundary, nb, run_ctor_step, out); });
+    return guarded("sphx_create", [&] { return sphx_create_impl(P, fluid, n, boundary, nb, run_ctor_step, out); });
 }
 
 }  // extern "C"
 
-static int create_impl(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
-                       sphx_system** out)
+int sphx_create_impl(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
+                     sphx_system** out)
 {
     if (!P || !out || n < 0 || nb < 0 || (n && !fluid) || (nb && !boundary)) return fail(SPHX_ERR_INVALID, "sphx_create: bad argument");
     if (P->pow7_mode != 0 || P->xsph_mode != 0) return fail(SPHX_ERR_INVALID, "sphx_create: pow7_mode and xsph_mode must be 0");
@@ -273,6 +266,24 @@ int sphx_get_params(const sphx_system* h, sphx_params* out)
     return SPHX_OK;
 }
 
+int sphx_row_stats(const sphx_system* h, long long* total, int* longest, int* hist128)
+{
+    if (!h || !h->wcsph || !total || !longest) return fail(SPHX_ERR_INVALID, "sphx_row_stats: bad argument");
+    const int n = (int)h->system->getFluids()->size();
+    std::vector<int> cnt((size_t)std::max(n, 1));
+    if (n > 0 && (hipMemcpyAsync(cnt.data(), h->wcsph->engineRowCounts(), sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+                  hipStreamSynchronize(sphx::stream()) != hipSuccess))
+        return fail(SPHX_ERR_HIP, "sphx_row_stats: copy failed");
+    long long t = 0; int mx = 0;
+    if (hist128) std::memset(hist128, 0, sizeof(int) * 128);
+    for (int i = 0; i < n; ++i) {
+        t += cnt[i]; mx = std::max(mx, cnt[i]);
+        if (hist128) hist128[std::min(std::max(cnt[i], 0), 127)]++;
+    }
+    *total = t; *longest = mx;
+    return SPHX_OK;
+}
+
 int sphx_iters(const sphx_system* h, int* div, int* den)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "null system");
@@ -282,7 +293,7 @@ int sphx_iters(const sphx_system* h, int* div, int* den)
 }
 
 // ------------------------------------------------------------------------------------ fields
-static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
+int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
 {
     const auto f = h->system->getFluids();
     const auto b = h->system->getBoundaries();
@@ -321,21 +332,21 @@ static int locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
 int sphx_field_bytes(const sphx_system* h, int field, size_t* bytes)
 {
     void* p;
-    if (!h || !bytes || locate(h, field, &p, bytes)) return fail(SPHX_ERR_INVALID, "sphx_field_bytes: unknown field for this solver");
+    if (!h || !bytes || sphx_locate(h, field, &p, bytes)) return fail(SPHX_ERR_INVALID, "sphx_field_bytes: unknown field for this solver");
     return SPHX_OK;
 }
 
 int sphx_device_ptr(const sphx_system* h, int field, void** out)
 {
     size_t sz;
-    if (!h || !out || locate(h, field, out, &sz)) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: unknown field for this solver");
+    if (!h || !out || sphx_locate(h, field, out, &sz)) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: unknown field for this solver");
     return SPHX_OK;
 }
 
 int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
 {
     void* p; size_t sz;
-    if (!h || !dst || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
+    if (!h || !dst || sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
     if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_get: size mismatch");
     if (!sz) return SPHX_OK;
     if (hipMemcpyAsync(dst, p, sz, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
@@ -350,7 +361,7 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
         field != SPHX_F_ID)
         return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
     void* p; size_t sz;
-    if (!h || !src || locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
+    if (!h || !src || sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
     if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
     if (!sz) return SPHX_OK;
     if (hipMemcpyAsync(p, src, sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
@@ -633,7 +644,7 @@ int sphx_snapshot_save(const sphx_system* h, const char* path)
         std::vector<char> buf;
         for (int f : fields) {
             void* p; size_t sz;
-            if (locate(h, f, &p, &sz)) return fail(SPHX_ERR_STATE, "sphx_snapshot_save: field missing");
+            if (sphx_locate(h, f, &p, &sz)) return fail(SPHX_ERR_STATE, "sphx_snapshot_save: field missing");
             buf.resize(sz);
             const int rc = sz ? sphx_get(h, f, buf.data(), sz) : (int)SPHX_OK;
             if (rc) return rc;
@@ -679,13 +690,13 @@ int sphx_snapshot_load(const char* path, sphx_system** out)
             return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: position fields missing or mis-sized");
         sphx_system* h = nullptr;
         // mode 2: no constructor step and NO initial fluid sort — the arrays continue in the saved order
-        int rc = create_impl(&P, reinterpret_cast<const float*>(pos->data()), counts[0],
+        int rc = sphx_create_impl(&P, reinterpret_cast<const float*>(pos->data()), counts[0],
                              reinterpret_cast<const float*>(bpos->data()), counts[1], 2, &h);
         if (rc) return rc;
         for (auto& b : blobs) {
             if (b.first == SPHX_F_POS || b.first == SPHX_F_BPOS || b.second.empty()) continue;
             void* p; size_t sz;
-            if (locate(h, b.first, &p, &sz) || sz != b.second.size()) { sphx_destroy(h); return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: field does not fit this solver"); }
+            if (sphx_locate(h, b.first, &p, &sz) || sz != b.second.size()) { sphx_destroy(h); return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: field does not fit this solver"); }
             if (hipMemcpyAsync(p, b.second.data(), sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
                 hipStreamSynchronize(sphx::stream()) != hipSuccess) { sphx_destroy(h); return fail(SPHX_ERR_HIP, "sphx_snapshot_load: upload failed"); }
             if (b.first == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();

@@ -6,6 +6,7 @@
 // of a second key sort; the warm reset / accumulate passes and the |error| reduction are fused
 // into the error kernel; the termination sum is an exact fixed-point integer, read
 // back only in adaptive mode.
+#include <algorithm>
 #include <limits>
 
 #include "DFSPHSolver.h"
@@ -43,12 +44,12 @@ float DFSPHSolver::readErrorTotal()
 
 namespace {
 template <bool DENSITY_MODE, int WARM>
-void launch_rate(const OpRate& op, int n, bool reduce)
+void launch_rate(const OpRate& op, int n, bool reduce, bool keepAccum = false)
 {
     if (n <= 0) return;
     OpRate o = op;
     if (!reduce) o.out.accum = nullptr;
-    else HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long), sphx::stream()));
+    else if (!keepAccum) HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long), sphx::stream()));
     launch_rate_kernel<DENSITY_MODE, WARM>(o, n);
 }
 }  // namespace
@@ -276,7 +277,8 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_DIV_ERROR: {
         ScopedKernel t("divergence_error");
         launch_rate<false, 0>(OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
-                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw(), sumLo, sumHi}}, num, reduce);
+                                     RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw(), sumLo, sumHi}}, num, reduce,
+                              c.keepErrorAccum);
         break;
     }
     case SPHX_PH_VISC_COLOR: {
@@ -298,7 +300,8 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
                                 surfaceTensionIntensity, airPressure, dt}, num);
         } else {
             ScopedKernel t("add_delta_v");
-            launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), num);
+            const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, num) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, num) : num;
+            launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
         }
         break;
     }
@@ -317,8 +320,8 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         ScopedKernel t("density_error");
         const OpRate rate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                           RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0, c.posfw(), sumLo, sumHi}};
-        if (phase == SPHX_PH_DEN_ERROR_SET) launch_rate<true, 1>(rate, num, reduce);
-        else launch_rate<true, 2>(rate, num, reduce);
+        if (phase == SPHX_PH_DEN_ERROR_SET) launch_rate<true, 1>(rate, num, reduce, c.keepErrorAccum);
+        else launch_rate<true, 2>(rate, num, reduce, c.keepErrorAccum);
         break;
     }
     default: throw "DFSPHSolver::runPhase: unknown stage";

@@ -61,6 +61,10 @@ struct SweepCache {
     // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
     // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
     unsigned int generation = 0;
+    // range-restricted sweeps (slab drivers split a stage into edge and interior particles so that halo
+    // traffic overlaps the interior): particles [rangeLo, rangeHi) of the next launches; -1 = all
+    int rangeLo = -1, rangeHi = -1;
+    bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
     bool fluidValid = false;
     bool boundaryValid = false;
     bool listValid = false;
@@ -124,6 +128,7 @@ void ew_copy(void* dst, const void* src, size_t bytes);
 void ew_fill_float(float* dst, float value, int n);
 void ew_iota(int* dst, int n);
 
+void device_exclusive_scan(int* data, int count, int* blockSums);
 void use_external_stream(hipStream_t s);
 const std::string& last_error_text();
 void set_error_text(const std::string& s);

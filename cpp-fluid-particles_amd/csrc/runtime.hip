@@ -463,6 +463,13 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.cg4 = cg4w();
     c.tileOrder = (orderValid && !(flags & kFlagLinearTiles)) ? tileOrder.addr() : nullptr;
     c.numTiles = (n + kTile - 1) / kTile;
+    c.tile0 = 0; c.lo = 0; c.hi = n;
+    if (rangeLo >= 0) {                       // a contiguous sub-range: linear tiles from the first one it touches
+        c.lo = std::min(rangeLo, n); c.hi = std::min(std::max(rangeHi, c.lo), n);
+        c.tile0 = c.lo / kTile;
+        c.numTiles = c.hi > c.lo ? (c.hi - 1) / kTile - c.tile0 + 1 : 0;
+        c.tileOrder = nullptr;
+    }
     c.posf = posfw();
     c.massUniform = (allowPacked && cellOffsetX == 0) ? massUniform.addr() : nullptr;
     return c;
@@ -478,7 +485,10 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; ++generation; return; }
     if (!nbr || (unsigned long long)nbr->length() < entries) { nbr.reset(new DArray<int>((unsigned)entries)); ++generation; }
     ensureTileOrder();
+    const int keepLo = rangeLo, keepHi = rangeHi;
+    rangeLo = rangeHi = -1;                    // rows are always built for every particle
     SweepCtx c = ctx(csF, csB);
+    rangeLo = keepLo; rangeHi = keepHi;
     c.nbr = nullptr;
     listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");

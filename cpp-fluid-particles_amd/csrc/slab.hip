@@ -1,0 +1,785 @@
+// slab.hip — the native multi-GPU layer (include/sphx_slab.h): SPHSystem::step() over x-slabs, one process per
+// GPU, halo exchange by RCCL point-to-point messages, or all slabs in one process (loopback) for testing.
+//
+// The decomposition follows from the reference's cell id (x slowest, CUDAFunctions.cuh:64-70) and cell length >=
+// support radius (main.cpp:56-57): one ghost cell column per side suffices (two for PBD, whose sweeps run on
+// positions that moved after binning, PBDSolver.cu:225-258).  See sphx_slab.h for the invariants that make the
+// result bit-identical to the single-device run.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>          // types and enums only: the library is opened at run time (sphx works without it)
+
+#include "capi_internal.hpp"
+#include "engine.hpp"
+#include "sphx_slab.h"
+
+using namespace sphx;
+
+namespace {
+
+// ================================================================================ RCCL, opened lazily
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+    bool load(std::string& why)
+    {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !AllReduce || !GroupStart || !GroupEnd) {
+            why = "librccl lacks an expected symbol";
+            return false;
+        }
+        return true;
+    }
+};
+RcclApi g_rccl;
+
+struct SlabError { std::string text; };
+[[noreturn]] void die(const std::string& s) { throw SlabError{s}; }
+void hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) die(std::string(what) + ": " + hipGetErrorString(e)); }
+void nccl_ok(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess) die(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+}
+
+// ================================================================================ transports
+struct Msg { int from, to; void* buf; size_t bytes; };     // global slab ranks; device buffers
+
+struct Transport {
+    virtual ~Transport() {}
+    // Executes the posted messages ordered after everything enqueued so far on the engine stream.  With
+    // async = true the transfer may run beside later engine work; wait() orders later engine work after it.
+    virtual void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) = 0;
+    virtual void wait() = 0;
+    virtual long long allreduce_sum(long long localSum) = 0;   // blocking; every process calls it
+};
+
+// all slabs in this process: a message is one device-to-device copy on the engine stream
+struct LoopbackTransport final : Transport {
+    void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool) override
+    {
+        std::vector<char> used(sends.size(), 0);
+        for (const Msg& r : recvs) {
+            size_t k = 0;
+            while (k < sends.size() && (used[k] || sends[k].from != r.from || sends[k].to != r.to)) ++k;
+            if (k == sends.size()) die("loopback: a receive has no matching send");
+            if (sends[k].bytes != r.bytes) die("loopback: message size mismatch between neighbours");
+            used[k] = 1;
+            if (r.bytes) hip_ok(hipMemcpyAsync(r.buf, sends[k].buf, r.bytes, hipMemcpyDeviceToDevice, sphx::stream()), "loopback copy");
+        }
+        for (size_t k = 0; k < sends.size(); ++k) if (!used[k]) die("loopback: a send has no matching receive");
+        sends.clear(); recvs.clear();
+    }
+    void wait() override {}
+    long long allreduce_sum(long long v) override { return v; }
+};
+
+// one process per GPU: grouped ncclSend / ncclRecv on a communication stream of its own
+struct RcclTransport final : Transport {
+    ncclComm_t comm = nullptr;
+    hipStream_t commStream = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool pending = false;
+    long long* dScalar = nullptr;       // 2 x int64 on the device for the all-reduce
+    long long* hScalar = nullptr;       // pinned
+
+    RcclTransport(int rank, int world, const char* id128)
+    {
+        std::string why;
+        if (!g_rccl.load(why)) die(why);
+        ncclUniqueId id;
+        static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+        std::memcpy(&id, id128, 128);
+        nccl_ok(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+        hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
+        hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
+        hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
+        hip_ok(hipHostMalloc((void**)&hScalar, 2 * sizeof(long long), hipHostMallocDefault), "pinned scalar");
+    }
+    ~RcclTransport() override
+    {
+        (void)hipStreamSynchronize(commStream);
+        if (comm) (void)g_rccl.CommDestroy(comm);
+        if (dScalar) (void)hipFree(dScalar);
+        if (hScalar) (void)hipHostFree(hScalar);
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+        if (commStream) (void)hipStreamDestroy(commStream);
+    }
+    void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) override
+    {
+        if (pending) wait();
+        hip_ok(hipEventRecord(ready, sphx::stream()), "event record");
+        hip_ok(hipStreamWaitEvent(commStream, ready, 0), "stream wait");
+        nccl_ok(g_rccl.GroupStart(), "ncclGroupStart");
+        for (const Msg& m : sends) if (m.bytes) nccl_ok(g_rccl.Send(m.buf, m.bytes, ncclInt8, m.to, comm, commStream), "ncclSend");
+        for (const Msg& m : recvs) if (m.bytes) nccl_ok(g_rccl.Recv(m.buf, m.bytes, ncclInt8, m.from, comm, commStream), "ncclRecv");
+        nccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd");
+        hip_ok(hipEventRecord(done, commStream), "event record");
+        pending = true;
+        sends.clear(); recvs.clear();
+        if (!async) wait();
+    }
+    void wait() override
+    {
+        if (!pending) return;
+        hip_ok(hipStreamWaitEvent(sphx::stream(), done, 0), "stream wait");
+        pending = false;
+    }
+    long long allreduce_sum(long long v) override
+    {
+        wait();
+        hScalar[0] = v;
+        hip_ok(hipMemcpyAsync(dScalar, hScalar, sizeof(long long), hipMemcpyHostToDevice, sphx::stream()), "scalar upload");
+        hip_ok(hipEventRecord(ready, sphx::stream()), "event record");
+        hip_ok(hipStreamWaitEvent(commStream, ready, 0), "stream wait");
+        nccl_ok(g_rccl.AllReduce(dScalar, dScalar + 1, 1, ncclInt64, ncclSum, comm, commStream), "ncclAllReduce");
+        hip_ok(hipMemcpyAsync(hScalar + 1, dScalar + 1, sizeof(long long), hipMemcpyDeviceToHost, commStream), "scalar download");
+        hip_ok(hipStreamSynchronize(commStream), "comm sync");
+        return hScalar[1];
+    }
+};
+
+// ================================================================================ device helpers
+// classification of the owned particles after last step's advect: global cell column by the engine's own
+// expression (true fp32 division, truncation: cell_of), which neighbour needs a copy, and a sanity flag
+__global__ void k_slab_classify(const float3* __restrict__ pos, int m, float cellLength, int x0, int x1, int g, int hasLeft,
+                                int hasRight, int* __restrict__ flagL, int* __restrict__ flagR, int* __restrict__ violation)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int col = (int)(pos[k].x / cellLength);
+    flagL[k] = (hasLeft && col <= x0 + g - 1) ? 1 : 0;
+    flagR[k] = (hasRight && col >= x1 - g) ? 1 : 0;
+    if (col < x0 - 1 || col > x1) *violation = 1;     // moved more than one column in one step
+}
+
+// payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives every owned particle,
+// sendL / sendR the stable compactions (scanL / scanR = exclusive scans of the flags)
+__global__ void k_slab_pack(const float3* __restrict__ pos, const float3* __restrict__ vel, const int* __restrict__ ids,
+                            const float* __restrict__ extra, int E, int m, const int* __restrict__ flagL,
+                            const int* __restrict__ flagR, const int* __restrict__ scanL, const int* __restrict__ scanR,
+                            float* __restrict__ own, float* __restrict__ sendL, float* __restrict__ sendR,
+                            long long* __restrict__ counts)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int W = 7 + E;
+    float row[10];
+    const float3 p = pos[k], v = vel[k];
+    row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = v.x; row[4] = v.y; row[5] = v.z; row[6] = __int_as_float(ids[k]);
+    for (int e = 0; e < E; ++e) row[7 + e] = extra[(size_t)k * E + e];
+    float* dst = own + (size_t)k * W;
+    for (int t = 0; t < W; ++t) dst[t] = row[t];
+    if (flagL[k]) { float* d = sendL + (size_t)scanL[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
+    if (flagR[k]) { float* d = sendR + (size_t)scanR[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
+    if (k == m - 1) { counts[0] = scanL[k] + flagL[k]; counts[1] = scanR[k] + flagR[k]; }
+}
+
+// new pre-sort arrays = [from left | previously owned | from right]: ascending in last step's global order, which
+// keeps the stable cell sort identical to the single-device one
+__global__ void k_slab_unpack(float3* __restrict__ pos, float3* __restrict__ vel, int* __restrict__ ids, float* __restrict__ extra,
+                              int E, const float* __restrict__ fromL, int nl, const float* __restrict__ own, int m,
+                              const float* __restrict__ fromR, int nr)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nl + m + nr) return;
+    const int W = 7 + E;
+    const float* row = t < nl ? fromL + (size_t)t * W : (t < nl + m ? own + (size_t)(t - nl) * W : fromR + (size_t)(t - nl - m) * W);
+    pos[t] = make_float3(row[0], row[1], row[2]);
+    vel[t] = make_float3(row[3], row[4], row[5]);
+    ids[t] = __float_as_int(row[6]);
+    for (int e = 0; e < E; ++e) extra[(size_t)t * E + e] = row[7 + e];
+}
+
+__global__ void k_slab_pick5(const int* __restrict__ cellStart, int i0, int i1, int i2, int i3, int i4, int* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = cellStart[i0]; out[1] = cellStart[i1]; out[2] = cellStart[i2]; out[3] = cellStart[i3]; out[4] = cellStart[i4];
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t count = 0;
+    void alloc(size_t n) { count = n ? n : 1; hip_ok(hipMalloc((void**)&p, sizeof(T) * count), "slab scratch"); hip_ok(hipMemsetAsync(p, 0, sizeof(T) * count, sphx::stream()), "memset"); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// ================================================================================ one slab
+struct Slab {
+    int rank = 0, world = 1;
+    int x0 = 0, x1 = 0, ghost = 1, cellsPerColumn = 0, localColumns = 0;
+    float cellLength = 0.0f;
+    int solver = SPHX_WCSPH;
+    sphx_system* sys = nullptr;
+    int capacity = 0, extraFloats = 0;
+    int o0 = 0, o1 = 0;              // owned particles [o0, o1) of the engine arrays
+    int layer[5] = {0, 0, 0, 0, 0};  // [0,l0) left ghosts, [l0,l1) first owned layers, [l2,l3) last owned layers, [l3,l4) right ghosts
+    int held = 0;
+    bool hasLeft = false, hasRight = false;
+    long stepsDone = 0;
+    // engine arrays
+    float3 *pos = nullptr, *vel = nullptr; int* ids = nullptr; float* extra = nullptr; float* density = nullptr; int* cellStart = nullptr;
+    // scratch
+    DevBuf<int> flagL, flagR, scanL, scanR, blockSums, violation, layerOut;
+    DevBuf<float> own, sendL, sendR, recvL, recvR;
+    DevBuf<long long> counts;        // [sendL, sendR, recvL, recvR]
+    long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 4 counts; 5 layer offsets + violation
+
+    ~Slab()
+    {
+        if (sys) sphx_destroy(sys);
+        if (hCounts) (void)hipHostFree(hCounts);
+        if (hInts) (void)hipHostFree(hInts);
+    }
+    int width() const { return 7 + extraFloats; }
+    void* field(int f, size_t* bytesPerParticle) const
+    {
+        void* p = nullptr; size_t total = 0;
+        if (sphx_locate(sys, f, &p, &total)) die("slab: the engine lacks a field of this solver");
+        *bytesPerParticle = total / (size_t)std::max(capacity, 1);
+        return p;
+    }
+};
+
+}  // namespace
+
+// ================================================================================ the group
+struct sphx_slab_group {
+    std::vector<std::unique_ptr<Slab>> slabs;
+    std::unique_ptr<Transport> transport;
+    sphx_params global{};
+    int world = 1, flags = 0;
+    bool surface = false, adaptive = false;
+    long long nGlobal = 0;
+    int lastDiv = 0, lastDen = 0;
+    double waitSeconds = 0.0;
+    std::vector<Msg> sends, recvs;
+
+    bool overlap() const { return (flags & SPHX_SLAB_NO_OVERLAP) == 0; }
+
+    void sync(const char* what)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        transport->wait();
+        hip_ok(hipStreamSynchronize(sphx::stream()), what);
+        waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    // ---- particle exchange (migrants and ghost copies alike) ------------------------------------------------
+    void exchangeParticles()
+    {
+        hipStream_t st = sphx::stream();
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            const int m = s.o1 - s.o0;
+            hip_ok(hipMemsetAsync(s.counts.p, 0, 4 * sizeof(long long), st), "memset");
+            hip_ok(hipMemsetAsync(s.violation.p, 0, sizeof(int), st), "memset");
+            if (m > 0) {
+                k_slab_classify<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, m, s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0,
+                                                                s.hasRight ? 1 : 0, s.flagL.p, s.flagR.p, s.violation.p);
+                hip_ok(hipMemcpyAsync(s.scanL.p, s.flagL.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
+                hip_ok(hipMemcpyAsync(s.scanR.p, s.flagR.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
+                device_exclusive_scan(s.scanL.p, m, s.blockSums.p);
+                device_exclusive_scan(s.scanR.p, m, s.blockSums.p);
+                k_slab_pack<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, s.vel + s.o0, s.ids + s.o0,
+                                                            s.extraFloats ? s.extra + (size_t)s.o0 * s.extraFloats : nullptr, s.extraFloats, m,
+                                                            s.flagL.p, s.flagR.p, s.scanL.p, s.scanR.p, s.own.p, s.sendL.p, s.sendR.p, s.counts.p);
+            }
+            // message sizes travel first (8 bytes per neighbour)
+            if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.counts.p + 0, 8}); recvs.push_back({s.rank - 1, s.rank, s.counts.p + 2, 8}); }
+            if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.counts.p + 1, 8}); recvs.push_back({s.rank + 1, s.rank, s.counts.p + 3, 8}); }
+        }
+        transport->exchange(sends, recvs, false);
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
+            hip_ok(hipMemcpyAsync(s.hInts + 5, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
+        }
+        sync("particle exchange (sizes)");
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            if (s.hInts[5]) die("slab: a particle crossed more than one cell column in one step");
+            const size_t rowBytes = sizeof(float) * (size_t)s.width();
+            const long long sl = s.hCounts[0], sr = s.hCounts[1], rl = s.hasLeft ? s.hCounts[2] : 0, rr = s.hasRight ? s.hCounts[3] : 0;
+            if ((long long)(s.o1 - s.o0) + rl + rr > s.capacity) die("slab: capacity exceeded (particles piled up in one slab)");
+            if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.sendL.p, (size_t)sl * rowBytes}); recvs.push_back({s.rank - 1, s.rank, s.recvL.p, (size_t)rl * rowBytes}); }
+            if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.sendR.p, (size_t)sr * rowBytes}); recvs.push_back({s.rank + 1, s.rank, s.recvR.p, (size_t)rr * rowBytes}); }
+        }
+        transport->exchange(sends, recvs, false);
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            const int m = s.o1 - s.o0, nl = s.hasLeft ? (int)s.hCounts[2] : 0, nr = s.hasRight ? (int)s.hCounts[3] : 0;
+            const int n = nl + m + nr;
+            if (n > 0)
+                k_slab_unpack<<<blocks_for(n), 256, 0, st>>>(s.pos, s.vel, s.ids, s.extra, s.extraFloats, s.recvL.p, nl, s.own.p, m, s.recvR.p, nr);
+            s.sys->system->getFluids()->setActiveCount((unsigned)n);
+            s.held = n;
+        }
+    }
+
+    // after the local sort: where the ghost and edge layers are (cell starts at five column boundaries)
+    void updateLayers()
+    {
+        hipStream_t st = sphx::stream();
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            const int L = s.cellsPerColumn, w = s.ghost, gl = s.localColumns;
+            k_slab_pick5<<<1, 64, 0, st>>>(s.cellStart, w * L, 2 * w * L, (gl - 2 * w) * L, (gl - w) * L, gl * L, s.layerOut.p);
+            hip_ok(hipMemcpyAsync(s.hInts, s.layerOut.p, 5 * sizeof(int), hipMemcpyDeviceToHost, st), "layers");
+        }
+        sync("layer offsets");
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            for (int k = 0; k < 5; ++k) s.layer[k] = s.hInts[k];
+            s.o0 = s.layer[0]; s.o1 = s.layer[3];
+        }
+    }
+
+    // Halo refresh of one or more per-particle fields: the edge layers are contiguous ranges of the sorted arrays, so
+    // a message is a plain slice of the engine's own array (no pack kernels, no staging copies); the sizes are known
+    // on both sides from their own cell tables (my right ghosts ARE the neighbour's first owned layers).
+    void postHalo(const std::vector<int>& fields, bool async)
+    {
+        if (fields.empty()) return;
+        for (int fieldId : fields)
+            for (auto& sp : slabs) {
+                Slab& s = *sp;
+                size_t bpp = 0;
+                char* base = static_cast<char*>(s.field(fieldId, &bpp));
+                const int* l = s.layer;
+                if (s.hasLeft) {
+                    sends.push_back({s.rank, s.rank - 1, base + (size_t)l[0] * bpp, (size_t)(l[1] - l[0]) * bpp});
+                    recvs.push_back({s.rank - 1, s.rank, base, (size_t)l[0] * bpp});
+                }
+                if (s.hasRight) {
+                    sends.push_back({s.rank, s.rank + 1, base + (size_t)l[2] * bpp, (size_t)(l[3] - l[2]) * bpp});
+                    recvs.push_back({s.rank + 1, s.rank, base + (size_t)l[3] * bpp, (size_t)(l[4] - l[3]) * bpp});
+                }
+            }
+        transport->exchange(sends, recvs, async);
+    }
+
+    void runAll(int phase)
+    {
+        transport->wait();
+        for (auto& sp : slabs) sp->sys->system->phase(phase);
+    }
+
+    // A sweep stage of DFSPH / WCSPH: only owned particles are swept (ghost values arrive by halo).  With overlap the
+    // two edge layers go first, the halo of the stage's output starts, the interior follows.
+    // reduce: the stage accumulates the exact |error| total of the owned particles (adaptive DFSPH).
+    void sweepStage(int phase, const std::vector<int>& halo, bool reduce = false)
+    {
+        transport->wait();                      // the edges read ghost values written by the previous stage's halo
+        const bool sweepGhosts = !overlap() && (flags & SPHX_SLAB_SWEEP_GHOSTS);
+        if (!overlap()) {
+            for (auto& sp : slabs) {
+                Slab& s = *sp;
+                if (sweepGhosts) s.sys->system->phaseEx(phase, -1, -1, reduce, s.o0, s.o1, false);
+                else s.sys->system->phaseEx(phase, s.o0, s.o1, reduce, s.o0, s.o1, false);
+            }
+            postHalo(halo, false);
+            return;
+        }
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            const int* l = s.layer;
+            s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, false);
+            s.sys->system->phaseEx(phase, l[2], l[3], reduce, s.o0, s.o1, true);
+        }
+        postHalo(halo, true);
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            s.sys->system->phaseEx(phase, s.layer[1], s.layer[2], reduce, s.o0, s.o1, true);
+        }
+    }
+
+    // global |error| total of the last error stage as the fp32 value DFSPHSolver compares with its threshold
+    float globalError()
+    {
+        long long local = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (auto& sp : slabs) local += sp->sys->system->errorTotalFixed();
+        const long long total = transport->allreduce_sum(local);
+        waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return (float)((double)total * (1.0 / 4294967296.0));
+    }
+
+    void stepDfsph()
+    {
+        const int v = global.dfsph_fixed_div, d = global.dfsph_fixed_den;
+        exchangeParticles();
+        runAll(SPHX_PH_SEARCH);
+        updateLayers();
+        sweepStage(SPHX_PH_HEAD, {SPHX_F_KAPPA});
+        int itDiv = 0, itDen = 0;
+        if (!adaptive) {
+            for (; itDiv < v; ++itDiv) {
+                sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
+                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA});
+            }
+        } else {       // DFSPHSolver.cu:347-361
+            const float limit = global.dfsph_divergence_thr * (float)nGlobal * global.rho0;
+            float total = 3.4028235e38f;
+            while ((itDiv < 1 || total > limit) && itDiv < global.dfsph_max_iter) {
+                sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
+                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA}, true);
+                total = globalError();
+                ++itDiv;
+            }
+        }
+        runAll(SPHX_PH_FORCE);
+        sweepStage(SPHX_PH_VISC_COLOR, surface ? std::vector<int>{SPHX_F_CG4} : std::vector<int>{});
+        sweepStage(SPHX_PH_SURFACE, {SPHX_F_VEL4});
+        sweepStage(SPHX_PH_WARM_CORRECT, {SPHX_F_VEL4});
+        sweepStage(SPHX_PH_DEN_ERROR_SET, {SPHX_F_KAPPA});
+        if (!adaptive) {
+            for (; itDen < d; ++itDen) {
+                sweepStage(SPHX_PH_DEN_CORRECT, {SPHX_F_VEL4});
+                sweepStage(SPHX_PH_DEN_ERROR_ACC, itDen + 1 < d ? std::vector<int>{SPHX_F_KAPPA} : std::vector<int>{});
+            }
+        } else {       // DFSPHSolver.cu:187-208
+            const float limit = global.dfsph_density_thr * (float)nGlobal * global.rho0;
+            float total = 3.4028235e38f;
+            while ((itDen < 2 || total > limit) && itDen < global.dfsph_max_iter) {
+                sweepStage(SPHX_PH_DEN_CORRECT, {SPHX_F_VEL4});
+                ++itDen;
+                const bool needTotal = itDen >= 2;
+                sweepStage(SPHX_PH_DEN_ERROR_ACC, {SPHX_F_KAPPA}, needTotal);
+                if (needTotal) total = globalError();
+            }
+        }
+        lastDiv = itDiv; lastDen = itDen;
+        for (auto& sp : slabs) if (sp->sys->dfsph) sp->sys->dfsph->noteIterations(itDiv, itDen);
+        runAll(SPHX_PH_ADVECT);
+    }
+
+    void stepWcsph()
+    {
+        exchangeParticles();
+        runAll(SPHX_PH_W_SEARCH);
+        updateLayers();
+        // W_PROPS writes the colour gradient (read by W_SURFACE) and the pressure term (read by W_PRESSURE)
+        sweepStage(SPHX_PH_W_PROPS, surface ? std::vector<int>{SPHX_F_CG4, SPHX_F_PTERM} : std::vector<int>{SPHX_F_PTERM});
+        sweepStage(SPHX_PH_W_SURFACE, {});
+        sweepStage(SPHX_PH_W_PRESSURE, {});
+        runAll(SPHX_PH_ADVECT);
+    }
+
+    // PBDSolver::step (PBDSolver.cu:34-79): two ghost columns, every stage on all held particles, halo after each
+    // stage that writes a neighbour-read field.  The first call only sorts and records positions (PBDSolver.cu:45-49).
+    void stepPbd()
+    {
+        exchangeParticles();
+        runAll(SPHX_PH_P_SEARCH);
+        updateLayers();
+        Slab& any = *slabs[0];
+        const bool first = any.stepsDone == 0;
+        if (first) return;
+        for (int it = 0; it < global.pbd_iters; ++it) {
+            runAll(SPHX_PH_P_LAMBDA); postHalo({SPHX_F_LAMBDA}, false);
+            runAll(SPHX_PH_P_DELTA); postHalo({SPHX_F_POS4}, false);
+        }
+        runAll(SPHX_PH_P_VELOCITY); postHalo({SPHX_F_VEL4}, false);
+        runAll(SPHX_PH_P_XSPH);
+        if (surface) postHalo({SPHX_F_CG4}, false);
+        runAll(SPHX_PH_P_SURFACE);
+        runAll(SPHX_PH_P_TAIL);
+    }
+
+    void step()
+    {
+        if (global.solver == SPHX_DFSPH) stepDfsph();
+        else if (global.solver == SPHX_WCSPH) stepWcsph();
+        else stepPbd();
+        for (auto& sp : slabs) sp->stepsDone++;
+    }
+};
+
+namespace {
+
+int slab_fail(int code, const std::string& msg) { return sphx_fail(code, msg); }
+
+template <class F>
+int slab_guarded(const char* where, F&& body)
+{
+    try {
+        return body();
+    } catch (const SlabError& e) {
+        return slab_fail(SPHX_ERR_STATE, std::string(where) + ": " + e.text);
+    } catch (const char* msg) {
+        return slab_fail(SPHX_ERR_STATE, std::string(where) + ": " + msg);
+    } catch (const sphx::DeviceAllocError& e) {
+        return slab_fail(SPHX_ERR_HIP, std::string(where) + ": " + e.what());
+    } catch (const std::exception& e) {
+        return slab_fail(SPHX_ERR_STATE, std::string(where) + ": " + e.what());
+    } catch (...) {
+        return slab_fail(SPHX_ERR_STATE, std::string(where) + ": unknown exception");
+    }
+}
+
+// cut planes x_0 = 0 < x_1 < ... < x_world = gx balancing the particle counts; every slab at least minWidth columns
+// (ghost width + 1: a particle that moves one column must be deliverable by its last owner to every rank that
+// needs it, owner or ghost holder, with neighbour messages only)
+std::vector<int> choose_cuts(const std::vector<int>& column, int gx, int world, int minWidth)
+{
+    std::vector<long long> cdf((size_t)gx, 0);
+    for (int c : column) cdf[(size_t)std::min(std::max(c, 0), gx - 1)]++;
+    for (int x = 1; x < gx; ++x) cdf[x] += cdf[x - 1];
+    const long long total = cdf[gx - 1];
+    std::vector<int> cuts{0};
+    for (int r = 1; r < world; ++r) {
+        const double target = (double)total * r / world;
+        int x = (int)(std::lower_bound(cdf.begin(), cdf.end(), target, [](long long a, double t) { return (double)a < t; }) - cdf.begin()) + 1;
+        x = std::max(x, cuts.back() + minWidth);
+        x = std::min(x, gx - minWidth * (world - r));
+        cuts.push_back(x);
+    }
+    cuts.push_back(gx);
+    for (size_t k = 0; k + 1 < cuts.size(); ++k)
+        if (cuts[k + 1] - cuts[k] < minWidth) die("domain too narrow for this many slabs");
+    return cuts;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sphx_slab_rccl_unique_id(char id128[128])
+{
+    if (!id128) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_rccl_unique_id: null buffer");
+    return slab_guarded("sphx_slab_rccl_unique_id", [&] {
+        std::string why;
+        if (!g_rccl.load(why)) die(why);
+        ncclUniqueId id;
+        nccl_ok(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id128, &id, 128);
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const float* fluid_vel, int n_fluid,
+                     const float* boundary_xyz, int n_boundary, int world, int first_rank, int local_ranks,
+                     const char* rccl_id128, int flags, sphx_slab_group** out)
+{
+    if (!params || !out || n_fluid < 0 || n_boundary < 0 || (n_fluid && !fluid_xyz) || (n_boundary && !boundary_xyz) || world < 1 ||
+        first_rank < 0 || local_ranks < 1 || first_rank + local_ranks > world)
+        return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: bad argument");
+    if (!rccl_id128 && (first_rank != 0 || local_ranks != world))
+        return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: without an RCCL token all slabs must be local (loopback)");
+    if (rccl_id128 && local_ranks != 1) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: RCCL drives one slab per process");
+    return slab_guarded("sphx_slab_create", [&] {
+        *out = nullptr;
+        std::unique_ptr<sphx_slab_group> G(new sphx_slab_group());
+        const sphx_params& P = *params;
+        G->global = P; G->world = world; G->flags = flags; G->nGlobal = n_fluid;
+        G->surface = P.surface_tension > EPSILON || P.air_pressure > EPSILON;
+        G->adaptive = P.solver == SPHX_DFSPH && (P.dfsph_fixed_div < 0 || P.dfsph_fixed_den < 0);
+        const int gx = P.cells[0], gy = P.cells[1], gz = P.cells[2];
+        const int ghost = P.solver == SPHX_PBD ? 2 : 1;
+        // transport first: it binds this process to its device-side communicator
+        if (rccl_id128) G->transport.reset(new RcclTransport(first_rank, world, rccl_id128));
+        else G->transport.reset(new LoopbackTransport());
+
+        // global boundary masses from a boundary-only whole-domain system (SPHSystem.cu:69-71), cell-sorted
+        std::vector<float> bpos((size_t)3 * n_boundary), bmass((size_t)n_boundary);
+        {
+            sphx_system* bs = nullptr;
+            sphx_params Pb = P; Pb.reserved[1] = 0; Pb.reserved[2] = 0;
+            const int rc = sphx_create_impl(&Pb, nullptr, 0, boundary_xyz, n_boundary, 0, &bs);
+            if (rc) die(std::string("boundary system: ") + sphx_last_error());
+            if (n_boundary) {
+                if (sphx_get(bs, SPHX_F_BPOS, bpos.data(), sizeof(float) * bpos.size()) || sphx_get(bs, SPHX_F_BMASS, bmass.data(), sizeof(float) * bmass.size()))
+                    die("boundary system: read-back failed");
+            }
+            sphx_destroy(bs);
+        }
+        // columns by the engine's expression on the host (IEEE division, truncation)
+        auto column_of = [&](float x) { volatile float q = x / P.cell_length; return (int)q; };
+        std::vector<int> col((size_t)n_fluid), bcol((size_t)n_boundary);
+        for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
+        for (int i = 0; i < n_boundary; ++i) bcol[i] = column_of(bpos[3 * (size_t)i]);
+        const std::vector<int> cuts = choose_cuts(col, gx, world, ghost + 1);
+        std::vector<long long> perSlab((size_t)world, 0);
+        for (int c : col) { int r = 0; while (r + 1 < world && c >= cuts[r + 1]) ++r; if (c >= 0 && c < gx) perSlab[r]++; }
+        const long long most = *std::max_element(perSlab.begin(), perSlab.end());
+
+        for (int r = first_rank; r < first_rank + local_ranks; ++r) {
+            std::unique_ptr<Slab> S(new Slab());
+            Slab& s = *S;
+            s.rank = r; s.world = world; s.x0 = cuts[r]; s.x1 = cuts[r + 1]; s.ghost = ghost;
+            s.cellsPerColumn = gy * gz; s.localColumns = (s.x1 - s.x0) + 2 * ghost; s.cellLength = P.cell_length;
+            s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
+            s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
+            s.capacity = (int)std::min<long long>((long long)(most * 1.3) + 4096, 2000000000LL);
+            // the slab's engine: a sub-grid of localColumns columns whose column 0 is global column x0 - ghost
+            sphx_params Pl = P;
+            Pl.cells[0] = s.localColumns; Pl.reserved[1] = s.x0 - ghost; Pl.reserved[2] = 1;
+            std::vector<float> bsel, msel;
+            for (int i = 0; i < n_boundary; ++i)
+                if (bcol[i] >= s.x0 - ghost && bcol[i] <= s.x1 + ghost - 1) {
+                    bsel.insert(bsel.end(), {bpos[3 * (size_t)i], bpos[3 * (size_t)i + 1], bpos[3 * (size_t)i + 2]});
+                    msel.push_back(bmass[i]);
+                }
+            std::vector<float> zeros((size_t)3 * s.capacity, 0.0f);
+            const int rc = sphx_create_impl(&Pl, zeros.data(), s.capacity, bsel.data(), (int)msel.size(), 0, &s.sys);
+            if (rc) die(std::string("slab engine: ") + sphx_last_error());
+            zeros.clear(); zeros.shrink_to_fit();
+            if (!msel.empty() && sphx_set(s.sys, SPHX_F_BMASS, msel.data(), sizeof(float) * msel.size())) die("slab engine: boundary masses");
+            // engine arrays
+            const auto f = s.sys->system->getFluids();
+            s.pos = f->getPosPtr(); s.vel = f->getVelPtr(); s.ids = f->getIdPtr(); s.density = f->getDensityPtr();
+            s.cellStart = s.sys->system->getCellStartFluid().addr();
+            if (P.solver == SPHX_DFSPH) s.extra = s.sys->dfsph->getWarmStiffness().addr();
+            if (P.solver == SPHX_PBD) s.extra = reinterpret_cast<float*>(s.sys->pbd->getPosLast().addr());
+            // scratch
+            const size_t cap = (size_t)s.capacity, W = (size_t)s.width();
+            s.flagL.alloc(cap); s.flagR.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.blockSums.alloc(cap / 2048 + 2);
+            s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(4);
+            s.own.alloc(cap * W); s.sendL.alloc(cap * W); s.sendR.alloc(cap * W); s.recvL.alloc(cap * W); s.recvR.alloc(cap * W);
+            hip_ok(hipHostMalloc((void**)&s.hCounts, 4 * sizeof(long long), hipHostMallocDefault), "pinned counts");
+            hip_ok(hipHostMalloc((void**)&s.hInts, 8 * sizeof(int), hipHostMallocDefault), "pinned ints");
+            // initial distribution: this slab's particles in generation order, ids = global generation index
+            std::vector<float> p0, v0; std::vector<int> id0;
+            for (int i = 0; i < n_fluid; ++i)
+                if (col[i] >= s.x0 && col[i] < s.x1) {
+                    p0.insert(p0.end(), {fluid_xyz[3 * (size_t)i], fluid_xyz[3 * (size_t)i + 1], fluid_xyz[3 * (size_t)i + 2]});
+                    if (fluid_vel) v0.insert(v0.end(), {fluid_vel[3 * (size_t)i], fluid_vel[3 * (size_t)i + 1], fluid_vel[3 * (size_t)i + 2]});
+                    id0.push_back(i);
+                }
+            const int m = (int)id0.size();
+            if (m > s.capacity) die("slab: capacity too small for the initial distribution");
+            hipStream_t st = sphx::stream();
+            if (m > 0) {
+                hip_ok(hipMemcpyAsync(s.pos, p0.data(), sizeof(float) * p0.size(), hipMemcpyHostToDevice, st), "upload");
+                if (fluid_vel) hip_ok(hipMemcpyAsync(s.vel, v0.data(), sizeof(float) * v0.size(), hipMemcpyHostToDevice, st), "upload");
+                else hip_ok(hipMemsetAsync(s.vel, 0, sizeof(float3) * (size_t)m, st), "memset");
+                hip_ok(hipMemcpyAsync(s.ids, id0.data(), sizeof(int) * id0.size(), hipMemcpyHostToDevice, st), "upload");
+                if (P.solver == SPHX_DFSPH) hip_ok(hipMemsetAsync(s.extra, 0, sizeof(float) * (size_t)m, st), "memset");
+                if (P.solver == SPHX_PBD) {
+                    // PBDSolver.h:56-60: the first step records the positions.  PBD derives velocities from
+                    // displacements, so initial velocities enter as last positions moved back by dt * vel.
+                    if (fluid_vel) for (size_t t = 0; t < p0.size(); ++t) v0[t] = p0[t] - P.dt * v0[t];
+                    hip_ok(hipMemcpyAsync(s.extra, fluid_vel ? v0.data() : p0.data(), sizeof(float) * p0.size(), hipMemcpyHostToDevice, st), "upload");
+                }
+            }
+            hip_ok(hipStreamSynchronize(st), "upload sync");
+            if (P.solver == SPHX_PBD) s.sys->pbd->markPosLastInitialized();
+            s.o0 = 0; s.o1 = m; s.held = m;
+            G->slabs.push_back(std::move(S));
+        }
+        *out = G.release();
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_destroy(sphx_slab_group* g)
+{
+    if (!g) return SPHX_OK;
+    (void)hipStreamSynchronize(sphx::stream());
+    delete g;
+    return SPHX_OK;
+}
+
+int sphx_slab_step(sphx_slab_group* g, int n, float* ms_total)
+{
+    if (!g || n < 0) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_step: bad argument");
+    return slab_guarded("sphx_slab_step", [&] {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < n; ++k) g->step();
+        g->transport->wait();
+        hip_ok(hipStreamSynchronize(sphx::stream()), "step sync");
+        if (ms_total) *ms_total = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_info(const sphx_slab_group* g, int index, int* x0, int* x1, int* owned, int* held)
+{
+    if (!g || index < 0 || index >= (int)g->slabs.size()) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_info: bad argument");
+    const Slab& s = *g->slabs[index];
+    if (x0) *x0 = s.x0;
+    if (x1) *x1 = s.x1;
+    if (owned) *owned = s.o1 - s.o0;
+    if (held) *held = s.held;
+    return SPHX_OK;
+}
+
+int sphx_slab_gather(sphx_slab_group* g, int index, int capacity, int* ids, float* pos, float* vel, float* density, int* count)
+{
+    if (!g || index < 0 || index >= (int)g->slabs.size() || !count) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_gather: bad argument");
+    return slab_guarded("sphx_slab_gather", [&] {
+        Slab& s = *g->slabs[index];
+        const int m = s.o1 - s.o0;
+        *count = m;
+        if (m > capacity) die("host arrays too small");
+        g->transport->wait();
+        hipStream_t st = sphx::stream();
+        if (m > 0) {
+            if (ids) hip_ok(hipMemcpyAsync(ids, s.ids + s.o0, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, st), "gather");
+            if (pos) hip_ok(hipMemcpyAsync(pos, s.pos + s.o0, sizeof(float3) * (size_t)m, hipMemcpyDeviceToHost, st), "gather");
+            if (vel) hip_ok(hipMemcpyAsync(vel, s.vel + s.o0, sizeof(float3) * (size_t)m, hipMemcpyDeviceToHost, st), "gather");
+            if (density) hip_ok(hipMemcpyAsync(density, s.density + s.o0, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st), "gather");
+        }
+        hip_ok(hipStreamSynchronize(st), "gather sync");
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_iters(const sphx_slab_group* g, int* div, int* den)
+{
+    if (!g) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_iters: null group");
+    if (div) *div = g->lastDiv;
+    if (den) *den = g->lastDen;
+    return SPHX_OK;
+}
+
+int sphx_slab_system(const sphx_slab_group* g, int index, sphx_system** sys)
+{
+    if (!g || !sys || index < 0 || index >= (int)g->slabs.size()) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_system: bad argument");
+    *sys = g->slabs[index]->sys;
+    return SPHX_OK;
+}
+
+int sphx_slab_wait_seconds(const sphx_slab_group* g, double* seconds)
+{
+    if (!g || !seconds) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_wait_seconds: bad argument");
+    *seconds = g->waitSeconds;
+    return SPHX_OK;
+}
+
+}  // extern "C"

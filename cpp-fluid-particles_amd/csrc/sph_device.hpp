@@ -314,7 +314,9 @@ struct SweepCtx {
     float4* posf;                           // (x, y, z, scalar field): position AND the neighbour scalar in one gather
     const int* massUniform;                 // device flag: 1 when every fluid particle has the mass of particle 0
     const int* tileOrder;                   // schedule: the tile each launched wave works on (nullptr: identity)
-    int numTiles;
+    int numTiles;                           // tiles this launch covers
+    int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
+    int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
     int n;
 };
 
@@ -326,8 +328,9 @@ __device__ __forceinline__ int wave_tile(const SweepCtx& c)
 {
     const int lt = logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6);
     if (lt >= c.numTiles) return -1;
-    return c.tileOrder ? c.tileOrder[lt] : lt;
+    return c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
 }
+__device__ __forceinline__ bool in_range(const SweepCtx& c, int i) { return i >= c.lo && i < c.hi; }
 
 // The 18 neighbour ranges of a tile, one per lane (lanes 0..8 fluid, 9..17 boundary; r = 3*(dx+1) +
 // (dy+1)), with each range's offset inside the LDS stage of its dx group (fluid dy=-1,0,1 first,

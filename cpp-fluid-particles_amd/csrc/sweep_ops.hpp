@@ -33,14 +33,17 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op o
     const int tile = wave_tile(op.c);
     if (tile < 0) return;                  // whole wave past the end (wave-uniform)
     const int i = tile * kTile + (int)(threadIdx.x & 63);
-    op(i, i < n, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
+    (void)n;
+    op(i, in_range(op.c, i), STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
 }
+// grid of a sweep launch: one wave per tile of the launch's range, padded to a multiple of 8 blocks
+inline unsigned int sweep_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kTile, kWideBlock); }
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
-    if (n <= 0) return;
-    if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(op, n);
-    else k_run_op<Op, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(op, n);
+    if (n <= 0 || op.c.numTiles <= 0) return;
+    if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+    else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
 }
 
 // wave-level sum of the fixed-point |error| terms, one atomic per wave
@@ -244,7 +247,8 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     const int tile = wave_tile(o.c);
     if (tile < 0) return;
     const int i = tile * kTile + (int)(threadIdx.x & 63);
-    const bool valid = i < n;
+    (void)n;
+    const bool valid = in_range(o.c, i);
     long long fixed = 0;
     OpDfsphHead::Body b{o, (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
     sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
@@ -259,9 +263,9 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
 template <bool WITH_RATE>
 inline void launch_dfsph_head(const OpDfsphHead& o, int n)
 {
-    if (n <= 0) return;
-    if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
-    else k_dfsph_head<WITH_RATE, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
+    if (n <= 0 || o.c.numTiles <= 0) return;
+    if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else k_dfsph_head<WITH_RATE, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
 // stand-alone rate sweep: e = sum_f m_j (v_i - v_j).gradW + sum_b m_j v_i.gradW
@@ -289,7 +293,8 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate
     const int tile = wave_tile(o.c);
     if (tile < 0) return;
     const int i = tile * kTile + (int)(threadIdx.x & 63);
-    const bool valid = i < n;
+    (void)n;
+    const bool valid = in_range(o.c, i);
     long long fixed = 0;
     OpRate::Body b{o, valid ? o.vel[i] : v3(0, 0, 0), 0.0f};
     sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
@@ -299,9 +304,9 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate
 template <bool DENSITY_MODE, int WARM>
 inline void launch_rate_kernel(const OpRate& o, int n)
 {
-    if (n <= 0) return;
-    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
-    else k_rate<DENSITY_MODE, WARM, false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(o, n);
+    if (n <= 0 || o.c.numTiles <= 0) return;
+    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
 // correctDivergenceError_CUDA (DFSPHSolver.cu:308-329) / correctDensityError_CUDA (:138-158)

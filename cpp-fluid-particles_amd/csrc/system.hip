@@ -278,6 +278,38 @@ SPHSystem::SPHSystem(Slab slab, std::shared_ptr<SPHParticles>& fluidParticles,
 
 SPHSystem::~SPHSystem() noexcept {}
 
+namespace sphx {
+// exclusive prefix sum of `count` ints in place; blockSums: scratch of at least count / 2048 + 2 ints
+void device_exclusive_scan(int* data, int count, int* blockSums)
+{
+    if (count <= 0) return;
+    hipStream_t st = sphx::stream();
+    const int tiles = (count - 1) / kScanTile + 1;
+    k_scan_tiles<<<tiles, 256, 0, st>>>(data, blockSums, count);
+    if (tiles > 1) {
+        k_scan_block_sums<<<1, 256, 0, st>>>(blockSums, tiles);
+        k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(data, blockSums, count);
+    }
+}
+}  // namespace sphx
+
+// a stage restricted to particles [lo, hi) (lo < 0: all), optionally accumulating the |error| total of
+// particles [sumLo, sumHi) (DFSPH error stages); keepAccum: add to the running total (a later part of a split stage)
+void SPHSystem::phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum)
+{
+    auto* basic = dynamic_cast<BasicSPHSolver*>(_solver.get());
+    if (!basic) throw "SPHSystem::phaseEx: needs an engine solver";
+    basic->setSweepRange(lo, hi, keepAccum);
+    try {
+        if (reduce) phaseReduce(p, sumLo, sumHi);
+        else phase(p);
+    } catch (...) {
+        basic->setSweepRange(-1, -1, false);
+        throw;
+    }
+    basic->setSweepRange(-1, -1, false);
+}
+
 // one stage of the DFSPH step (distributed drivers; see sphx_phase)
 void SPHSystem::phaseReduce(int p, int sumLo, int sumHi)
 {

@@ -10,6 +10,7 @@
 //            advect+clamp.  3 sweeps instead of 5.
 //   unfused  the reference's sequence of protected building blocks (force, diffuse, handleSurface,
 //            project, advect), used when a subclass overrides any of them or when asked for.
+#include <algorithm>
 #include <typeinfo>
 
 #include "BasicSPHSolver.h"
@@ -29,8 +30,10 @@ void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
 void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void* BasicSPHSolver::enginePos4() const { return _cache->posm.addr(); }
+const int* BasicSPHSolver::engineRowCounts() const { return _cache->nbrCount.addr(); }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
+void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->allowPacked = false; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
@@ -198,7 +201,8 @@ void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& flu
             launch_op(op, n);
         } else {
             ScopedKernel t("add_delta_v");
-            launch_add3(fluids->getVelPtr(), c.vel4w(), c.aux3.addr(), n);
+            const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, n) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, n) : n;
+            launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
         }
         return;
     }

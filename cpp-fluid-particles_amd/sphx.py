@@ -32,7 +32,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
-    "sphx_get_params",
+    "sphx_get_params", "sphx_row_stats",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -107,6 +107,7 @@ def lib():
         L.sphx_snapshot_save.argtypes = [C.c_void_p, C.c_char_p]
         L.sphx_snapshot_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.sphx_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.sphx_row_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
         L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.sphx_sizeof_params() != C.sizeof(Params):
@@ -196,6 +197,13 @@ class System:
         _check(lib().sphx_error_total_fixed(self._h, C.byref(v)))
         return v.value
 
+    def row_stats(self):
+        """(total accepted pairs, longest row, histogram[128] of row lengths) of the last row build"""
+        tot, mx = C.c_longlong(), C.c_int()
+        hist = np.zeros(128, np.int32)
+        _check(lib().sphx_row_stats(self._h, C.byref(tot), C.byref(mx), hist.ctypes.data))
+        return tot.value, mx.value, hist
+
     def device_ptr(self, field):
         p = C.c_void_p()
         _check(lib().sphx_device_ptr(self._h, field, C.byref(p)))
@@ -211,6 +219,91 @@ class System:
     def close(self):
         if getattr(self, "_h", None):
             lib().sphx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------ native slab layer
+SLAB_NO_OVERLAP, SLAB_SWEEP_GHOSTS = 1, 2
+SLAB_EXPORTS = ["sphx_slab_rccl_unique_id", "sphx_slab_create", "sphx_slab_destroy", "sphx_slab_step", "sphx_slab_info",
+                "sphx_slab_gather", "sphx_slab_iters", "sphx_slab_system", "sphx_slab_wait_seconds"]
+
+
+def rccl_unique_id():
+    """128-byte RCCL bootstrap token (rank 0 creates it; hand it to every rank over any side channel)"""
+    buf = C.create_string_buffer(128)
+    _check(lib().sphx_slab_rccl_unique_id(buf))
+    return buf.raw
+
+
+class SlabGroup:
+    """include/sphx_slab.h: the x-slabs of one simulation driven by this process (one with RCCL, all with loopback)"""
+
+    def __init__(self, params, fluid, boundary, world, first_rank=0, local_ranks=None, rccl_id=None, flags=0, velocity=None):
+        L = lib()
+        L.sphx_slab_create.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.sphx_slab_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.sphx_slab_info.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
+        L.sphx_slab_gather.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(C.c_int)]
+        L.sphx_slab_iters.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sphx_slab_system.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.sphx_slab_wait_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.sphx_slab_destroy.argtypes = [C.c_void_p]
+        fluid = np.ascontiguousarray(fluid, np.float32).reshape(-1, 3)
+        boundary = np.ascontiguousarray(boundary, np.float32).reshape(-1, 3)
+        vel = None if velocity is None else np.ascontiguousarray(velocity, np.float32).reshape(-1, 3)
+        self.world = world
+        self.local = world if local_ranks is None else local_ranks
+        self.n = len(fluid)
+        h = C.c_void_p()
+        _check(L.sphx_slab_create(C.byref(params), fluid.ctypes.data, None if vel is None else vel.ctypes.data, len(fluid),
+                                  boundary.ctypes.data, len(boundary), world, first_rank, self.local, rccl_id, flags, C.byref(h)))
+        self._h = h
+
+    def step(self, n=1):
+        ms = C.c_float()
+        _check(lib().sphx_slab_step(self._h, n, C.byref(ms)))
+        return ms.value
+
+    def info(self, index=0):
+        v = [C.c_int() for _ in range(4)]
+        _check(lib().sphx_slab_info(self._h, index, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)          # x0, x1, owned, held
+
+    def gather(self, index=0):
+        cap = self.info(index)[2]
+        ids = np.empty(cap, np.int32); pos = np.empty((cap, 3), np.float32); vel = np.empty((cap, 3), np.float32)
+        den = np.empty(cap, np.float32)
+        cnt = C.c_int()
+        _check(lib().sphx_slab_gather(self._h, index, cap, ids.ctypes.data, pos.ctypes.data, vel.ctypes.data, den.ctypes.data, C.byref(cnt)))
+        return ids, pos, vel, den
+
+    def gather_all(self):
+        """owned state of every local slab, concatenated and ordered by original particle index"""
+        parts = [self.gather(i) for i in range(self.local)]
+        ids = np.concatenate([p[0] for p in parts])
+        order = np.argsort(ids, kind="stable")
+        return (ids[order],) + tuple(np.concatenate([p[k] for p in parts])[order] for k in (1, 2, 3))
+
+    def iters(self):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().sphx_slab_iters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def wait_seconds(self):
+        v = C.c_double()
+        _check(lib().sphx_slab_wait_seconds(self._h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sphx_slab_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -42,6 +42,8 @@ public:
     void* engineCg4() const;
     void* enginePterm() const;
     void* enginePos4() const;
+    // per-particle neighbour-row lengths of the most recent row build (bench statistics)
+    const int* engineRowCounts() const;
     // reserve the boundary part of the engine's unified neighbour arrays (called once by SPHSystem
     // before any engine pointer is handed out; otherwise done lazily by the first step)
     void reserveBoundary(int count);
@@ -52,6 +54,9 @@ public:
                        const DArray<int>& cellStartBoundary, float3 spaceSize, int3 cellSize, float cellLength,
                        float radius, float dt, float rho0, float rhoB, float stiff, float visc, float3 G,
                        float surfaceTensionIntensity, float airPressure);
+    // restrict the sweeps of the following stages to particles [lo, hi) (lo < 0: all).  Slab drivers run a
+    // stage on the edge particles first, start the halo exchange, then run it on the interior.
+    void setSweepRange(int lo, int hi, bool keepErrorAccum = false);
     // call after writing boundary positions/masses through raw pointers
     void invalidateBoundary();
 

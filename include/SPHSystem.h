@@ -68,6 +68,9 @@ public:
     void phase(int p);
     void phaseReduce(int p, int sumLo, int sumHi);   // error stages with the |error| total over [lo, hi)
     long long errorTotalFixed();
+    // a stage on particles [lo, hi) only (lo < 0: all): slab drivers sweep the edge layers first, start the halo
+    // exchange of the stage's output, then sweep the interior
+    void phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum);
     const DArray<int>& getCellStartFluid() const { return _fluidCellStart; }
     const DArray<int>& getCellStartBoundary() const { return _wallCellStart; }
     BaseSolver* getSolver() const { return _solver.get(); }

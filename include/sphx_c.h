@@ -177,6 +177,9 @@ int  sphx_cell_columns(const float *device_xyz, int n, float cell_length, int *d
 int  sphx_counts(const sphx_system *sys, int *n_fluid, int *n_boundary, int *n_cells);
 /* the scalars the system was created with (e.g. after sphx_snapshot_load) */
 int  sphx_get_params(const sphx_system *sys, sphx_params *out);
+/* neighbour statistics of the most recent row build (bench.py reports them beside the timings): total
+ * accepted pairs, longest row, histogram of row lengths (bin 127 = 127 and more; may be NULL)   */
+int  sphx_row_stats(const sphx_system *sys, long long *total_pairs, int *longest_row, int *hist128);
 /* iteration counts of the last DFSPH step (the values DFSPHSolver.cu:49,65 compute and drop) */
 int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iters);
 

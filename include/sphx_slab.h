@@ -1,0 +1,70 @@
+/*
+ * sphx_slab.h — C ABI of the native multi-GPU layer: SPHSystem::step() over x-slabs of the domain, one
+ * process per GPU, halo exchange with RCCL point-to-point messages over xGMI (libsphx.so, csrc/slab.hip).
+ *
+ * Why x-slabs: the reference's linear cell id runs x slowest (CUDAFunctions.cuh:68), so the particles of the cell
+ * columns [x0, x1) plus one ghost column per side are ONE contiguous range of the globally cell-sorted arrays.
+ * Every slab holds [left ghosts | owned | right ghosts], entry for entry a slice of the single-device array, so
+ * each per-particle sum visits the same neighbours in the same order: the distributed run is bit-identical to
+ * SPHSystem::step() on one device for any number of slabs (tests/test_gpu_slab.py).
+ *
+ * One step = particle exchange (migrants and ghost copies, after last step's advect) -> local cell sort -> the
+ * solver's stages (sphx_phase in sphx_c.h) with a halo refresh after every stage that writes a field the next
+ * stage reads from neighbours.  With overlap on (default) a stage runs on the two edge layers first, the halo
+ * messages of its output start on a separate stream, and the interior particles are swept meanwhile.
+ *
+ * Transports: RCCL (one process per GPU; ncclSend/ncclRecv grouped per exchange, ncclAllReduce of one integer per
+ * iteration in adaptive DFSPH) and loopback (all slabs in this process on the current device; device-to-device
+ * copies) for single-GPU testing.
+ */
+#ifndef SPHX_SLAB_H
+#define SPHX_SLAB_H
+
+#include "sphx_c.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sphx_slab_group sphx_slab_group;   /* the slabs driven by this process: 1 (RCCL) or all (loopback) */
+
+enum {
+    SPHX_SLAB_NO_OVERLAP = 1,       /* run every stage on all particles, then exchange (the simple schedule) */
+    SPHX_SLAB_SWEEP_GHOSTS = 2      /* with NO_OVERLAP: also sweep the ghost particles (what the r01 Python driver did) */
+};
+
+/* 128-byte RCCL bootstrap token: rank 0 creates it, the launcher hands it to every rank (any side channel) */
+int sphx_slab_rccl_unique_id(char id128[128]);
+
+/*
+ * Cuts the GLOBAL scene (the same arrays on every rank; fluid velocities optional) into `world` x-slabs balancing
+ * the initial particle counts and creates the slabs [first_rank, first_rank + local_ranks).
+ *   RCCL:     local_ranks = 1, rccl_id128 = the token, one call per process after sphx_set_device
+ *   loopback: first_rank = 0, local_ranks = world, rccl_id128 = NULL
+ * params: the whole-domain scalars (as for sphx_create); DFSPH runs fixed or adaptive iterations as params say.
+ */
+int sphx_slab_create(const sphx_params *params, const float *fluid_xyz, const float *fluid_vel_or_null, int n_fluid,
+                     const float *boundary_xyz, int n_boundary, int world, int first_rank, int local_ranks,
+                     const char *rccl_id128, int flags, sphx_slab_group **out);
+int sphx_slab_destroy(sphx_slab_group *g);
+
+/* n steps; the k-th step since creation equals the k-th SPHSystem::step() of the single-device system counting its
+ * constructor step.  *ms_total: wall time of the batch on this process (host clock, device synchronised).        */
+int sphx_slab_step(sphx_slab_group *g, int n, float *ms_total);
+
+/* geometry and sizes of local slab `index`: owned cell columns [x0, x1), particles owned / held incl. ghosts */
+int sphx_slab_info(const sphx_slab_group *g, int index, int *x0, int *x1, int *owned, int *held);
+/* owned particles of local slab `index` to host arrays of `capacity` particles (ids: original indices) */
+int sphx_slab_gather(sphx_slab_group *g, int index, int capacity, int *ids, float *pos_xyz, float *vel_xyz,
+                     float *density, int *count);
+/* iteration counts of the last DFSPH step (identical on every rank) */
+int sphx_slab_iters(const sphx_slab_group *g, int *divergence_iters, int *density_iters);
+/* the engine system of local slab `index` (for sphx_kernel_timer / sphx_device_ptr); owned by the group */
+int sphx_slab_system(const sphx_slab_group *g, int index, sphx_system **sys);
+/* seconds this process spent in host-side waits for exchanges since creation (diagnostic) */
+int sphx_slab_wait_seconds(const sphx_slab_group *g, double *seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_SLAB_H */

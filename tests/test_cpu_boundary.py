@@ -11,8 +11,8 @@ import pytest
 from conftest import ROOT, assert_bit_equal
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "sphx_c.h")).read()
+def _declared(header="sphx_c.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sphx_[a-z_0-9]+)\s*\(", text)))
 
@@ -24,6 +24,10 @@ def test_library_exports_every_declared_symbol(sphx):
     for nm in names:
         assert hasattr(L, nm), "libsphx.so does not export %s declared in include/sphx_c.h" % nm
     assert sorted(sphx.EXPORTS) == names, "sphx.py EXPORTS out of date with include/sphx_c.h"
+    slab = [nm for nm in _declared("sphx_slab.h") if nm.startswith("sphx_slab_") and nm != "sphx_slab_group"]
+    assert sorted(sphx.SLAB_EXPORTS) == slab, "sphx.py SLAB_EXPORTS out of date with include/sphx_slab.h"
+    for nm in slab:
+        assert hasattr(L, nm), "libsphx.so does not export %s declared in include/sphx_slab.h" % nm
     for nm in sphx.REFERENCE_EXPORTS:       # the reference's own extern "C" symbol (vbo.cu:46-51)
         assert hasattr(L, nm), "libsphx.so does not export the reference symbol %s" % nm
 
