@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the steady-state leg and the configs 2-4 legs")
     ap.add_argument("--settle-steps", type=int, default=300, help="steps advanced before the steady-state leg is timed")
     ap.add_argument("--steady-steps", type=int, default=100)
-    ap.add_argument("--force-slab", action="store_true", help="run the x-slab driver even with one rank (debug)")
+    ap.add_argument("--force-slab", action="store_true", help="run the x-slab layer with one process: --slabs loopback slabs on one device")
+    ap.add_argument("--slabs", type=int, default=1, help="with --force-slab: number of loopback slabs")
+    ap.add_argument("--no-overlap", action="store_true", help="slab layer: stage-then-exchange instead of edge-first stages")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -212,6 +214,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "SPHX_BENCH_DEVICE" in os.environ:        # probes that put several ranks on one device
+        local_rank = int(os.environ["SPHX_BENCH_DEVICE"])
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
 

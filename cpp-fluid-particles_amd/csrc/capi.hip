@@ -322,6 +322,7 @@ int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
     case SPHX_F_CG4: if (h->wcsph) { p = h->wcsph->engineCg4(); sz = 16 * n; } else known = false; break;
     case SPHX_F_PTERM: if (h->wcsph) { p = h->wcsph->enginePterm(); sz = 4 * n; } else known = false; break;
     case SPHX_F_POS4: if (h->wcsph) { p = h->wcsph->enginePos4(); sz = 16 * n; } else known = false; break;
+    case SPHX_F_POSF: if (h->wcsph) { p = h->wcsph->enginePosf(); sz = 16 * n; } else known = false; break;
     default: known = false; break;
     }
     if (!known) return SPHX_ERR_INVALID;

@@ -41,7 +41,7 @@ struct SweepCache {
     DArray<float> cg4;                       // float4 mirror of the colour gradient
     DArray<float> posf;                      // float4 (x, y, z, scalar neighbour field): one-gather sweeps
     DArray<int> massUniform;                 // device flag set by the pack pass: all fluid masses equal
-    bool allowPacked = true;                 // false for slab systems (their halo refresh targets the plain arrays)
+    bool allowPacked = true;                 // one-gather sweeps allowed (slab drivers refresh posf next to the scalar's own array)
     DArray<int> nbrCount;
     DArray<int> tileFmt;                     // per 64-particle tile: entry format of its rows (0 or 2)
     DArray<int> tileOrder;                   // launch schedule of the tiles (wave_tile)

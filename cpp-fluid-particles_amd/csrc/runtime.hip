@@ -471,7 +471,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
         c.tileOrder = nullptr;
     }
     c.posf = posfw();
-    c.massUniform = (allowPacked && cellOffsetX == 0) ? massUniform.addr() : nullptr;
+    c.massUniform = allowPacked ? massUniform.addr() : nullptr;
     return c;
 }
 

@@ -445,19 +445,19 @@ struct sphx_slab_group {
         exchangeParticles();
         runAll(SPHX_PH_SEARCH);
         updateLayers();
-        sweepStage(SPHX_PH_HEAD, {SPHX_F_KAPPA});
+        sweepStage(SPHX_PH_HEAD, {SPHX_F_KAPPA, SPHX_F_POSF});
         int itDiv = 0, itDen = 0;
         if (!adaptive) {
             for (; itDiv < v; ++itDiv) {
                 sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
-                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA});
+                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA, SPHX_F_POSF});
             }
         } else {       // DFSPHSolver.cu:347-361
             const float limit = global.dfsph_divergence_thr * (float)nGlobal * global.rho0;
             float total = 3.4028235e38f;
             while ((itDiv < 1 || total > limit) && itDiv < global.dfsph_max_iter) {
                 sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
-                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA}, true);
+                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA, SPHX_F_POSF}, true);
                 total = globalError();
                 ++itDiv;
             }
@@ -466,11 +466,11 @@ struct sphx_slab_group {
         sweepStage(SPHX_PH_VISC_COLOR, surface ? std::vector<int>{SPHX_F_CG4} : std::vector<int>{});
         sweepStage(SPHX_PH_SURFACE, {SPHX_F_VEL4});
         sweepStage(SPHX_PH_WARM_CORRECT, {SPHX_F_VEL4});
-        sweepStage(SPHX_PH_DEN_ERROR_SET, {SPHX_F_KAPPA});
+        sweepStage(SPHX_PH_DEN_ERROR_SET, {SPHX_F_KAPPA, SPHX_F_POSF});
         if (!adaptive) {
             for (; itDen < d; ++itDen) {
                 sweepStage(SPHX_PH_DEN_CORRECT, {SPHX_F_VEL4});
-                sweepStage(SPHX_PH_DEN_ERROR_ACC, itDen + 1 < d ? std::vector<int>{SPHX_F_KAPPA} : std::vector<int>{});
+                sweepStage(SPHX_PH_DEN_ERROR_ACC, itDen + 1 < d ? std::vector<int>{SPHX_F_KAPPA, SPHX_F_POSF} : std::vector<int>{});
             }
         } else {       // DFSPHSolver.cu:187-208
             const float limit = global.dfsph_density_thr * (float)nGlobal * global.rho0;
@@ -479,7 +479,7 @@ struct sphx_slab_group {
                 sweepStage(SPHX_PH_DEN_CORRECT, {SPHX_F_VEL4});
                 ++itDen;
                 const bool needTotal = itDen >= 2;
-                sweepStage(SPHX_PH_DEN_ERROR_ACC, {SPHX_F_KAPPA}, needTotal);
+                sweepStage(SPHX_PH_DEN_ERROR_ACC, {SPHX_F_KAPPA, SPHX_F_POSF}, needTotal);
                 if (needTotal) total = globalError();
             }
         }
@@ -494,7 +494,7 @@ struct sphx_slab_group {
         runAll(SPHX_PH_W_SEARCH);
         updateLayers();
         // W_PROPS writes the colour gradient (read by W_SURFACE) and the pressure term (read by W_PRESSURE)
-        sweepStage(SPHX_PH_W_PROPS, surface ? std::vector<int>{SPHX_F_CG4, SPHX_F_PTERM} : std::vector<int>{SPHX_F_PTERM});
+        sweepStage(SPHX_PH_W_PROPS, surface ? std::vector<int>{SPHX_F_CG4, SPHX_F_PTERM, SPHX_F_POSF} : std::vector<int>{SPHX_F_PTERM, SPHX_F_POSF});
         sweepStage(SPHX_PH_W_SURFACE, {});
         sweepStage(SPHX_PH_W_PRESSURE, {});
         runAll(SPHX_PH_ADVECT);
@@ -511,7 +511,7 @@ struct sphx_slab_group {
         const bool first = any.stepsDone == 0;
         if (first) return;
         for (int it = 0; it < global.pbd_iters; ++it) {
-            runAll(SPHX_PH_P_LAMBDA); postHalo({SPHX_F_LAMBDA}, false);
+            runAll(SPHX_PH_P_LAMBDA); postHalo({SPHX_F_LAMBDA, SPHX_F_POSF}, false);
             runAll(SPHX_PH_P_DELTA); postHalo({SPHX_F_POS4}, false);
         }
         runAll(SPHX_PH_P_VELOCITY); postHalo({SPHX_F_VEL4}, false);

@@ -30,11 +30,12 @@ void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
 void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void* BasicSPHSolver::enginePos4() const { return _cache->posm.addr(); }
+void* BasicSPHSolver::enginePosf() const { return _cache->posf.addr(); }
 const int* BasicSPHSolver::engineRowCounts() const { return _cache->nbrCount.addr(); }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
 void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }
-void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->allowPacked = false; }
+void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)

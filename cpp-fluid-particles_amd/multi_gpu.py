@@ -32,9 +32,12 @@ column may sit one column further out when it is swept, so PBD slabs keep TWO gh
 (still one contiguous range) and refresh lambda and the position mirror inside every Jacobi iteration,
 then the velocity mirror and the colour gradient: 2 * iters + 2 refreshes per step.
 
-Status this round: all three solvers; static cut planes chosen from the initial particle
-histogram; halo refreshes are not yet overlapped with interior work.  The driver is engine-agnostic: the HIP
-engine is the product; the CPU tests plug in a stand-in engine (tests/slab_cpu_engine.py) to exercise this file under gloo.
+Two host drivers implement this protocol.  The product path is the native layer csrc/slab.hip (C++, RCCL or
+loopback transport, device-side particle exchange, edge-first stages so that halo traffic overlaps the interior
+sweeps): run_slab_bench() below only bootstraps it (RCCL token, barriers).  The classes in this file are the
+protocol written against torch.distributed and an abstract engine: with the CPU stand-in engine of
+tests/slab_cpu_engine.py they exercise the N > 1 protocol under gloo on machines without a GPU
+(tests/test_slab_cpu.py), with HipSlabEngine they drive the HIP engine over gloo or RCCL.
 """
 import os
 import time
@@ -162,7 +165,8 @@ class HipSlabEngine:
 
         self.f = {"pos": view(sphx.F_POS, 3), "vel": view(sphx.F_VEL, 3), "ids": view(sphx.F_ID, 1, "<i4"),
                   "vel_nbr": view(sphx.F_VEL4, 4), "cg_nbr": view(sphx.F_CG4, 4), "density": view(sphx.F_DENSITY, 1),
-                  "pterm": view(sphx.F_PTERM, 1)}
+                  "pterm": view(sphx.F_PTERM, 1),
+                  "posf": view(sphx.F_POSF, 4)}      # (x, y, z, scalar): what the one-gather sweeps read from neighbours
         if params.solver == sphx.DFSPH:
             self.f["warm"] = view(sphx.F_WARM, 1)
             self.f["kappa"] = view(sphx.F_KAPPA, 1)
@@ -292,6 +296,9 @@ class SlabDriver:
         self.owned = (c[0], c[3])
 
     def _halo(self, name):
+        # scalars that one-gather sweeps read through the packed (x, y, z, scalar) records travel in that array too
+        if name in ("kappa", "pterm", "lambda") and self.e.has("posf"):
+            self._halo("posf")
         t0 = time.perf_counter() if self.timers is not None else 0.0
         c0, c1, c2, c3, c4 = self.layers
         e = self.e
@@ -464,51 +471,64 @@ def engine_count(drv):
     return int(drv.e.count)
 
 
+def _bootstrap(rank, world):
+    """a side channel for the 128-byte RCCL token and the closing barrier / max-over-ranks: a gloo group over TCP
+    (the data path itself never touches torch.distributed)"""
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
 def run_slab_bench(args, rank, world, local_rank):
-    """bench.py --gpus N (N > 1): the same global workload split into N x-slabs (strong scaling)."""
+    """bench.py --gpus N (N > 1): the same global workload split into N x-slabs (strong scaling), driven by the
+    native layer csrc/slab.hip: one process per GPU, RCCL point-to-point halos over xGMI, edge-first stages so that
+    halo traffic overlaps the interior sweeps.  With one process (--force-slab) `args.slabs` loopback slabs share
+    the device, which measures the decomposition's overhead without a second GPU."""
     import sphx
     torch.cuda.set_device(local_rank)
     sphx.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    sphx.use_stream(torch.cuda.current_stream().cuda_stream)
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=device)
     P, fluid, boundary = sphx.scene(args.nx)
     solver_name = getattr(args, "solver", "dfsph")
     P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver_name]
     P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, getattr(args, "pbd_iters", 4)
     if P.solver == sphx.WCSPH:
         P.dt = 0.001
-    # global boundary masses from a boundary-only whole-domain system (SPHSystem.cu:69-71)
-    bsys = sphx.System(P, np.zeros((0, 3), np.float32), boundary, ctor_step=False)
-    bpos, bmass = bsys.get(sphx.F_BPOS), bsys.get(sphx.F_BMASS)
-    bsys.close()
-
-    def make_engine(Pl, cap, bp, bm):
-        return HipSlabEngine(sphx, Pl, cap, bp, bm, device)
-
-    drv, cuts, counts = build_slab(make_engine, P, fluid, bpos, bmass, rank, world)
+    flags = sphx.SLAB_NO_OVERLAP if getattr(args, "no_overlap", False) else 0
+    if world > 1:
+        _bootstrap(rank, world)
+        token = [sphx.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(token, src=0)
+        group = sphx.SlabGroup(P, fluid, boundary, world, first_rank=rank, local_ranks=1, rccl_id=token[0], flags=flags)
+        slabs_here, transport = 1, "RCCL point-to-point (ncclSend/ncclRecv grouped per exchange) over xGMI"
+    else:
+        slabs_here = max(1, int(getattr(args, "slabs", 1)))
+        group = sphx.SlabGroup(P, fluid, boundary, slabs_here, flags=flags)
+        transport = "loopback (%d slabs on one device)" % slabs_here
     n_total = len(fluid)
-    drv.step()                                   # = the constructor step of the single-device path
+    group.step(1)                                # = the constructor step of the single-device path
     if P.solver == sphx.PBD:
-        drv.step()                               # PBD: the constructor step only records positions
-    for _ in range(args.warmup):
-        drv.step()
-    # live roofline leg (rank 0's slab): hipEvents around every launch of the dominant kernel on the
-    # stream the engine launches on (torch's current stream, handed over with sphx_use_stream)
+        group.step(1)                            # PBD: the constructor step only records positions
+    if args.warmup > 0:
+        group.step(args.warmup)
+    # live roofline leg (rank 0's slab): hipEvents around every launch of the dominant kernel on the engine stream
     span = "density_error"
     if rank == 0 and P.solver == sphx.DFSPH:
         sphx.kernel_timer(True, span)
-    active_sum = 0
-    dist.barrier(); torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv.step()
-        active_sum += engine_count(drv)
-    torch.cuda.synchronize(); dist.barrier()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    wall = float(wall.item())
+    group.step(args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
     if P.solver == sphx.DFSPH:
         bpp = 420 + 92 * args.div_iters + 104 * args.den_iters + 72
         what = "DFSPH(%d div + %d density iters, fixed)" % (args.div_iters, args.den_iters)
@@ -517,15 +537,18 @@ def run_slab_bench(args, rank, world, local_rank):
     else:
         bpp, what = 300 + 104 * P.pbd_iters + 72, "PBD(%d Jacobi iters)" % P.pbd_iters
     steps_per_s = args.steps / wall
-    halo_s = drv.timers.get("halo", 0.0) if drv.timers else None
+    infos = [group.info(i) for i in range(slabs_here)]
     result = {
-        "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s, "unit": "steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g"
+        "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s,
+        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic"
                                % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt),
-                   "particles": n_total, "decomposition": "%d x-slabs, cuts %s, initial particles per slab %s, %d-cell halos over RCCL p2p"
-                                                          % (world, cuts, counts, drv.g),
+                   "particles": n_total,
+                   "decomposition": "%d x-slabs; this process: columns %s, owned/held particles %s; transport %s; %s"
+                                    % (world if world > 1 else slabs_here, [(a, b) for a, b, _, _ in infos], [(o, h) for _, _, o, h in infos],
+                                       transport, "stage-then-exchange" if flags else "edge-first stages, halo overlapped with interior sweeps"),
+                   "host_wait_seconds_rank0": group.wait_seconds(),
                    "step_algorithmic_bytes_per_particle": bpp,
                    "step_algorithmic_GBps": bpp * n_total * steps_per_s / 1e9,
                    "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
@@ -536,13 +559,18 @@ def run_slab_bench(args, rank, world, local_rank):
         sphx.kernel_timer(False)
         if span in spans and spans[span][1] > 0:
             tot_ms, launches = spans[span]
-            avg_ms = tot_ms / launches
-            per_launch = 44.0 * active_sum / args.steps        # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
+            # a stage is launched on the two edge layers and the interior: one logical launch = 3 spans per slab
+            logical = launches / (3.0 if not flags else 1.0) / slabs_here
+            avg_ms = tot_ms / logical
+            owned = sum(o for _, _, o, _ in infos) / float(slabs_here)
+            per_launch = 44.0 * owned                                   # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s'), rank 0's slab incl. ghosts" % span,
+            result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s'), rank 0's slab, owned particles" % span,
                                   "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                                  "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                                  "traffic": None, "avg_launch_ms": avg_ms, "launches": logical,
                                   "algorithmic_bytes_per_launch": per_launch}
-    dist.barrier()
-    dist.destroy_process_group()
+    group.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return result

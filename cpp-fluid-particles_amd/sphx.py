@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SPHX_LIB", os.path.join(_HERE, "libsphx.so"))
 WCSPH, DFSPH, PBD = 0, 1, 2
 
 (F_POS, F_VEL, F_DENSITY, F_PRESSURE, F_MASS, F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID, F_BPOS,
- F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3, F_VEL4, F_CG4, F_PTERM, F_POS4) = range(22)
+ F_BMASS, F_ALPHA, F_KAPPA, F_ERROR, F_WARM, F_POS_LAST, F_LAMBDA, F_BUF3, F_VEL4, F_CG4, F_PTERM, F_POS4, F_POSF) = range(23)
 
 (PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
  PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE,

@@ -42,6 +42,7 @@ public:
     void* engineCg4() const;
     void* enginePterm() const;
     void* enginePos4() const;
+    void* enginePosf() const;
     // per-particle neighbour-row lengths of the most recent row build (bench statistics)
     const int* engineRowCounts() const;
     // reserve the boundary part of the engine's unified neighbour arrays (called once by SPHSystem

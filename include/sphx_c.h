@@ -90,6 +90,8 @@ typedef enum sphx_field {
     SPHX_F_CG4,            /* float[4n]  engine mirror of the colour gradient                  */
     SPHX_F_PTERM,          /* float[n]   p / max(EPS, rho^2), the neighbour term of the pressure force */
     SPHX_F_POS4,           /* float[4n]  engine mirror of pos (x,y,z,mass), what sweeps gather (PBD halo target) */
+    SPHX_F_POSF,           /* float[4n]  (x,y,z, scalar neighbour field: kappa / pressure term / lambda): what the one-gather
+                              sweeps read; halo target next to the scalar's own array */
     SPHX_F_COUNT_
 } sphx_field;
 

@@ -83,3 +83,22 @@ def test_native_slab_layer_rejects_bad_geometry(sphx):
         sphx.SlabGroup(P, fluid, boundary, 8)
     with pytest.raises(sphx.SphxError):
         sphx.SlabGroup(P, fluid, boundary, 2, first_rank=1, local_ranks=1)      # a single remote-less slab needs an RCCL token
+
+
+def test_native_slab_layer_rccl_transport_single_rank(sphx, oracle):
+    """the RCCL transport with a one-rank communicator (the test box has one GPU and RCCL refuses two ranks on one
+    device): library loading, ncclGetUniqueId / ncclCommInitRank, the communication stream and events, and
+    ncclAllReduce of the adaptive termination sum all run; the result still equals the oracle"""
+    nx, steps, seed = 12, 5, 23
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, "dfsph", True)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    g = sphx.SlabGroup(P, pos, boundary, 1, first_rank=0, local_ranks=1, rccl_id=sphx.rccl_unique_id(), velocity=vel)
+    for _ in range(steps):
+        g.step()
+    ids, p, v, d = g.gather_all()
+    it = g.iters()
+    g.close()
+    rp, rv, rd, rit = _single_domain(oracle, nx, steps, seed, "dfsph", True, want_iters=True)
+    assert_bit_equal(p, rp, "rccl(1) pos"); assert_bit_equal(d, rd, "rccl(1) density")
+    assert it == rit
