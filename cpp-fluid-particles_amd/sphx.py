@@ -32,7 +32,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
-    "sphx_get_params", "sphx_row_stats",
+    "sphx_get_params", "sphx_row_stats", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -226,6 +226,35 @@ class System:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------ obstacle samplers
+def _sample(fn, *args):
+    n = C.c_int()
+    _check(fn(*args, None, 0, C.byref(n)))
+    out = np.empty((n.value, 3), np.float32)
+    _check(fn(*args, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+    return out
+
+
+def sample_box(lo, hi, spacing):
+    """boundary particles on the surface of the axis-aligned box [lo, hi] (sphx_sample_box)"""
+    f = lib().sphx_sample_box
+    f.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return _sample(f, (C.c_float * 3)(*lo), (C.c_float * 3)(*hi), C.c_float(spacing))
+
+
+def sample_sphere(center, radius, spacing):
+    f = lib().sphx_sample_sphere
+    f.argtypes = [C.c_float * 3, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return _sample(f, (C.c_float * 3)(*center), C.c_float(radius), C.c_float(spacing))
+
+
+def sample_triangles(tri, spacing):
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    f = lib().sphx_sample_triangles
+    f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return _sample(f, C.c_void_p(tri.ctypes.data), len(tri), C.c_float(spacing))
 
 
 # ------------------------------------------------------------------------------------ native slab layer

@@ -223,6 +223,15 @@ int  sphx_fastmath_selftest(float radius, unsigned long long samples, unsigned i
  * SPHParticles>)` (vbo.cu:46-51; C++ callers declare it as main.cpp:268 does).                  */
 int  sphx_generate_dots(const sphx_system *sys, float *device_dot, float *device_color);
 
+/* Boundary particles for static obstacles (the step upstream of the path).  The reference
+ * samples one shape, the shell of the domain box (main.cpp:89-116); sphx_create turns ANY boundary set into
+ * masses with the reference's formula (computeBoundaryMass_CUDA, SPHSystem.cu:79-112).  These host-side,
+ * deterministic samplers produce particle layers for other shapes, to be appended to the shell before
+ * sphx_create.  Two-call protocol: out_xyz = NULL returns the count only.                          */
+int  sphx_sample_box(const float lo[3], const float hi[3], float spacing, float *out_xyz, int capacity, int *count);
+int  sphx_sample_sphere(const float center[3], float radius, float spacing, float *out_xyz, int capacity, int *count);
+int  sphx_sample_triangles(const float *tri_xyz, int n_triangles, float spacing, float *out_xyz, int capacity, int *count);
+
 /* State snapshots (checkpoint / resume and fixture I/O; the reference has none).
  * save: positions, velocities, ids, density, pressure in the CURRENT array order, the boundary set with
  * its masses, and the solver's persistent array (DFSPH warm stiffness / PBD last positions), in one

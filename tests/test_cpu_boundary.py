@@ -93,3 +93,42 @@ def test_product_never_references_the_oracle():
                 if f.endswith((".hip", ".hpp", ".h", ".py", ".cpp")) or f == "Makefile":
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "sph_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_obstacle_samplers(sphx):
+    """host-side boundary samplers for static obstacles (§8f-4): box lattice equals an independent numpy
+    restatement, sphere and triangle samples lie on their surfaces and are nowhere sparser than the spacing"""
+    lo, hi, h = np.float32([0.40, 0.0, 0.10]), np.float32([0.46, 0.15, 0.40]), np.float32(0.02)
+    got = sphx.sample_box(lo, hi, h)
+    n = [max(1, int(np.ceil((hi[a] - lo[a]) / h - 1e-4))) for a in range(3)]
+    ax = [lo[a] + (hi[a] - lo[a]) * (np.arange(n[a] + 1, dtype=np.float32) / np.float32(n[a])) for a in range(3)]
+    want = []
+    for a in range(n[0] + 1):
+        for b in range(n[1] + 1):
+            want += [(ax[0][a], ax[1][b], lo[2]), (ax[0][a], ax[1][b], hi[2])]
+    for a in range(n[0] + 1):
+        for c in range(1, n[2]):
+            want += [(ax[0][a], lo[1], ax[2][c]), (ax[0][a], hi[1], ax[2][c])]
+    for b in range(1, n[1]):
+        for c in range(1, n[2]):
+            want += [(lo[0], ax[1][b], ax[2][c]), (hi[0], ax[1][b], ax[2][c])]
+    assert_bit_equal(got, np.array(want, np.float32), "box sampler")
+    assert len(np.unique(got, axis=0)) == len(got), "edges and corners exactly once"
+
+    c, r = np.float32([0.25, 0.3, 0.25]), np.float32(0.05)
+    s = sphx.sample_sphere(c, r, 0.01)
+    assert np.abs(np.linalg.norm(s - c, axis=1) - r).max() < 1e-6
+    d = np.linalg.norm(s[:, None, :] - s[None, :, :], axis=2) + np.eye(len(s)) * 9
+    assert d.min(axis=1).max() <= 0.0101 and d.min() > 0.002, "no holes wider than the spacing, no duplicates"
+
+    tri = np.float32([[0, 0, 0, 0.1, 0, 0, 0, 0.1, 0.02], [0.1, 0, 0, 0.1, 0.1, 0.02, 0, 0.1, 0.02]])
+    t = sphx.sample_triangles(tri, 0.02)
+    nrm = np.cross(tri[0, 3:6] - tri[0, 0:3], tri[0, 6:9] - tri[0, 0:3]); nrm /= np.linalg.norm(nrm)
+    on0 = np.abs((t - tri[0, 0:3]) @ nrm) < 1e-6
+    nrm1 = np.cross(tri[1, 3:6] - tri[1, 0:3], tri[1, 6:9] - tri[1, 0:3]); nrm1 /= np.linalg.norm(nrm1)
+    on1 = np.abs((t - tri[1, 0:3]) @ nrm1) < 1e-6
+    assert (on0 | on1).all()
+    d = np.linalg.norm(t[:, None, :] - t[None, :, :], axis=2) + np.eye(len(t)) * 9
+    assert d.min() > 0.02 / 8 and d.min(axis=1).max() <= 0.0205
+    with pytest.raises(sphx.SphxError):
+        sphx.sample_sphere(c, -1.0, 0.01)

@@ -211,6 +211,40 @@ def test_edge_cases_no_boundary_and_out_of_grid(sphx, oracle):
         compare(sphx, oracle, gs, os_, names, "edge step %d" % s)
 
 
+@pytest.mark.parametrize("solver", [0, 1])
+def test_static_obstacles_boundary_mass_and_trajectory(sphx, oracle, solver):
+    """§8f-4: a box, a sphere and a triangle-soup ramp sampled into boundary particles and appended to the shell;
+    the boundary grid, the boundary masses (SPHSystem.cu:79-112 on a non-shell set) and the fluid trajectory
+    falling onto them equal the oracle bit for bit"""
+    P, fluid, shell = sphx.scene(12)
+    P.solver = solver
+    P.dt = 0.001 if solver == 0 else 0.002
+    box = sphx.sample_box((0.40, 0.0, 0.10), (0.46, 0.15, 0.40), 0.02)
+    ball = sphx.sample_sphere((0.25, 0.02, 0.25), 0.018, 0.01)
+    ramp = sphx.sample_triangles(np.float32([[0.05, 0.0, 0.05, 0.13, 0.0, 0.05, 0.05, 0.06, 0.45],
+                                             [0.13, 0.0, 0.05, 0.13, 0.06, 0.45, 0.05, 0.06, 0.45]]), 0.02)
+    boundary = np.concatenate([shell, box, ball, ramp]).astype(np.float32)
+    assert len(boundary) > len(shell) + 400
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, fluid, boundary, ctor_step=False)
+    os_ = oracle.System(Po, fluid, boundary, ctor_step=False)
+    compare(sphx, oracle, gs, os_, ["CELLSTART_B", "BPOS", "BMASS", "CELL", "CELLSTART_F", "ID"], "obstacle init")
+    bm = gs.get(sphx.F_BMASS)
+    assert np.isfinite(bm).all() and bm.min() > 0
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else [])
+    vel = np.zeros_like(fluid); vel[:, 1] = -1.5; vel[:, 0] = 0.8          # drive the block into the obstacles
+    ids = gs.get(sphx.F_ID)
+    gs.set(sphx.F_VEL, vel[ids]); os_.set(oracle.F_VEL, vel[ids])
+    touched = False
+    for s in range(12):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, names, "obstacles solver %d step %d" % (solver, s + 1))
+    # the fluid did meet the obstacle particles: some rows contain boundary neighbours beyond the shell's reach
+    pos = gs.get(sphx.F_POS)
+    d = np.linalg.norm(pos[:, None, :] - ball[None, ::4, :], axis=2).min()
+    assert d < 0.04, "the block must come within the support radius of the sphere obstacle"
+
+
 def test_single_particle(sphx, oracle):
     P, fluid, boundary = sphx.scene(8)
     P.solver = sphx.DFSPH
