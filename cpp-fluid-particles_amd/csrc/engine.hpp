@@ -65,6 +65,15 @@ struct SweepCache {
     // traffic overlaps the interior): particles [rangeLo, rangeHi) of the next launches; -1 = all
     int rangeLo = -1, rangeHi = -1;
     bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
+    // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps
+    // re-test every pair against the true support, `staleFlag` (device) is raised by the position update when a
+    // particle has moved more than 0.45 * skin since the build (then every sweep walks the cells directly).
+    bool skinRows = false;
+    bool isSlab = false;
+    float skin = 0.0f;                       // absolute length
+    std::unique_ptr<DArray<float>> posBuild; // (x, y, z, -) of every fluid particle when the rows were built
+    DArray<int> staleFlag;
+    float staleLimit2() const { return (0.45f * skin) * (0.45f * skin); }
     bool fluidValid = false;
     bool boundaryValid = false;
     bool listValid = false;

@@ -4,6 +4,8 @@
 // Jacobi iterations on a fixed cell table while positions move, velocity from displacement, XSPH,
 // surface effects, gravity, then predict.  XSPH writes to a separate buffer (Jacobi) instead of
 // the reference's racy in-place update.
+#include <cstdlib>
+
 #include "PBDSolver.h"
 #include "sphx_c.h"
 #include "engine.hpp"
@@ -33,6 +35,17 @@ void PBDSolver::initializePosLast(const DArray<float3>& posFluid)
 {
     ew_copy(fluidPosLast.addr(), posFluid.addr(), sizeof(float3) * fluidPosLast.length());
     posLastInitialized = true;
+}
+
+// One row build per step instead of one per Jacobi iteration: rows with a skin (engine.hpp).  Whole-domain systems
+// only: a slab's ghost particles move by halo messages, which the displacement watch does not see.
+void PBDSolver::configureSkin(float radius)
+{
+    SweepCache& c = cache();
+    float factor = 0.1f;
+    if (const char* e = getenv("SPHX_PBD_SKIN")) factor = (float)atof(e);
+    c.skinRows = !c.isSlab && factor > 0.0f;
+    c.skin = c.skinRows ? factor * radius : 0.0f;
 }
 
 // PBDSolver::updateNeighborhood, PBDSolver.cu:81-87: carry last positions through this step's sort
@@ -86,12 +99,23 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         }
         {
             ScopedKernel t("pbd_apply_clamp");   // keeps the packed position view in step with pos
-            launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num);
-            c.listValid = false;
+            applyDelta(fluids, spaceSize, num);
         }
         ++iter;
     }
     return iter;
+}
+
+// pos += delta-p with the box clamp (PBDSolver.cu:212-223, :247-253).  Ordinary rows are invalid afterwards; skin
+// rows stay, the update itself watches how far particles have moved since the build.
+void PBDSolver::applyDelta(std::shared_ptr<SPHParticles>& fluids, float3 spaceSize, int num)
+{
+    SweepCache& c = cache();
+    const bool skin = c.skinRows && c.skin > 0.0f && c.listValid && c.posBuild;
+    launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num,
+                             skin ? reinterpret_cast<const float4*>(c.posBuild->addr()) : nullptr, skin ? c.staleFlag.addr() : nullptr,
+                             c.staleLimit2());
+    if (!skin) c.listValid = false;
 }
 
 // PBDSolver::predict, PBDSolver.cu:75-79
@@ -115,6 +139,7 @@ void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_pt
     invalidatePositions();
     SweepCache& c = cache();
     c.allowTiles = false;   // PBD sweeps run on positions that moved after binning
+    configureSkin(radius);
     const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
     const int num = (int)fluids->size();
     updateNeighborhood(fluids);
@@ -212,8 +237,7 @@ void PBDSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const
             launch_op(OpDeltaPos{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true}, num);
         }
         ScopedKernel t("pbd_apply_clamp");
-        launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num);
-        c.listValid = false;
+        applyDelta(fluids, spaceSize, num);
         break;
     }
     case SPHX_PH_P_XSPH: {

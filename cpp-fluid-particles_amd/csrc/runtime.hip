@@ -370,7 +370,8 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
-      tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num)
+      tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
+      staleFlag(1u)
 {
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
@@ -471,6 +472,10 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
         c.tileOrder = nullptr;
     }
     c.posf = posfw();
+    const bool skinNow = skinRows && skin > 0.0f && use;
+    c.stale = skinNow ? staleFlag.addr() : nullptr;
+    c.buildCut = k.tCut;
+    if (skinRows && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
     return c;
 }
@@ -497,6 +502,11 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
         k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
     else
         k_build_list<false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
+    if (skinRows && skin > 0.0f) {          // remember where every particle was: the position updates measure against it
+        if (!posBuild) { posBuild.reset(new DArray<float>(4u * (unsigned)capN)); ++generation; }
+        HIP_CALL(hipMemsetAsync(staleFlag.addr(), 0, sizeof(int), stream()));
+        ew_copy(posBuild->addr(), posm.addr(), sizeof(float) * 4u * (size_t)n);
+    }
     listValid = true;
 }
 

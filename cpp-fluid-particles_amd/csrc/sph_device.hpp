@@ -314,6 +314,13 @@ struct SweepCtx {
     float4* posf;                           // (x, y, z, scalar field): position AND the neighbour scalar in one gather
     const int* massUniform;                 // device flag: 1 when every fluid particle has the mass of particle 0
     const int* tileOrder;                   // schedule: the tile each launched wave works on (nullptr: identity)
+    // Skin rows (PBD): the rows were built once per step with the enlarged cutoff `buildCut`, positions have moved
+    // since (Jacobi iterations on a fixed cell table, PBDSolver.cu:225-258).  Every pair re-tests its CURRENT squared
+    // distance against tCut (beyond it every kernel is exactly +0, so skipping is exact) and re-derives its plain-ops
+    // predicate.  `stale` (device flag) is raised when some particle moved farther than half the skin since the
+    // build: the rows may then miss a pair, and every sweep walks the cells directly until the next build.
+    const int* stale;                       // nullptr: ordinary rows (positions frozen since the build)
+    float buildCut;                         // squared cutoff the row builder accepts candidates with
     int numTiles;                           // tiles this launch covers
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
@@ -462,7 +469,7 @@ __device__ __forceinline__ void pair_dispatch(Body& body, const bool plain, cons
 #ifndef SPHX_AHEAD
 #define SPHX_AHEAD 4
 #endif
-template <bool PACKED, bool WANT_BOUNDARY, class Op, class Body>
+template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, class Op, class Body>
 __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ row, const int cnt,
                                          const float m0, const bool allPlain, const float3 pi, Body& body)
 {
@@ -481,7 +488,10 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
             const bool isB = (e[u] & kBoundaryBit) != 0u;
             if (!WANT_BOUNDARY && isB) continue;
             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
-            pair_dispatch(body, allPlain || (e[u] & kPlainBit) != 0u, f[u], isB, d, dot3(d, d), pj[u].w, (int)(e[u] & kIndexMask));
+            const float r2 = dot3(d, d);
+            if (SKIN && r2 > c.k.tCut) continue;
+            const bool plain = SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u;
+            pair_dispatch(body, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
         }
     }
     for (; t < cnt; ++t) {
@@ -491,7 +501,10 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
         float4 pj; typename Op::Field fj;
         fetch_pair<PACKED, Op>(op, c, m0, e, pj, fj);
         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-        pair_dispatch(body, allPlain || (e & kPlainBit) != 0u, fj, isB, d, dot3(d, d), pj.w, (int)(e & kIndexMask));
+        const float r2 = dot3(d, d);
+        if (SKIN && r2 > c.k.tCut) continue;
+        const bool plain = SKIN ? pair_needs_plain_ops(d, r2) : (e & kPlainBit) != 0u;
+        pair_dispatch(body, allPlain || plain, fj, isB, d, r2, pj.w, (int)(e & kIndexMask));
     }
 }
 
@@ -504,7 +517,8 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                                       const int i, const bool valid, const float3 pi, Body& body)
 {
     const int lane = threadIdx.x & 63;
-    const bool rows = c.nbr != nullptr;
+    const bool skin = c.stale != nullptr;
+    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);    // stale skin rows: direct walks (launch-uniform)
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     const bool useRow = rows && valid && cnt <= c.cap;
@@ -557,8 +571,13 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
     if (useRow) {
         // one-gather mode is uniform over the launch: two separate loops, so that each keeps its
         // single 16-byte gather per neighbour (a merged loop makes the compiler split the loads)
-        if (packed) walk_row<true, WANT_BOUNDARY>(op, c, row, cnt, m0, allPlain, pi, body);
-        else walk_row<false, WANT_BOUNDARY>(op, c, row, cnt, m0, allPlain, pi, body);
+        if (skin) {
+            if (packed) walk_row<true, WANT_BOUNDARY, true>(op, c, row, cnt, m0, allPlain, pi, body);
+            else walk_row<false, WANT_BOUNDARY, true>(op, c, row, cnt, m0, allPlain, pi, body);
+        } else {
+            if (packed) walk_row<true, WANT_BOUNDARY, false>(op, c, row, cnt, m0, allPlain, pi, body);
+            else walk_row<false, WANT_BOUNDARY, false>(op, c, row, cnt, m0, allPlain, pi, body);
+        }
         return;
     }
     walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
@@ -630,7 +649,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                         for (int u = 0; u < 4; ++u) {
                             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
                             const float r2 = dot3(d, d);
-                            if (r2 > c.k.tCut || j + u == i) continue;
+                            if (r2 > c.buildCut || j + u == i) continue;
                             if (cnt < c.cap)
                                 row[(size_t)cnt * 64u] = (unsigned int)(j + u + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
                             ++cnt;
@@ -640,7 +659,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                         const float4 pj = streamed ? ldsPos[j + fShift] : c.posm[j];
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                         const float r2 = dot3(d, d);
-                        if (r2 > c.k.tCut || j == i) continue;
+                        if (r2 > c.buildCut || j == i) continue;
                         if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);
                         ++cnt;
                     }
@@ -650,7 +669,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                             const float4 pj = streamed ? ldsPos[j + bShift] : c.bposm[j];
                             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                             const float r2 = dot3(d, d);
-                            if (r2 > c.k.tCut) continue;
+                            if (r2 > c.buildCut) continue;
                             if (cnt < c.cap) row[(size_t)cnt * 64u] = (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u);   // bShift: + bOff (fmt 0)
                             ++cnt;
                         }

@@ -495,8 +495,11 @@ static __global__ void k_kick_remember_advect(float3* __restrict__ pos, float3* 
     vel[i] = v;
 }
 // pos += deltaPos; enforceBoundary_CUDA(pos): PBDSolver.cu:212-223, :247-253 (also refreshes posm)
+// With skin rows (posBuild != nullptr) the update also checks how far the particle is from where the rows were
+// built; beyond the limit the rows may miss a pair and `stale` sends every later sweep to the direct cell walk.
 static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __restrict__ posm, float4* __restrict__ posf,
-                                           const float3* __restrict__ dpos, float3 space, int n)
+                                           const float3* __restrict__ dpos, float3 space, int n,
+                                           const float4* __restrict__ posBuild, int* __restrict__ stale, float limit2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -506,6 +509,10 @@ static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __r
     pos[i] = p;
     posm[i] = make_float4(p.x, p.y, p.z, posm[i].w);
     posf[i] = make_float4(p.x, p.y, p.z, 0.0f);
+    if (posBuild) {
+        const float3 d = sub3(p, xyz(posBuild[i]));
+        if (!(dot3(d, d) <= limit2)) *stale = 1;      // also raised for a NaN
+    }
 }
 // vel = (pos - posLast) / dt, PBDSolver.cu:55-60
 static __global__ void k_velocity_from_displacement(float3* __restrict__ vel, float4* __restrict__ vel4,
@@ -543,9 +550,10 @@ inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLas
 {
     if (n > 0) k_kick_remember_advect<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, posLast, dv, dt, space, n);
 }
-inline void launch_apply_delta_clamp(float3* pos, float4* posm, float4* posf, const float3* dpos, float3 space, int n)
+inline void launch_apply_delta_clamp(float3* pos, float4* posm, float4* posf, const float3* dpos, float3 space, int n,
+                                     const float4* posBuild = nullptr, int* stale = nullptr, float limit2 = 0.0f)
 {
-    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n);
+    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n, posBuild, stale, limit2);
 }
 inline void launch_velocity_from_displacement(float3* vel, float4* vel4, const float3* pos, const float3* posLast, float dt, int n)
 {

@@ -89,15 +89,35 @@ struct StepGraph {
 
 // mapParticles2Cells_CUDA + countingInCell_CUDA (CUDAFunctions.cuh:56-78) fused: cell id by true
 // fp32 division and truncation, histogram by atomics; the returned arrival slot is remembered.
-__global__ void k_cell_and_count(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts,
-                                 const float3* __restrict__ pos, GridDesc g, int n)
+// The input is nearly cell-sorted (it was sorted one step ago), so neighbouring lanes mostly hit the same cell: one
+// atomic per RUN of equal ids inside a wave, the run's lanes take consecutive slots (any slot assignment inside a
+// cell is acceptable here: the stable rank fix-up below restores the reference's order).
+__global__ void __launch_bounds__(256) k_cell_and_count(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts,
+                                                        const float3* __restrict__ pos, GridDesc g, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int3 c = cell_of(pos[i], g);
-    const int id = cell_id(c.x, c.y, c.z, g);
-    p2c[i] = id;
-    slot[i] = atomicAdd(&counts[id], 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    int id = -1;
+    if (valid) {
+        const int3 c = cell_of(pos[i], g);
+        id = cell_id(c.x, c.y, c.z, g);
+        p2c[i] = id;
+    }
+    const int prev = __shfl_up(id, 1, 64);
+    const bool head = valid && (lane == 0 || prev != id);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long live = __ballot(valid);
+    if (!valid) return;
+    // my run: from the closest head at or below my lane up to the lane before the next head (or the last live lane)
+    const unsigned long long below = heads & (~0ull >> (63 - lane));
+    const int first = 63 - __builtin_clzll(below);
+    const unsigned long long above = heads & ~(~0ull >> (63 - lane));            // heads strictly above me
+    const int end = above ? __builtin_ctzll(above) : (64 - __builtin_clzll(live));   // one past the run's last lane
+    int base = 0;
+    if (head) base = atomicAdd(&counts[id], end - first);
+    base = __shfl(base, first, 64);
+    slot[i] = base + (lane - first);
 }
 
 // ---- exclusive scan over C+1 ints (replaces thrust::exclusive_scan, SPHSystem.cu:125) ----------

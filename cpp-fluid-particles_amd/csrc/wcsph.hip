@@ -35,7 +35,7 @@ const int* BasicSPHSolver::engineRowCounts() const { return _cache->nbrCount.add
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
 void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }
-void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; }
+void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true; }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)

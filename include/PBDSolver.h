@@ -51,6 +51,8 @@ protected:
 
 private:
     void updateNeighborhood(const std::shared_ptr<SPHParticles>& particles);
+    void applyDelta(std::shared_ptr<SPHParticles>& fluids, float3 spaceSize, int num);
+    void configureSkin(float radius);
 
     bool posLastInitialized = false;
     const int maxIter;

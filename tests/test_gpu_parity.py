@@ -168,6 +168,32 @@ def test_tile_schedule_is_only_a_schedule(sphx, oracle, solver, monkeypatch):
         compare(sphx, oracle, gs, os_, names, "tile schedule solver %d step %d" % (solver, s + 1))
 
 
+@pytest.mark.parametrize("skin", ["0", "0.002", "0.1", "0.4"])
+def test_pbd_skin_rows_are_exact(sphx, oracle, skin, monkeypatch):
+    """PBD builds its neighbour rows once per step with an enlarged cutoff (skin) and re-tests every pair per sweep;
+    when a particle moves farther than the skin allows, a device flag sends the sweeps to direct cell walks.
+    skin 0 = a rebuild per Jacobi iteration (the r01 behaviour); 0.002 R = practically always stale; 0.1 R = the
+    default; 0.4 R = long rows.  All equal the oracle bit for bit on a violent splash."""
+    monkeypatch.setenv("SPHX_PBD_SKIN", skin)
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.PBD; P.pbd_iters = 5; P.dt = 0.002
+    pos, vel = _splash_state(len(fluid), P, 333)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    gs.step(); os_.step()                        # records the positions (PBDSolver.cu:45-49)
+    ids = gs.get(sphx.F_ID)
+    last = (pos - np.float32(P.dt) * vel).astype(np.float32)[ids]     # velocities enter through the last positions
+    gs.set(sphx.F_POS_LAST, last); os_.set(oracle.F_POS_LAST, last)
+    for s in range(5):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "skin %s step %d" % (skin, s + 1))
+    gs.step_n(3)
+    for _ in range(3):
+        os_.step()
+    compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "skin %s graph replay" % skin)
+
+
 def test_dfsph_fixed_iterations_and_graph_replay(sphx, oracle):
     """fixed (v=1, d=4) mode: step_n replays a captured hipGraph; results equal eager stepping."""
     def tweak(P):

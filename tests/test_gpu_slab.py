@@ -85,20 +85,28 @@ def test_native_slab_layer_rejects_bad_geometry(sphx):
         sphx.SlabGroup(P, fluid, boundary, 2, first_rank=1, local_ranks=1)      # a single remote-less slab needs an RCCL token
 
 
-def test_native_slab_layer_rccl_transport_single_rank(sphx, oracle):
+def test_native_slab_layer_rccl_transport_single_rank(oracle, tmp_path):
     """the RCCL transport with a one-rank communicator (the test box has one GPU and RCCL refuses two ranks on one
     device): library loading, ncclGetUniqueId / ncclCommInitRank, the communication stream and events, and
-    ncclAllReduce of the adaptive termination sum all run; the result still equals the oracle"""
+    ncclAllReduce of the adaptive termination sum all run; the result still equals the oracle.  Runs in a fresh
+    process that imports torch first, as bench.py does: RCCL must bind to the HIP runtime the engine uses."""
+    import os, subprocess, sys
     nx, steps, seed = 12, 5, 23
-    P, fluid, boundary = sphx.scene(nx)
-    slab_worker.configure(P, sphx, "dfsph", True)
-    pos, vel = slab_worker.splash(len(fluid), P, seed)
-    g = sphx.SlabGroup(P, pos, boundary, 1, first_rank=0, local_ranks=1, rccl_id=sphx.rccl_unique_id(), velocity=vel)
-    for _ in range(steps):
-        g.step()
-    ids, p, v, d = g.gather_all()
-    it = g.iters()
-    g.close()
+    out = str(tmp_path / "rccl1.npz")
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "import sphx, slab_worker\n"
+        "P, fluid, boundary = sphx.scene(%d)\n"
+        "slab_worker.configure(P, sphx, 'dfsph', True)\n"
+        "pos, vel = slab_worker.splash(len(fluid), P, %d)\n"
+        "g = sphx.SlabGroup(P, pos, boundary, 1, first_rank=0, local_ranks=1, rccl_id=sphx.rccl_unique_id(), velocity=vel)\n"
+        "g.step(%d)\n"
+        "ids, p, v, d = g.gather_all()\n"
+        "np.savez(%r, pos=p, density=d, iters=np.array(g.iters()))\n"
+    ) % (os.path.join(slab_worker.ROOT, "cpp-fluid-particles_amd"), os.path.join(slab_worker.ROOT, "tests"), slab_worker.ROOT, nx, seed, steps, out)
+    subprocess.check_call([sys.executable, "-c", code])
+    z = np.load(out)
     rp, rv, rd, rit = _single_domain(oracle, nx, steps, seed, "dfsph", True, want_iters=True)
-    assert_bit_equal(p, rp, "rccl(1) pos"); assert_bit_equal(d, rd, "rccl(1) density")
-    assert it == rit
+    assert_bit_equal(z["pos"], rp, "rccl(1) pos"); assert_bit_equal(z["density"], rd, "rccl(1) density")
+    assert tuple(z["iters"]) == rit
