@@ -195,6 +195,8 @@ int sphx_create_impl(const sphx_params* P, const float* fluid, int n, const floa
     default: return fail(SPHX_ERR_INVALID, "sphx_create: unknown solver");
     }
     if (P->reserved[0]) h->wcsph->setEngineFlags(P->reserved[0]);
+    if (P->reserved[3] != 0 && P->reserved[3] != 1) return fail(SPHX_ERR_INVALID, "sphx_create: reserved[3] (arithmetic) must be 0 (strict) or 1 (tolerance)");
+    if (P->reserved[3] == 1) h->wcsph->setToleranceArithmetic(true);
     const float3 space = make_float3(P->space[0], P->space[1], P->space[2]);
     const float3 G = make_float3(P->gravity[0], P->gravity[1], P->gravity[2]);
     const int3 cells = make_int3(P->cells[0], P->cells[1], P->cells[2]);

@@ -68,6 +68,7 @@ struct SweepCache {
     // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps
     // re-test every pair against the true support, `staleFlag` (device) is raised by the position update when a
     // particle has moved more than 0.45 * skin since the build (then every sweep walks the cells directly).
+    bool tolerance = false;                  // row walks use the tolerance arithmetic (sph_device.hpp)
     bool skinRows = false;
     bool isSlab = false;
     float skin = 0.0f;                       // absolute length

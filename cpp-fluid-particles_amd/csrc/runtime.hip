@@ -75,6 +75,11 @@ KernelConsts make_kernel_consts(float R)
     k.rcpR = 1.0f / R;
     k.fastQ = 0;
     k.fastDiv = 0;
+    k.tol = 0;
+    k.twoOverR = 2.0f / R;
+    k.gradScale = 1.0f / (kPi * R * R * R * R * R);
+    k.viscScale = 45.0f / k.viscDen;
+    k.stScale = 136.0241f / k.stK;
     return k;
 }
 
@@ -451,6 +456,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
 {
     SweepCtx c;
     c.g = g; c.k = k;
+    c.k.tol = tolerance ? 1 : 0;
     c.csF = csF.addr(); c.posm = fluid4();
     c.csB = csB.addr(); c.bposm = boundary4(); c.bOff = capN;
     const bool use = listValid && nbr && !(flags & kFlagNoList);

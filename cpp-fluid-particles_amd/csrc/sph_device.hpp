@@ -30,6 +30,12 @@ struct KernelConsts {
     int fastQ;      // 1: x/R == fma-refined x*rcpR for EVERY float x in [0, 2.2R] (checked exhaustively)
     int fastDiv;    // 1: the denominators of gradW / surface gradient stay inside [2^-90, 2^16]
     int q2Free;     // 1: r2 <= tCut implies q <= 2 and r <= R, i.e. row entries never fail a support test
+    // --- tolerance arithmetic (sphx_params.reserved[3] = 1): hardware rsq / rcp, fused multiply-adds, constants folded
+    int tol;        // 1: row walks use the pair_tol bodies
+    float twoOverR;     // 2 / R
+    float gradScale;    // 1 / (PI R^5)
+    float viscScale;    // 45 / (PI R^6)
+    float stScale;      // 136.0241 / (PI R^9)
 };
 
 struct GridDesc {
@@ -169,6 +175,53 @@ __device__ __forceinline__ float3 kSurfGrad(float3 d, float x, const KernelConst
     const float3 a = div3_sel<FAST>(smul3(136.0241f, neg3(d)), outside ? 1.0f : k.stK * x);
     const float3 g = mul3s(a, (2.0f * x <= k.R) ? (2.0f * cube(k.R - x) * cube(x) - k.stC) : (cube(k.R - x) * cube(x)));
     return outside ? v3(0.0f, 0.0f, 0.0f) : g;
+}
+
+// ---- tolerance arithmetic ---------------------------------------------------------------------------------------
+// The same formulas with v_rsq_f32 / v_rcp_f32 (1 ulp), contraction into FMAs and folded constants: relative
+// deviations of a few 1e-7 per pair term from the strict path (the reference binary itself is built with
+// -use_fast_math, src/CMakeLists.txt:43).  Only the row walks use it; support tests are unchanged because the rows
+// were built with the exact threshold.  tests/test_gpu_tolerance.py bounds the deviation from the oracle.
+struct TolPair { float r, q, rcpq; };      // |d|, 2|d|/R, 1/(q + EPS)
+__device__ __forceinline__ TolPair tol_pair(float r2, const KernelConsts& k)
+{
+#pragma clang fp contract(fast)
+    TolPair t;
+    t.r = r2 * __builtin_amdgcn_rsqf(fmaxf(r2, 1.0e-36f));
+    t.q = t.r * k.twoOverR;
+    t.rcpq = __builtin_amdgcn_rcpf(t.q + kEps);
+    return t;
+}
+// W (CUDAFunctions.cuh:23-35)
+__device__ __forceinline__ float tol_W(const TolPair& t, const KernelConsts& k)
+{
+#pragma clang fp contract(fast)
+    const float a = 2.0f - t.q;
+    const float w = k.wA * ((t.q > 1.0f) ? a * a * a : ((3.0f * t.q - 6.0f) * t.q * t.q + 4.0f));
+    return (t.q < kEps) ? 0.0f : w;
+}
+// gradW = d * tol_gradW_scale (CUDAFunctions.cuh:37-50)
+__device__ __forceinline__ float tol_gradW_scale(const TolPair& t, const KernelConsts& k)
+{
+#pragma clang fp contract(fast)
+    const float poly = (t.q > 1.0f) ? ((12.0f - 3.0f * t.q) * t.q - 12.0f) : ((9.0f * t.q - 12.0f) * t.q);
+    return poly * k.gradScale * t.rcpq;
+}
+// viscosity laplacian (CUDAFunctions.cuh:52-54)
+__device__ __forceinline__ float tol_viscLap(const TolPair& t, const KernelConsts& k)
+{
+#pragma clang fp contract(fast)
+    return (k.R - t.r) * k.viscScale;
+}
+// surface-tension gradient = d * tol_surf_scale (CUDAFunctions.cuh:82-98)
+__device__ __forceinline__ float tol_surf_scale(const TolPair& t, const KernelConsts& k)
+{
+#pragma clang fp contract(fast)
+    const float x = t.r;
+    const float c3 = cube(k.R - x) * cube(x);
+    const float poly = (2.0f * x <= k.R) ? (2.0f * c3 - k.stC) : c3;
+    const float s = -k.stScale * __builtin_amdgcn_rcpf(fmaxf(x, kEps)) * poly;
+    return (x < kEps) ? 0.0f : s;
 }
 
 // x^7 of the Tait equation of state (BasicSPHSolver.cu:108): fp64 multiply chain, one rounding
@@ -469,7 +522,7 @@ __device__ __forceinline__ void pair_dispatch(Body& body, const bool plain, cons
 #ifndef SPHX_AHEAD
 #define SPHX_AHEAD 4
 #endif
-template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, class Op, class Body>
+template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
 __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ row, const int cnt,
                                          const float m0, const bool allPlain, const float3 pi, Body& body)
 {
@@ -490,6 +543,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
             const float r2 = dot3(d, d);
             if (SKIN && r2 > c.k.tCut) continue;
+            if (TOL) { body.pair_tol(f[u], isB, d, r2, pj[u].w); continue; }
             const bool plain = SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u;
             pair_dispatch(body, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
         }
@@ -503,6 +557,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
         const float r2 = dot3(d, d);
         if (SKIN && r2 > c.k.tCut) continue;
+        if (TOL) { body.pair_tol(fj, isB, d, r2, pj.w); continue; }
         const bool plain = SKIN ? pair_needs_plain_ops(d, r2) : (e & kPlainBit) != 0u;
         pair_dispatch(body, allPlain || plain, fj, isB, d, r2, pj.w, (int)(e & kIndexMask));
     }
@@ -571,12 +626,21 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
     if (useRow) {
         // one-gather mode is uniform over the launch: two separate loops, so that each keeps its
         // single 16-byte gather per neighbour (a merged loop makes the compiler split the loads)
-        if (skin) {
-            if (packed) walk_row<true, WANT_BOUNDARY, true>(op, c, row, cnt, m0, allPlain, pi, body);
-            else walk_row<false, WANT_BOUNDARY, true>(op, c, row, cnt, m0, allPlain, pi, body);
+        // arithmetic mode, skin rows and one-gather mode are uniform over the launch: separate loops
+        if (c.k.tol) {
+            if (skin) {
+                if (packed) walk_row<true, WANT_BOUNDARY, true, true>(op, c, row, cnt, m0, allPlain, pi, body);
+                else walk_row<false, WANT_BOUNDARY, true, true>(op, c, row, cnt, m0, allPlain, pi, body);
+            } else {
+                if (packed) walk_row<true, WANT_BOUNDARY, false, true>(op, c, row, cnt, m0, allPlain, pi, body);
+                else walk_row<false, WANT_BOUNDARY, false, true>(op, c, row, cnt, m0, allPlain, pi, body);
+            }
+        } else if (skin) {
+            if (packed) walk_row<true, WANT_BOUNDARY, true, false>(op, c, row, cnt, m0, allPlain, pi, body);
+            else walk_row<false, WANT_BOUNDARY, true, false>(op, c, row, cnt, m0, allPlain, pi, body);
         } else {
-            if (packed) walk_row<true, WANT_BOUNDARY, false>(op, c, row, cnt, m0, allPlain, pi, body);
-            else walk_row<false, WANT_BOUNDARY, false>(op, c, row, cnt, m0, allPlain, pi, body);
+            if (packed) walk_row<true, WANT_BOUNDARY, false, false>(op, c, row, cnt, m0, allPlain, pi, body);
+            else walk_row<false, WANT_BOUNDARY, false, false>(op, c, row, cnt, m0, allPlain, pi, body);
         }
         return;
     }

@@ -102,6 +102,25 @@ struct OpFluidProps {
                 }
             }
         }
+        __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            if (VISC && !isB) {
+                const float s = mj * __builtin_amdgcn_rcpf(o.rho0) * tol_viscLap(t, o.c.k);
+                a = v3(a.x + (vj.x - vi.x) * s, a.y + (vj.y - vi.y) * s, a.z + (vj.z - vi.z) * s);
+            }
+            if (COLOR || DENS) {
+                const float w = tol_W(t, o.c.k);
+                if (DENS) den += mj * w;
+                if (COLOR) {
+                    const float vol = mj * __builtin_amdgcn_rcpf(isB ? o.rhoB : o.rho0);
+                    const float s = vol * tol_gradW_scale(t, o.c.k);
+                    cg = v3(cg.x + d.x * s, cg.y + d.y * s, cg.z + d.z * s);
+                    cden += vol * w;
+                }
+            }
+        }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -142,6 +161,15 @@ struct OpSurface {
             a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
             a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW<FAST>(d, q, o.c.k)), li), ml));
         }
+        __device__ __forceinline__ void pair_tol(Field cg4, bool, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            const float m2 = mj * __builtin_amdgcn_rcpf(o.rho0 * o.rho0);
+            const float s = 0.25f * m2 * o.tension * (dii + cg4.x * cg4.x + cg4.y * cg4.y + cg4.z * cg4.z) * tol_surf_scale(t, o.c.k) +
+                            o.airPressure * m2 * tol_gradW_scale(t, o.c.k) * li * __builtin_amdgcn_rcpf(ml);
+            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+        }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -173,6 +201,12 @@ struct OpPressureForce {
         {
             if (!isB && idx == i) return;
             a = add3(a, smul3(-mj * (pti + ptj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
+        }
+        __device__ __forceinline__ void pair_tol(Field ptj, bool, float3 d, float r2, float mj)      // rows never hold the particle itself
+        {
+#pragma clang fp contract(fast)
+            const float s = -mj * (pti + ptj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
+            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
@@ -237,6 +271,17 @@ struct OpDfsphHead {
             if (!isB) sl += dot3(gr, gr);
             if (withRate) e += mj * dot3(sub3(vi, xyz(vj)), gw);
         }
+        __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            den += mj * tol_W(t, o.c.k);
+            const float g = tol_gradW_scale(t, o.c.k), s = mj * g;
+            const float3 gr = v3(d.x * s, d.y * s, d.z * s);
+            gs = v3(gs.x + gr.x, gs.y + gr.y, gs.z + gr.z);
+            if (!isB) sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
+            if (withRate) e += s * ((vi.x - vj.x) * d.x + (vi.y - vj.y) * d.y + (vi.z - vj.z) * d.z);
+        }
     };
 };
 template <bool WITH_RATE, bool STREAM>
@@ -283,6 +328,12 @@ struct OpRate {
         {
             e += mj * dot3(sub3(vi, xyz(vj)), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k));
         }
+        __device__ __forceinline__ void pair_tol(Field vj, bool, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const float s = mj * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
+            e += s * ((vi.x - vj.x) * d.x + (vi.y - vj.y) * d.y + (vi.z - vj.z) * d.z);
+        }
     };
 };
 template <bool DENSITY_MODE, int WARM, bool STREAM>
@@ -326,6 +377,12 @@ struct OpCorrect {
         {
             a = add3(a, smul3(mj * (ki + kj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
         }
+        __device__ __forceinline__ void pair_tol(Field kj, bool, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const float s = mj * (ki + kj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
+            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+        }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -359,6 +416,17 @@ struct OpLambda {
             gs = sub3(gs, gr);
             sl += dot3(gr, gr);
         }
+        __device__ __forceinline__ void pair_tol(Field, bool, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            den += mj * tol_W(t, o.c.k);
+            float s = -mj * tol_gradW_scale(t, o.c.k);
+            if (o.rb != 1.0f) s = s / o.rb;
+            const float3 gr = v3(d.x * s, d.y * s, d.z * s);
+            gs = v3(gs.x - gr.x, gs.y - gr.y, gs.z - gr.z);
+            sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
+        }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -387,6 +455,12 @@ struct OpDeltaPos {
         __device__ __forceinline__ void pair(Field lj, bool, float3 d, float r2, float mj, int)
         {
             a = add3(a, smul3(mj * (li + lj), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k)));
+        }
+        __device__ __forceinline__ void pair_tol(Field lj, bool, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const float s = mj * (li + lj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
+            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
@@ -418,6 +492,19 @@ struct OpXsph {
             if (COLOR) {
                 const float vol = mj / (isB ? o.rhoB : o.rho0);
                 cg = add3(cg, smul3(vol, kGradW<FAST>(d, q, o.c.k)));
+                cden += vol * w;
+            }
+        }
+        __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            const float w = tol_W(t, o.c.k);
+            if (!isB) { const float s = mj * w; a = v3(a.x + (vj.x - vi.x) * s, a.y + (vj.y - vi.y) * s, a.z + (vj.z - vi.z) * s); }
+            if (COLOR) {
+                const float vol = mj * __builtin_amdgcn_rcpf(isB ? o.rhoB : o.rho0);
+                const float s = vol * tol_gradW_scale(t, o.c.k);
+                cg = v3(cg.x + d.x * s, cg.y + d.y * s, cg.z + d.z * s);
                 cden += vol * w;
             }
         }

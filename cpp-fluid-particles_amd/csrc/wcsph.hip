@@ -26,6 +26,7 @@ BasicSPHSolver::~BasicSPHSolver() noexcept {}
 void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; _cache->listValid = false; ++_cache->generation; }
 unsigned int BasicSPHSolver::graphGeneration() const { return _cache->generation; }
+void BasicSPHSolver::setToleranceArithmetic(bool on) { _cache->tolerance = on; ++_cache->generation; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
 void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }

@@ -35,6 +35,9 @@ public:
     // bit 2: stage neighbour ranges in LDS per 64-particle tile)
     const DArray<float3>& getColorGradient() const { return bufferFloat3; }
     void setEngineFlags(int flags);
+    // arithmetic of the neighbour sweeps: strict (default; every bit equals the IEEE evaluation of the reference's
+    // expressions) or tolerance (hardware rsq / rcp and fused multiply-adds: deviations of a few 1e-7 per pair term)
+    void setToleranceArithmetic(bool on);
     // slab decompositions: global x index of this solver's local cell column 0
     void setCellOffsetX(int cellOffsetX);
     // raw device pointers of the float4 mirrors the sweeps gather from (halo exchange targets)

@@ -28,6 +28,7 @@ typedef enum sphx_status {
     SPHX_ERR_STATE = -4        /* call not valid in the current state */
 } sphx_status;
 
+enum { SPHX_ARITH_STRICT = 0, SPHX_ARITH_TOLERANCE = 1 };
 /* solver kinds: the three BaseSolver implementations selected in main.cpp:119-130 */
 enum { SPHX_WCSPH = 0, SPHX_DFSPH = 1, SPHX_PBD = 2 };
 
@@ -63,7 +64,12 @@ typedef struct sphx_params {
     int   xsph_mode;           /* must be 0 (Jacobi XSPH) */
     int   reserved[4];         /* reserved[0]: engine switches for tests (bit0 unfused schedule,
                                   bit1 direct 27-cell walks instead of the neighbour list,
-                                  bit2 LDS-staged 64-particle tiles) */
+                                  bit2 LDS-staged 64-particle tiles);
+                                  reserved[1], reserved[2]: slab sub-grid (see sphx_slab.h);
+                                  reserved[3]: arithmetic of the neighbour sweeps, SPHX_ARITH_STRICT (0, default:
+                                  every bit equals the IEEE evaluation of the reference's expressions) or
+                                  SPHX_ARITH_TOLERANCE (1: hardware rsq/rcp + fused multiply-adds, ~1e-7 per pair term;
+                                  the reference's own binary is built -use_fast_math, src/CMakeLists.txt:43) */
 } sphx_params;
 
 /* device-resident fields readable through sphx_get (host copy) / sphx_device_ptr (raw pointer) */

@@ -1,0 +1,86 @@
+"""Tolerance arithmetic (sphx_params.reserved[3] = SPHX_ARITH_TOLERANCE): hardware rsq / rcp and fused multiply-adds in
+the neighbour sweeps.  The contract (BASELINE.json north star): positions and densities within 1e-5 relative of the
+reference after N steps, integer cell indices bit-exact.  Checked against the CPU oracle (strict IEEE restatement)
+on the horizon where that statement is meaningful (tens of steps; beyond that SPH trajectories
+separate chaotically whatever the arithmetic), and per sweep against the strict engine."""
+import numpy as np
+import pytest
+
+from conftest import same_params
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _rel(a, b, scale):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / scale)
+
+
+def _pair(sphx, oracle, nx, solver, tweak=None):
+    P, fluid, boundary = sphx.scene(nx)
+    P.solver = solver
+    if tweak:
+        tweak(P)
+    Po = same_params(oracle.Params(), P)
+    P.reserved[3] = 1
+    return sphx.System(P, fluid, boundary), oracle.System(Po, fluid, boundary), P
+
+
+@pytest.mark.parametrize("solver,steps,dt", [(0, 50, 0.001), (1, 50, 0.002), (2, 40, 0.002)])
+def test_tolerance_trajectory_within_1e5_of_oracle(sphx, oracle, solver, steps, dt):
+    """the reference's own scene (20,736 particles): after every step of the first `steps`, positions within 1e-5 of
+    the domain size, densities within 1e-5 of rho0, cell indices and cell tables identical to the strict oracle"""
+    def tweak(P):
+        P.dt = dt; P.pbd_iters = 5
+        P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    gs, os_, P = _pair(sphx, oracle, 24, solver, tweak)
+    worst_p = worst_d = 0.0
+    for s in range(steps):
+        gs.step(); os_.step()
+        assert np.array_equal(gs.get(sphx.F_ID), os_.get(oracle.F_ID)), "step %d: the sort permutation must not change" % s
+        assert np.array_equal(gs.get(sphx.F_CELL), os_.get(oracle.F_CELL)), "step %d: cell indices are bit-exact" % s
+        assert np.array_equal(gs.get(sphx.F_CELLSTART_F), os_.get(oracle.F_CELLSTART_F))
+        worst_p = max(worst_p, _rel(gs.get(sphx.F_POS), os_.get(oracle.F_POS), P.space[0]))
+        worst_d = max(worst_d, _rel(gs.get(sphx.F_DENSITY), os_.get(oracle.F_DENSITY), P.rho0))
+    assert worst_p <= TOL, "positions: %.2e" % worst_p
+    assert worst_d <= TOL, "densities: %.2e" % worst_d
+    assert worst_p > 0.0 or worst_d > 0.0, "the tolerance path must actually differ from the strict one"
+
+
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_tolerance_one_step_fields_close_to_strict(sphx, solver):
+    """one step from an identical disordered state, strict vs tolerance engine: every per-particle output within
+    1e-5 of its field's scale (the per-sweep statement; sums with cancellation are measured against the field's
+    largest magnitude, not element by element)"""
+    from test_gpu_parity import _splash_state
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = solver; P.pbd_iters = 3; P.dt = 0.001
+    P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 3
+    pos, vel = _splash_state(len(fluid), P, 77)
+    out = []
+    for mode in (0, 1):
+        Q = P.copy(); Q.reserved[3] = mode
+        s = sphx.System(Q, pos, boundary, ctor_step=False)
+        ids = s.get(sphx.F_ID)
+        s.set(sphx.F_VEL, vel[ids])
+        s.step()
+        if solver == 2:
+            s.step()
+        f = {"pos": s.get(sphx.F_POS), "vel": s.get(sphx.F_VEL), "density": s.get(sphx.F_DENSITY)}
+        if solver == 1:
+            f["alpha"] = s.get(sphx.F_ALPHA); f["kappa"] = s.get(sphx.F_KAPPA)
+        out.append(f)
+        s.close()
+    for k in out[0]:
+        a, b = out[0][k], out[1][k]
+        scale = max(float(np.abs(a).max()), 1e-30)
+        assert _rel(a, b, scale) <= TOL, "%s: %.2e of its scale" % (k, _rel(a, b, scale))
+
+
+def test_tolerance_mode_is_opt_in_and_validated(sphx):
+    import ctypes as C
+    P, fluid, boundary = sphx.scene(8)
+    P.reserved[3] = 7
+    h = C.c_void_p()
+    assert sphx.lib().sphx_create(C.byref(P), fluid.ctypes.data, len(fluid), boundary.ctypes.data, len(boundary), 1, C.byref(h)) == -1
