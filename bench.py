@@ -193,11 +193,13 @@ def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup):
     wall, _ = timed_steps(torch, sim, steps)
     note("leg nx=%d %s: %.3f ms/step" % (nx, solver, wall * 1e3 / steps))
     sps = steps / wall
+    what = {"wcsph": "WCSPH", "dfsph": "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults)",
+            "pbd": "PBD(%d Jacobi)" % pbd_iters}[solver]
     if solver == "dfsph" and div < 0:
         div, den = sim.iters()                  # iteration counts of the last step
+        what += ", last step ran (%d,%d) iterations" % (div, den)
     bpp = step_bytes_per_particle(solver, div, den, pbd_iters)
-    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (
-               nx, sim.n, {"wcsph": "WCSPH", "dfsph": "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults)", "pbd": "PBD(%d Jacobi)" % pbd_iters}[solver], P.dt),
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (nx, sim.n, what, P.dt),
            "particles": sim.n, "steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
            "algorithmic_GBps": bpp * sim.n * sps / 1e9, "hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS}
     sim.close()

@@ -360,6 +360,7 @@ template <bool STREAM>
 __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt)
 {
     __shared__ float4 pos[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
+    __shared__ unsigned int stage[STREAM ? 1 : kWideBlock / kTile][STREAM ? 1 : kRowStage * kTile];
     const int tile = wave_tile(c);
     if (tile < 0) return;                  // whole wave past the end
     const int i = tile * kTile + (int)(threadIdx.x & 63);
@@ -369,7 +370,8 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
         streamed = wave_ranges(c, i0).ok;
         if ((threadIdx.x & 63) == 0) tileFmt[i >> 6] = streamed ? 2 : 0;
     }
-    build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n);
+    build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n,
+                        STREAM ? nullptr : stage[threadIdx.x >> 6]);
 }
 
 SweepCache::SweepCache(int num)

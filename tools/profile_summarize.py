@@ -71,8 +71,22 @@ if traffic:
     kr = traffic["k_rate_density"]
     kr.update(extra)
     if "SQ_ACTIVE_INST_VALU" in extra and extra.get("GRBM_GUI_ACTIVE"):
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs
-        kr["valu_busy_frac"] = extra["SQ_ACTIVE_INST_VALU"] * 4.0 / (extra["GRBM_GUI_ACTIVE"] * 1024.0)
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs
+        cycles = extra["GRBM_GUI_ACTIVE"] / 8.0
+        kr["kernel_cycles"] = cycles
+        kr["valu_busy_frac"] = extra["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
+        stats = find("stats", "*kernel_stats.csv")
+        us = None
+        if stats:
+            for r in csv.DictReader(open(stats)):
+                if "k_rate<true, 2" in r["Name"] or "k_rate<(bool)1, 2" in r["Name"]:
+                    us = float(r["AverageNs"]) / 1e3
+        if us:
+            kr["avg_launch_us_rocprof"] = us
+        if "TA_TA_BUSY_sum" in extra:
+            kr["ta_busy_frac"] = extra["TA_TA_BUSY_sum"] / 256.0 / cycles          # 256 CUs, one texture-address unit each
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in extra:
+            kr["l1_line_accesses_per_clk_per_cu"] = extra["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cycles
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from srchash import engine_source_hash
     kr["source_hash"] = engine_source_hash()
