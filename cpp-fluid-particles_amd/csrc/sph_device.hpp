@@ -177,6 +177,70 @@ __device__ __forceinline__ float3 kSurfGrad(float3 d, float x, const KernelConst
     return outside ? v3(0.0f, 0.0f, 0.0f) : g;
 }
 
+// ---- the exact fast paths for TWO pairs at a time (packed fp32) ------------------------------------------------------
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 apply the IEEE operation to each half independently, so evaluating two
+// row entries in the halves of one register pair yields exactly the bits of two scalar evaluations at half the
+// instruction count (the scalar chain is VALU-issue-bound at <= 1 M particles: profiles/r02_ubench_sweep_structure.txt).
+// Accumulation into the per-particle sums stays scalar and in row order.  Only the <FAST> forms exist: a wave whose
+// pair needs the plain operators takes the scalar path for both entries.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+struct f2x3 { f2 x, y, z; };
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sel2(i2 m, f2 a, f2 b) { return f2{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+// sqrt_sel<true> per half
+__device__ __forceinline__ f2 sqrt_fast2(f2 x)
+{
+    const f2 s = f2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const i2 si = __builtin_bit_cast(i2, s);
+    const f2 sm = __builtin_bit_cast(f2, si - 1), sp = __builtin_bit_cast(f2, si + 1);
+    const f2 rm = fma2(-sm, s, x), rp = fma2(-sp, s, x);
+    f2 out = sel2(rm <= 0.0f, sm, s);
+    out = sel2(rp > 0.0f, sp, out);
+    return out;
+}
+// q_of<true> per half: div_by_radius<true>(2 r)
+__device__ __forceinline__ f2 q_fast2(f2 r, const KernelConsts& k)
+{
+    const f2 x = 2.0f * r, R = splat2(k.R), y = splat2(k.rcpR);
+    f2 q0 = x * y;
+    q0 = fma2(fma2(-R, q0, x), y, q0);
+    return fma2(fma2(-R, q0, x), y, q0);
+}
+// kW<true> per half
+__device__ __forceinline__ f2 kW_fast2(f2 q, const KernelConsts& k)
+{
+    const f2 w = k.wA * sel2(q > 1.0f, (2.0f - q) * (2.0f - q) * (2.0f - q), ((3.0f * q - 6.0f) * q * q + 4.0f));
+    return sel2(q < kEps, splat2(0.0f), w);
+}
+// kGradW<true> per half (div3_sel<true> inlined)
+__device__ __forceinline__ f2x3 kGradW_fast2(const f2x3& d, f2 q, const KernelConsts& k)
+{
+    const f2 den = kPi * (q + kEps) * k.R * k.R * k.R * k.R * k.R;
+    f2 rc = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    rc = fma2(fma2(-den, rc, splat2(1.0f)), rc, rc);
+    const f2 poly = sel2(q > 1.0f, ((12.0f - 3.0f * q) * q - 12.0f), ((9.0f * q - 12.0f) * q));
+    f2x3 g;
+    { f2 q0 = d.x * rc; q0 = fma2(fma2(-den, q0, d.x), rc, q0); g.x = fma2(fma2(-den, q0, d.x), rc, q0) * poly; }
+    { f2 q0 = d.y * rc; q0 = fma2(fma2(-den, q0, d.y), rc, q0); g.y = fma2(fma2(-den, q0, d.y), rc, q0) * poly; }
+    { f2 q0 = d.z * rc; q0 = fma2(fma2(-den, q0, d.z), rc, q0); g.z = fma2(fma2(-den, q0, d.z), rc, q0) * poly; }
+    return g;
+}
+// displacement of two neighbours from pi, their squared lengths, and gradW: what every pair2 body starts from
+struct Pair2 { f2x3 d; f2 r2, q; };
+__device__ __forceinline__ Pair2 pair2_geometry(const float3 pi, const float4 a, const float4 b, const KernelConsts& k)
+{
+    Pair2 p;
+    p.d.x = pi.x - f2{a.x, b.x}; p.d.y = pi.y - f2{a.y, b.y}; p.d.z = pi.z - f2{a.z, b.z};
+    p.r2 = p.d.x * p.d.x + p.d.y * p.d.y + p.d.z * p.d.z;
+    p.q = q_fast2(sqrt_fast2(p.r2), k);
+    return p;
+}
+template <class B> __device__ __forceinline__ constexpr auto has_pair2_impl(int) -> decltype(B::kPair2) { return B::kPair2; }
+template <class B> __device__ __forceinline__ constexpr bool has_pair2_impl(long) { return false; }
+template <class B> __device__ __forceinline__ constexpr bool has_pair2() { return has_pair2_impl<B>(0); }
+
 // ---- tolerance arithmetic ---------------------------------------------------------------------------------------
 // The same formulas with v_rsq_f32 / v_rcp_f32 (1 ulp), contraction into FMAs and folded constants: relative
 // deviations of a few 1e-7 per pair term from the strict path (the reference binary itself is built with
@@ -536,6 +600,18 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
         typename Op::Field f[kAhead];
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
+        if constexpr (has_pair2<Body>() && WANT_BOUNDARY && !SKIN && !TOL && (kAhead % 2 == 0)) {
+            // two entries per packed evaluation; one wave-uniform test of the plain-operator flags per group
+            unsigned int flags = 0u;
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) flags |= e[u];
+            if (!__any(allPlain || (flags & kPlainBit) != 0u)) {
+#pragma unroll
+                for (int u = 0; u < kAhead; u += 2)
+                    body.pair2(f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
+                continue;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const bool isB = (e[u] & kBoundaryBit) != 0u;

@@ -208,6 +208,16 @@ struct OpPressureForce {
             const float s = -mj * (pti + ptj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
+        static constexpr bool kPair2 = true;      // (rows never hold the particle itself, so no j == i test)
+        __device__ __forceinline__ void pair2(Field ta, Field tb, bool, bool, float3 pi, float4 pa, float4 pb)
+        {
+            const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
+            const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
+            const f2 s = -f2{pa.w, pb.w} * (pti + f2{ta, tb});
+            const f2 cx = s * g.x, cy = s * g.y, cz = s * g.z;
+            a = add3(a, v3(cx.x, cy.x, cz.x));
+            a = add3(a, v3(cx.y, cy.y, cz.y));
+        }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -258,7 +268,8 @@ struct OpDfsphHead {
     using Field = float4;   // neighbour velocity
     __device__ __forceinline__ Field stage(bool, int j) const { return vel ? field4(c.vel4, j) : f4zero(); }
     struct Body {
-        const OpDfsphHead& o; float3 vi; float den, sl, e; float3 gs;
+        const OpDfsphHead& o; float vix, viy, viz;   // own velocity as scalars: a float3 member keeps the whole struct in memory
+        float den, sl, e; float3 gs;
         bool withRate;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
@@ -269,7 +280,7 @@ struct OpDfsphHead {
             const float3 gr = smul3(mj, gw);
             gs = add3(gs, gr);
             if (!isB) sl += dot3(gr, gr);
-            if (withRate) e += mj * dot3(sub3(vi, xyz(vj)), gw);
+            if (withRate) e += mj * dot3(sub3(v3(vix, viy, viz), xyz(vj)), gw);
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
         {
@@ -280,7 +291,21 @@ struct OpDfsphHead {
             const float3 gr = v3(d.x * s, d.y * s, d.z * s);
             gs = v3(gs.x + gr.x, gs.y + gr.y, gs.z + gr.z);
             if (!isB) sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
-            if (withRate) e += s * ((vi.x - vj.x) * d.x + (vi.y - vj.y) * d.y + (vi.z - vj.z) * d.z);
+            if (withRate) e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
+        }
+        static constexpr bool kPair2 = true;
+        __device__ __forceinline__ void pair2(Field va, Field vb, bool isBa, bool isBb, float3 pi, float4 pa, float4 pb)
+        {
+            const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
+            const f2 m = f2{pa.w, pb.w};
+            const f2 dw = m * kW_fast2(p.q, o.c.k);
+            const f2x3 gw = kGradW_fast2(p.d, p.q, o.c.k);
+            const f2 gx = m * gw.x, gy = m * gw.y, gz = m * gw.z;
+            const f2 s2 = gx * gx + gy * gy + gz * gz;
+            f2 r = splat2(0.0f);
+            if (withRate) r = m * ((vix - f2{va.x, vb.x}) * gw.x + (viy - f2{va.y, vb.y}) * gw.y + (viz - f2{va.z, vb.z}) * gw.z);
+            den += dw.x; gs = add3(gs, v3(gx.x, gy.x, gz.x)); if (!isBa) sl += s2.x; if (withRate) e += r.x;
+            den += dw.y; gs = add3(gs, v3(gx.y, gy.y, gz.y)); if (!isBb) sl += s2.y; if (withRate) e += r.y;
         }
     };
 };
@@ -295,7 +320,8 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     (void)n;
     const bool valid = in_range(o.c, i);
     long long fixed = 0;
-    OpDfsphHead::Body b{o, (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0), 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
+    const float3 own = (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0);
+    OpDfsphHead::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
     sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
     if (valid) {
         const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
@@ -322,17 +348,25 @@ struct OpRate {
     using Field = float4;   // neighbour velocity
     __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.vel4, j); }
     struct Body {
-        const OpRate& o; float3 vi; float e;
+        const OpRate& o; float vix, viy, viz; float e;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool, float3 d, float r2, float mj, int)
         {
-            e += mj * dot3(sub3(vi, xyz(vj)), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k));
+            e += mj * dot3(sub3(v3(vix, viy, viz), xyz(vj)), kGradW<FAST>(d, q_of<FAST>(sqrt_sel<FAST>(r2), o.c.k), o.c.k));
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool, float3 d, float r2, float mj)
         {
 #pragma clang fp contract(fast)
             const float s = mj * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
-            e += s * ((vi.x - vj.x) * d.x + (vi.y - vj.y) * d.y + (vi.z - vj.z) * d.z);
+            e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
+        }
+        static constexpr bool kPair2 = true;
+        __device__ __forceinline__ void pair2(Field va, Field vb, bool, bool, float3 pi, float4 pa, float4 pb)
+        {
+            const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
+            const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
+            const f2 t = f2{pa.w, pb.w} * ((vix - f2{va.x, vb.x}) * g.x + (viy - f2{va.y, vb.y}) * g.y + (viz - f2{va.z, vb.z}) * g.z);
+            e += t.x; e += t.y;
         }
     };
 };
@@ -347,7 +381,8 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate
     (void)n;
     const bool valid = in_range(o.c, i);
     long long fixed = 0;
-    OpRate::Body b{o, valid ? o.vel[i] : v3(0, 0, 0), 0.0f};
+    const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
+    OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
     sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
     if (valid) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
@@ -382,6 +417,16 @@ struct OpCorrect {
 #pragma clang fp contract(fast)
             const float s = mj * (ki + kj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+        }
+        static constexpr bool kPair2 = true;
+        __device__ __forceinline__ void pair2(Field ka, Field kb, bool, bool, float3 pi, float4 pa, float4 pb)
+        {
+            const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
+            const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
+            const f2 s = f2{pa.w, pb.w} * (ki + f2{ka, kb});
+            const f2 cx = s * g.x, cy = s * g.y, cz = s * g.z;
+            a = add3(a, v3(cx.x, cy.x, cz.x));
+            a = add3(a, v3(cx.y, cy.y, cz.y));
         }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
