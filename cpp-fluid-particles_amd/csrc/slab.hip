@@ -176,23 +176,28 @@ struct RcclTransport final : Transport {
 // classification of the owned particles after last step's advect: global cell column by the engine's own
 // expression (true fp32 division, truncation: cell_of), which neighbour needs a copy, and a sanity flag
 __global__ void k_slab_classify(const float3* __restrict__ pos, int m, float cellLength, int x0, int x1, int g, int hasLeft,
-                                int hasRight, int* __restrict__ flagL, int* __restrict__ flagR, int* __restrict__ violation)
+                                int hasRight, int slackL, int slackR, int* __restrict__ flagL, int* __restrict__ flagR,
+                                int* __restrict__ flagK, int* __restrict__ violation)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int col = (int)(pos[k].x / cellLength);
     flagL[k] = (hasLeft && col <= x0 + g - 1) ? 1 : 0;
     flagR[k] = (hasRight && col >= x1 - g) ? 1 : 0;
-    if (col < x0 - 1 || col > x1) *violation = 1;     // moved more than one column in one step
+    // still inside this slab's ghost range?  (after a cut moved, a former owner may hold particles two columns out:
+    // they travel to the neighbour like every migrant and are dropped here)
+    flagK[k] = (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0;
+    // moved more than one column in one step (a cut that itself moved this step widens the allowance by its shift)
+    if (col < x0 - 1 - slackL || col > x1 + slackR) *violation = 1;
 }
 
-// payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives every owned particle,
-// sendL / sendR the stable compactions (scanL / scanR = exclusive scans of the flags)
+// payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives the owned particles still in
+// this slab's range, sendL / sendR the copies for the neighbours: three stable compactions (scan* = exclusive scans of the flags)
 __global__ void k_slab_pack(const float3* __restrict__ pos, const float3* __restrict__ vel, const int* __restrict__ ids,
                             const float* __restrict__ extra, int E, int m, const int* __restrict__ flagL,
-                            const int* __restrict__ flagR, const int* __restrict__ scanL, const int* __restrict__ scanR,
-                            float* __restrict__ own, float* __restrict__ sendL, float* __restrict__ sendR,
-                            long long* __restrict__ counts)
+                            const int* __restrict__ flagR, const int* __restrict__ flagK, const int* __restrict__ scanL,
+                            const int* __restrict__ scanR, const int* __restrict__ scanK, float* __restrict__ own,
+                            float* __restrict__ sendL, float* __restrict__ sendR, long long* __restrict__ counts)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
@@ -201,11 +206,10 @@ __global__ void k_slab_pack(const float3* __restrict__ pos, const float3* __rest
     const float3 p = pos[k], v = vel[k];
     row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = v.x; row[4] = v.y; row[5] = v.z; row[6] = __int_as_float(ids[k]);
     for (int e = 0; e < E; ++e) row[7 + e] = extra[(size_t)k * E + e];
-    float* dst = own + (size_t)k * W;
-    for (int t = 0; t < W; ++t) dst[t] = row[t];
+    if (flagK[k]) { float* d = own + (size_t)scanK[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
     if (flagL[k]) { float* d = sendL + (size_t)scanL[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
     if (flagR[k]) { float* d = sendR + (size_t)scanR[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
-    if (k == m - 1) { counts[0] = scanL[k] + flagL[k]; counts[1] = scanR[k] + flagR[k]; }
+    if (k == m - 1) { counts[0] = scanL[k] + flagL[k]; counts[3] = scanR[k] + flagR[k]; counts[12] = scanK[k] + flagK[k]; }
 }
 
 // new pre-sort arrays = [from left | previously owned | from right]: ascending in last step's global order, which
@@ -224,10 +228,11 @@ __global__ void k_slab_unpack(float3* __restrict__ pos, float3* __restrict__ vel
     for (int e = 0; e < E; ++e) extra[(size_t)t * E + e] = row[7 + e];
 }
 
-__global__ void k_slab_pick5(const int* __restrict__ cellStart, int i0, int i1, int i2, int i3, int i4, int* __restrict__ out)
+__global__ void k_slab_pick6(const int* __restrict__ cellStart, int i0, int i1, int i2, int i3, int i4, int i5, int* __restrict__ out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         out[0] = cellStart[i0]; out[1] = cellStart[i1]; out[2] = cellStart[i2]; out[3] = cellStart[i3]; out[4] = cellStart[i4];
+        out[5] = cellStart[i5];
     }
 }
 
@@ -241,7 +246,9 @@ struct DevBuf {
 // ================================================================================ one slab
 struct Slab {
     int rank = 0, world = 1;
-    int x0 = 0, x1 = 0, ghost = 1, cellsPerColumn = 0, localColumns = 0;
+    int x0 = 0, x1 = 0, ghost = 1, cellsPerColumn = 0, gx = 0;
+    // what the neighbours reported with last step's size message: their owned particle counts and widths (cut re-balancing)
+    long long ownedLeft = -1, ownedRight = -1; int widthLeft = 0, widthRight = 0;
     float cellLength = 0.0f;
     int solver = SPHX_WCSPH;
     sphx_system* sys = nullptr;
@@ -254,16 +261,21 @@ struct Slab {
     // engine arrays
     float3 *pos = nullptr, *vel = nullptr; int* ids = nullptr; float* extra = nullptr; float* density = nullptr; int* cellStart = nullptr;
     // scratch
-    DevBuf<int> flagL, flagR, scanL, scanR, blockSums, violation, layerOut;
+    DevBuf<int> flagL, flagR, flagK, scanL, scanR, scanK, blockSums, violation, layerOut;
     DevBuf<float> own, sendL, sendR, recvL, recvR;
-    DevBuf<long long> counts;        // [sendL, sendR, recvL, recvR]
-    long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 4 counts; 5 layer offsets + violation
+    // size messages, 3 x int64 each: {payload particles, owned particles, width in columns}
+    //   [0..2] to left  [3..5] to right  [6..8] from left  [9..11] from right   [12] owned particles kept here
+    DevBuf<long long> counts;
+    long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 12 size words; 6 layer offsets + violation
+    long long* hSend = nullptr;                            // pinned: the host-known size words
+    long long sentOwned = 0; int sentWidth = 0;            // what this slab reported with its last size message
 
     ~Slab()
     {
         if (sys) sphx_destroy(sys);
         if (hCounts) (void)hipHostFree(hCounts);
         if (hInts) (void)hipHostFree(hInts);
+        if (hSend) (void)hipHostFree(hSend);
     }
     int width() const { return 7 + extraFloats; }
     void* field(int f, size_t* bytesPerParticle) const
@@ -299,50 +311,90 @@ struct sphx_slab_group {
         waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 
+    // ---- cut re-balancing ---------------------------------------------------------------------------------------------
+    // Every `rebalanceEvery` steps a cut plane moves by one column towards the lighter neighbour when the two owned
+    // counts differ by more than `rebalanceTol`.  Both neighbours evaluate the same rule on the same numbers (the owned
+    // counts and widths exchanged with last step's size messages), so they agree without another message.  Ownership
+    // follows by itself: the particles of the column that changed hands are migrants of the ordinary exchange.
+    int rebalanceEvery = 16;
+    float rebalanceTol = 0.05f;
+    static int cut_shift(long long ownedA, long long ownedB, int widthA, int widthB, int ghost, float tol)
+    {
+        const int minShrinkable = ghost + 4;     // stays >= ghost + 2 even if its other cut shrinks it too
+        if ((double)ownedA > (double)ownedB * (1.0 + tol) && widthA >= minShrinkable) return -1;   // left slab hands a column over
+        if ((double)ownedB > (double)ownedA * (1.0 + tol) && widthB >= minShrinkable) return +1;
+        return 0;
+    }
+    void rebalance(Slab& s, int& slackL, int& slackR)
+    {
+        slackL = slackR = 0;
+        if (rebalanceEvery <= 0 || s.stepsDone == 0 || (s.stepsDone % rebalanceEvery) != 0) return;
+        if (s.hasLeft && s.ownedLeft >= 0) {
+            const int d = cut_shift(s.ownedLeft, s.sentOwned, s.widthLeft, s.sentWidth, s.ghost, rebalanceTol);
+            s.x0 += d; slackL = d < 0 ? -d : d;
+        }
+        if (s.hasRight && s.ownedRight >= 0) {
+            const int d = cut_shift(s.sentOwned, s.ownedRight, s.sentWidth, s.widthRight, s.ghost, rebalanceTol);
+            s.x1 += d; slackR = d < 0 ? -d : d;
+        }
+    }
+
     // ---- particle exchange (migrants and ghost copies alike) ------------------------------------------------
     void exchangeParticles()
     {
         hipStream_t st = sphx::stream();
         for (auto& sp : slabs) {
             Slab& s = *sp;
+            int slackL = 0, slackR = 0;
+            rebalance(s, slackL, slackR);
             const int m = s.o1 - s.o0;
-            hip_ok(hipMemsetAsync(s.counts.p, 0, 4 * sizeof(long long), st), "memset");
+            // size words that do not come from the device: owned count and width, for both neighbours
+            s.sentOwned = m; s.sentWidth = s.x1 - s.x0;
+            s.hSend[0] = 0; s.hSend[1] = m; s.hSend[2] = s.x1 - s.x0;
+            hip_ok(hipMemsetAsync(s.counts.p, 0, 13 * sizeof(long long), st), "memset");
+            hip_ok(hipMemcpyAsync(s.counts.p + 0, s.hSend, 3 * sizeof(long long), hipMemcpyHostToDevice, st), "size words");
+            hip_ok(hipMemcpyAsync(s.counts.p + 3, s.hSend, 3 * sizeof(long long), hipMemcpyHostToDevice, st), "size words");
             hip_ok(hipMemsetAsync(s.violation.p, 0, sizeof(int), st), "memset");
             if (m > 0) {
                 k_slab_classify<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, m, s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0,
-                                                                s.hasRight ? 1 : 0, s.flagL.p, s.flagR.p, s.violation.p);
+                                                                s.hasRight ? 1 : 0, slackL, slackR, s.flagL.p, s.flagR.p, s.flagK.p, s.violation.p);
                 hip_ok(hipMemcpyAsync(s.scanL.p, s.flagL.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
                 hip_ok(hipMemcpyAsync(s.scanR.p, s.flagR.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
+                hip_ok(hipMemcpyAsync(s.scanK.p, s.flagK.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
                 device_exclusive_scan(s.scanL.p, m, s.blockSums.p);
                 device_exclusive_scan(s.scanR.p, m, s.blockSums.p);
+                device_exclusive_scan(s.scanK.p, m, s.blockSums.p);
                 k_slab_pack<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, s.vel + s.o0, s.ids + s.o0,
                                                             s.extraFloats ? s.extra + (size_t)s.o0 * s.extraFloats : nullptr, s.extraFloats, m,
-                                                            s.flagL.p, s.flagR.p, s.scanL.p, s.scanR.p, s.own.p, s.sendL.p, s.sendR.p, s.counts.p);
+                                                            s.flagL.p, s.flagR.p, s.flagK.p, s.scanL.p, s.scanR.p, s.scanK.p, s.own.p, s.sendL.p, s.sendR.p,
+                                                            s.counts.p);
             }
-            // message sizes travel first (8 bytes per neighbour)
-            if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.counts.p + 0, 8}); recvs.push_back({s.rank - 1, s.rank, s.counts.p + 2, 8}); }
-            if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.counts.p + 1, 8}); recvs.push_back({s.rank + 1, s.rank, s.counts.p + 3, 8}); }
+            // size messages travel first (24 bytes per neighbour)
+            if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.counts.p + 0, 24}); recvs.push_back({s.rank - 1, s.rank, s.counts.p + 6, 24}); }
+            if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.counts.p + 3, 24}); recvs.push_back({s.rank + 1, s.rank, s.counts.p + 9, 24}); }
         }
         transport->exchange(sends, recvs, false);
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
-            hip_ok(hipMemcpyAsync(s.hInts + 5, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
+            hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 13 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
+            hip_ok(hipMemcpyAsync(s.hInts + 6, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
         }
         sync("particle exchange (sizes)");
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            if (s.hInts[5]) die("slab: a particle crossed more than one cell column in one step");
+            if (s.hInts[6]) die("slab: a particle crossed more than one cell column in one step");
             const size_t rowBytes = sizeof(float) * (size_t)s.width();
-            const long long sl = s.hCounts[0], sr = s.hCounts[1], rl = s.hasLeft ? s.hCounts[2] : 0, rr = s.hasRight ? s.hCounts[3] : 0;
-            if ((long long)(s.o1 - s.o0) + rl + rr > s.capacity) die("slab: capacity exceeded (particles piled up in one slab)");
+            const long long sl = s.hCounts[0], sr = s.hCounts[3], rl = s.hasLeft ? s.hCounts[6] : 0, rr = s.hasRight ? s.hCounts[9] : 0;
+            if (s.hasLeft) { s.ownedLeft = s.hCounts[7]; s.widthLeft = (int)s.hCounts[8]; }
+            if (s.hasRight) { s.ownedRight = s.hCounts[10]; s.widthRight = (int)s.hCounts[11]; }
+            if (s.hCounts[12] + rl + rr > s.capacity) die("slab: capacity exceeded (particles piled up in one slab)");
             if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.sendL.p, (size_t)sl * rowBytes}); recvs.push_back({s.rank - 1, s.rank, s.recvL.p, (size_t)rl * rowBytes}); }
             if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.sendR.p, (size_t)sr * rowBytes}); recvs.push_back({s.rank + 1, s.rank, s.recvR.p, (size_t)rr * rowBytes}); }
         }
         transport->exchange(sends, recvs, false);
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            const int m = s.o1 - s.o0, nl = s.hasLeft ? (int)s.hCounts[2] : 0, nr = s.hasRight ? (int)s.hCounts[3] : 0;
+            const int m = (int)s.hCounts[12], nl = s.hasLeft ? (int)s.hCounts[6] : 0, nr = s.hasRight ? (int)s.hCounts[9] : 0;   // m: kept
             const int n = nl + m + nr;
             if (n > 0)
                 k_slab_unpack<<<blocks_for(n), 256, 0, st>>>(s.pos, s.vel, s.ids, s.extra, s.extraFloats, s.recvL.p, nl, s.own.p, m, s.recvR.p, nr);
@@ -351,20 +403,22 @@ struct sphx_slab_group {
         }
     }
 
-    // after the local sort: where the ghost and edge layers are (cell starts at five column boundaries)
+    // after the local sort: where the ghost and edge layers are (cell starts at six column boundaries of the global grid)
     void updateLayers()
     {
         hipStream_t st = sphx::stream();
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            const int L = s.cellsPerColumn, w = s.ghost, gl = s.localColumns;
-            k_slab_pick5<<<1, 64, 0, st>>>(s.cellStart, w * L, 2 * w * L, (gl - 2 * w) * L, (gl - w) * L, gl * L, s.layerOut.p);
-            hip_ok(hipMemcpyAsync(s.hInts, s.layerOut.p, 5 * sizeof(int), hipMemcpyDeviceToHost, st), "layers");
+            const int L = s.cellsPerColumn, w = s.ghost;
+            auto at = [&](int column) { return std::min(std::max(column, 0), s.gx) * L; };
+            k_slab_pick6<<<1, 64, 0, st>>>(s.cellStart, at(s.x0 - w), at(s.x0), at(s.x0 + w), at(s.x1 - w), at(s.x1), at(s.x1 + w), s.layerOut.p);
+            hip_ok(hipMemcpyAsync(s.hInts, s.layerOut.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st), "layers");
         }
         sync("layer offsets");
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            for (int k = 0; k < 5; ++k) s.layer[k] = s.hInts[k];
+            if (s.hInts[0] != 0 || s.hInts[5] != s.held) die("slab: a held particle lies outside the slab's ghost range");
+            for (int k = 0; k < 5; ++k) s.layer[k] = s.hInts[k + 1];
             s.o0 = s.layer[0]; s.o1 = s.layer[3];
         }
     }
@@ -615,24 +669,10 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         if (rccl_id128) G->transport.reset(new RcclTransport(first_rank, world, rccl_id128));
         else G->transport.reset(new LoopbackTransport());
 
-        // global boundary masses from a boundary-only whole-domain system (SPHSystem.cu:69-71), cell-sorted
-        std::vector<float> bpos((size_t)3 * n_boundary), bmass((size_t)n_boundary);
-        {
-            sphx_system* bs = nullptr;
-            sphx_params Pb = P; Pb.reserved[1] = 0; Pb.reserved[2] = 0;
-            const int rc = sphx_create_impl(&Pb, nullptr, 0, boundary_xyz, n_boundary, 0, &bs);
-            if (rc) die(std::string("boundary system: ") + sphx_last_error());
-            if (n_boundary) {
-                if (sphx_get(bs, SPHX_F_BPOS, bpos.data(), sizeof(float) * bpos.size()) || sphx_get(bs, SPHX_F_BMASS, bmass.data(), sizeof(float) * bmass.size()))
-                    die("boundary system: read-back failed");
-            }
-            sphx_destroy(bs);
-        }
         // columns by the engine's expression on the host (IEEE division, truncation)
         auto column_of = [&](float x) { volatile float q = x / P.cell_length; return (int)q; };
-        std::vector<int> col((size_t)n_fluid), bcol((size_t)n_boundary);
+        std::vector<int> col((size_t)n_fluid);
         for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
-        for (int i = 0; i < n_boundary; ++i) bcol[i] = column_of(bpos[3 * (size_t)i]);
         const std::vector<int> cuts = choose_cuts(col, gx, world, ghost + 1);
         std::vector<long long> perSlab((size_t)world, 0);
         for (int c : col) { int r = 0; while (r + 1 < world && c >= cuts[r + 1]) ++r; if (c >= 0 && c < gx) perSlab[r]++; }
@@ -642,24 +682,20 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             std::unique_ptr<Slab> S(new Slab());
             Slab& s = *S;
             s.rank = r; s.world = world; s.x0 = cuts[r]; s.x1 = cuts[r + 1]; s.ghost = ghost;
-            s.cellsPerColumn = gy * gz; s.localColumns = (s.x1 - s.x0) + 2 * ghost; s.cellLength = P.cell_length;
+            s.cellsPerColumn = gy * gz; s.gx = gx; s.cellLength = P.cell_length;
             s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
             s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
             s.capacity = (int)std::min<long long>((long long)(most * 1.3) + 4096, 2000000000LL);
-            // the slab's engine: a sub-grid of localColumns columns whose column 0 is global column x0 - ghost
+            // The slab's engine works on the WHOLE grid (cell tables are a few tens of MB even at 10 M particles) and
+            // holds the whole boundary set, whose masses it computes like any system (SPHSystem.cu:69-71): only the
+            // particles it is handed are local.  Cut planes are then just two numbers of this driver and may move.
             sphx_params Pl = P;
-            Pl.cells[0] = s.localColumns; Pl.reserved[1] = s.x0 - ghost; Pl.reserved[2] = 1;
-            std::vector<float> bsel, msel;
-            for (int i = 0; i < n_boundary; ++i)
-                if (bcol[i] >= s.x0 - ghost && bcol[i] <= s.x1 + ghost - 1) {
-                    bsel.insert(bsel.end(), {bpos[3 * (size_t)i], bpos[3 * (size_t)i + 1], bpos[3 * (size_t)i + 2]});
-                    msel.push_back(bmass[i]);
-                }
-            std::vector<float> zeros((size_t)3 * s.capacity, 0.0f);
-            const int rc = sphx_create_impl(&Pl, zeros.data(), s.capacity, bsel.data(), (int)msel.size(), 0, &s.sys);
-            if (rc) die(std::string("slab engine: ") + sphx_last_error());
-            zeros.clear(); zeros.shrink_to_fit();
-            if (!msel.empty() && sphx_set(s.sys, SPHX_F_BMASS, msel.data(), sizeof(float) * msel.size())) die("slab engine: boundary masses");
+            Pl.reserved[1] = 0; Pl.reserved[2] = 1;          // a slab system: no initial fluid sort, stage-wise stepping
+            {
+                std::vector<float> zeros((size_t)3 * s.capacity, 0.0f);
+                const int rc = sphx_create_impl(&Pl, zeros.data(), s.capacity, boundary_xyz, n_boundary, 0, &s.sys);
+                if (rc) die(std::string("slab engine: ") + sphx_last_error());
+            }
             // engine arrays
             const auto f = s.sys->system->getFluids();
             s.pos = f->getPosPtr(); s.vel = f->getVelPtr(); s.ids = f->getIdPtr(); s.density = f->getDensityPtr();
@@ -668,10 +704,11 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             if (P.solver == SPHX_PBD) s.extra = reinterpret_cast<float*>(s.sys->pbd->getPosLast().addr());
             // scratch
             const size_t cap = (size_t)s.capacity, W = (size_t)s.width();
-            s.flagL.alloc(cap); s.flagR.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.blockSums.alloc(cap / 2048 + 2);
-            s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(4);
+            s.flagL.alloc(cap); s.flagR.alloc(cap); s.flagK.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.scanK.alloc(cap); s.blockSums.alloc(cap / 2048 + 2);
+            s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(13);
             s.own.alloc(cap * W); s.sendL.alloc(cap * W); s.sendR.alloc(cap * W); s.recvL.alloc(cap * W); s.recvR.alloc(cap * W);
-            hip_ok(hipHostMalloc((void**)&s.hCounts, 4 * sizeof(long long), hipHostMallocDefault), "pinned counts");
+            hip_ok(hipHostMalloc((void**)&s.hCounts, 13 * sizeof(long long), hipHostMallocDefault), "pinned counts");
+            hip_ok(hipHostMalloc((void**)&s.hSend, 3 * sizeof(long long), hipHostMallocDefault), "pinned size words");
             hip_ok(hipHostMalloc((void**)&s.hInts, 8 * sizeof(int), hipHostMallocDefault), "pinned ints");
             // initial distribution: this slab's particles in generation order, ids = global generation index
             std::vector<float> p0, v0; std::vector<int> id0;
@@ -758,6 +795,14 @@ int sphx_slab_gather(sphx_slab_group* g, int index, int capacity, int* ids, floa
         hip_ok(hipStreamSynchronize(st), "gather sync");
         return (int)SPHX_OK;
     });
+}
+
+int sphx_slab_set_rebalance(sphx_slab_group* g, int every_steps, float tolerance)
+{
+    if (!g || tolerance < 0.0f) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_set_rebalance: bad argument");
+    g->rebalanceEvery = every_steps;
+    g->rebalanceTol = tolerance;
+    return SPHX_OK;
 }
 
 int sphx_slab_iters(const sphx_slab_group* g, int* div, int* den)

@@ -260,7 +260,7 @@ def sample_triangles(tri, spacing):
 # ------------------------------------------------------------------------------------ native slab layer
 SLAB_NO_OVERLAP, SLAB_SWEEP_GHOSTS = 1, 2
 SLAB_EXPORTS = ["sphx_slab_rccl_unique_id", "sphx_slab_create", "sphx_slab_destroy", "sphx_slab_step", "sphx_slab_info",
-                "sphx_slab_gather", "sphx_slab_iters", "sphx_slab_system", "sphx_slab_wait_seconds"]
+                "sphx_slab_gather", "sphx_slab_iters", "sphx_slab_system", "sphx_slab_wait_seconds", "sphx_slab_set_rebalance"]
 
 
 def rccl_unique_id():
@@ -284,6 +284,7 @@ class SlabGroup:
         L.sphx_slab_system.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.sphx_slab_wait_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.sphx_slab_destroy.argtypes = [C.c_void_p]
+        L.sphx_slab_set_rebalance.argtypes = [C.c_void_p, C.c_int, C.c_float]
         fluid = np.ascontiguousarray(fluid, np.float32).reshape(-1, 3)
         boundary = np.ascontiguousarray(boundary, np.float32).reshape(-1, 3)
         vel = None if velocity is None else np.ascontiguousarray(velocity, np.float32).reshape(-1, 3)
@@ -299,6 +300,9 @@ class SlabGroup:
         ms = C.c_float()
         _check(lib().sphx_slab_step(self._h, n, C.byref(ms)))
         return ms.value
+
+    def set_rebalance(self, every_steps, tolerance=0.05):
+        _check(lib().sphx_slab_set_rebalance(self._h, every_steps, tolerance))
 
     def info(self, index=0):
         v = [C.c_int() for _ in range(4)]

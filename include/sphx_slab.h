@@ -8,6 +8,9 @@
  * each per-particle sum visits the same neighbours in the same order: the distributed run is bit-identical to
  * SPHSystem::step() on one device for any number of slabs (tests/test_gpu_slab.py).
  *
+ * Every slab's engine works on the whole grid and the whole boundary set and is only handed its own particles, so
+ * the cut planes are two numbers of the driver: they are re-balanced while the fluid spreads (sphx_slab_set_rebalance).
+ *
  * One step = particle exchange (migrants and ghost copies, after last step's advect) -> local cell sort -> the
  * solver's stages (sphx_phase in sphx_c.h) with a halo refresh after every stage that writes a field the next
  * stage reads from neighbours.  With overlap on (default) a stage runs on the two edge layers first, the halo
@@ -51,6 +54,12 @@ int sphx_slab_destroy(sphx_slab_group *g);
 /* n steps; the k-th step since creation equals the k-th SPHSystem::step() of the single-device system counting its
  * constructor step.  *ms_total: wall time of the batch on this process (host clock, device synchronised).        */
 int sphx_slab_step(sphx_slab_group *g, int n, float *ms_total);
+
+/* Cut re-balancing: every `every_steps` steps (<= 0: never; default 16) a cut plane moves by one cell column
+ * towards the lighter of its two slabs when their owned particle counts differ by more than `tolerance`
+ * (relative; default 0.05).  The dam break spreads along x, so static cuts lose balance exactly when the
+ * interesting part starts.  Must be set identically on every rank.  Results do not depend on it.       */
+int sphx_slab_set_rebalance(sphx_slab_group *g, int every_steps, float tolerance);
 
 /* geometry and sizes of local slab `index`: owned cell columns [x0, x1), particles owned / held incl. ghosts */
 int sphx_slab_info(const sphx_slab_group *g, int index, int *x0, int *x1, int *owned, int *held);

@@ -110,3 +110,32 @@ def test_native_slab_layer_rccl_transport_single_rank(oracle, tmp_path):
     rp, rv, rd, rit = _single_domain(oracle, nx, steps, seed, "dfsph", True, want_iters=True)
     assert_bit_equal(z["pos"], rp, "rccl(1) pos"); assert_bit_equal(z["density"], rd, "rccl(1) density")
     assert tuple(z["iters"]) == rit
+
+
+@pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("pbd", False), ("dfsph", True)])
+def test_native_slab_layer_moving_cuts(sphx, oracle, solver, adaptive):
+    """cut re-balancing forced to act every step with zero tolerance (4 slabs, a splash that sloshes along x): columns
+    change owners while particles migrate; the result still equals the single-domain oracle bit for bit"""
+    nx, steps, seed, world = 24, 8, 29, 4
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, adaptive)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    g = sphx.SlabGroup(P, pos, boundary, world, velocity=vel)
+    g.set_rebalance(1, 0.0)
+    cuts0 = [g.info(i)[:2] for i in range(world)]
+    seen = set()
+    for _ in range(steps):
+        g.step()
+        cuts = tuple(g.info(i)[:2] for i in range(world))
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1)), "neighbours must agree on every cut: %s" % (cuts,)
+        assert cuts[0][0] == 0 and cuts[-1][1] == P.cells[0]
+        seen.add(cuts)
+    ids, p, v, d = g.gather_all()
+    it = g.iters()
+    g.close()
+    assert len(seen) > 1, "the cuts must have moved (initial %s)" % (cuts0,)
+    rp, rv, rd, rit = _single_domain(oracle, nx, steps, seed, solver, adaptive, want_iters=True)
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32))
+    assert_bit_equal(p, rp, "moving cuts pos"); assert_bit_equal(v, rv, "moving cuts vel"); assert_bit_equal(d, rd, "moving cuts density")
+    if solver == "dfsph":
+        assert it == rit
