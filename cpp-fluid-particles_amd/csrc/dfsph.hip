@@ -43,6 +43,7 @@ float DFSPHSolver::readErrorTotal()
 }
 
 namespace {
+constexpr int kPhaseSurfaceThenWarm = 1000;     // internal stage of the single-device schedule (not part of sphx_phase)
 template <bool DENSITY_MODE, int WARM>
 void launch_rate(const OpRate& op, int n, bool reduce, bool keepAccum = false)
 {
@@ -212,8 +213,12 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     }
     run(SPHX_PH_FORCE);
     run(SPHX_PH_VISC_COLOR);
-    run(SPHX_PH_SURFACE);
-    run(SPHX_PH_WARM_CORRECT);
+    if (surface) {
+        run(kPhaseSurfaceThenWarm);     // one row walk for the surface sweep and the warm-start correction
+    } else {
+        run(SPHX_PH_SURFACE);
+        run(SPHX_PH_WARM_CORRECT);
+    }
     run(SPHX_PH_DEN_ERROR_SET);
     {
         const bool adaptive = fixedDen < 0;
@@ -303,6 +308,12 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
             const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, num) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, num) : num;
             launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
         }
+        break;
+    }
+    case kPhaseSurfaceThenWarm: {
+        ScopedKernel t("surface_warm_correct");
+        launch_op(OpSurfaceThen<1>{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), denWarmStiff.addr(), rho0,
+                                   surfaceTensionIntensity, airPressure, dt}, num);
         break;
     }
     case SPHX_PH_WARM_CORRECT: {

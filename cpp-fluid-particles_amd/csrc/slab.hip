@@ -797,6 +797,29 @@ int sphx_slab_gather(sphx_slab_group* g, int index, int capacity, int* ids, floa
     });
 }
 
+int sphx_slab_plan_cuts(const sphx_params* params, const float* fluid_xyz, int n_fluid, int world, int* cuts, long long* counts)
+{
+    if (!params || (n_fluid && !fluid_xyz) || n_fluid < 0 || world < 1 || !cuts) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_plan_cuts: bad argument");
+    return slab_guarded("sphx_slab_plan_cuts", [&] {
+        auto column_of = [&](float x) { volatile float q = x / params->cell_length; return (int)q; };
+        std::vector<int> col((size_t)n_fluid);
+        for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
+        const int ghost = params->solver == SPHX_PBD ? 2 : 1;
+        const std::vector<int> c = choose_cuts(col, params->cells[0], world, ghost + 1);
+        for (int r = 0; r <= world; ++r) cuts[r] = c[r];
+        if (counts) {
+            for (int r = 0; r < world; ++r) counts[r] = 0;
+            for (int x : col) { int r = 0; while (r + 1 < world && x >= c[r + 1]) ++r; if (x >= 0 && x < params->cells[0]) counts[r]++; }
+        }
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_cut_rule(long long owned_left, long long owned_right, int width_left, int width_right, int ghost, float tolerance)
+{
+    return sphx_slab_group::cut_shift(owned_left, owned_right, width_left, width_right, ghost, tolerance);
+}
+
 int sphx_slab_set_rebalance(sphx_slab_group* g, int every_steps, float tolerance)
 {
     if (!g || tolerance < 0.0f) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_set_rebalance: bad argument");

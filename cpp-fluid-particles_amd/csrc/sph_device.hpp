@@ -322,7 +322,8 @@ __device__ __forceinline__ void clamp_box(float3& p, float3& v, const float3 spa
     if (p.z >= hz) { p.z = hz; if (WITH_VEL) v.z = min0(v.z); }
 }
 
-template <class F> __device__ __forceinline__ F scalar_field(float v);
+// (ops whose Field is neither never run one-gather sweeps; the generic form only keeps their instantiation well-formed)
+template <class F> __device__ __forceinline__ F scalar_field(float) { return F{}; }
 template <> __device__ __forceinline__ float scalar_field<float>(float v) { return v; }
 template <> __device__ __forceinline__ float4 scalar_field<float4>(float v) { return make_float4(v, 0.0f, 0.0f, 0.0f); }
 

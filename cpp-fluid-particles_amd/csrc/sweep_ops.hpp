@@ -186,6 +186,75 @@ struct OpSurface {
     }
 };
 
+// The surface sweep fused with the sweep that follows it in the step when that one reads nothing the surface sweep
+// writes for the NEIGHBOURS (both only update the particle's own velocity):
+//   NEXT = 1  DFSPH: + the warm-start density correction (correctDensityError_CUDA with last step's stiffness,
+//             DFSPHSolver.cu:138-158, :181-183)
+//   NEXT = 2  WCSPH: + the pressure force (pressureForce_CUDA, BasicSPHSolver.cu:113-165)
+// One row walk instead of two, and gradW of the pair is evaluated once for both.  The velocity is updated in the
+// order of the separate sweeps (surface first), each with its own rounding, so the result has the same bits.
+template <int NEXT>
+struct OpSurfaceThen {
+    SweepCtx c;
+    const float3* colorGrad; const float3* velIn; const float3* addend; float3* velOut;
+    const float* scalar;    // NEXT 1: warm stiffness kappa; NEXT 2: pressure term p / max(EPS, rho^2)
+    float rho0, tension, airPressure, dt;
+    struct Field { float4 cg; float s; };
+    __device__ __forceinline__ Field stage(bool isB, int j) const { return Field{field4(c.cg4, j), fluid_only(scalar, isB, j)}; }
+    struct Body {
+        const OpSurfaceThen& o; float dii, li, ml, si; float3 a; float3 b;
+        template <bool FAST>
+        __device__ __forceinline__ void pair(Field f, bool isB, float3 d, float r2, float mj, int)
+        {
+            const float r = sqrt_sel<FAST>(r2);
+            const float q = q_of<FAST>(r, o.c.k);
+            const float3 gw = kGradW<FAST>(d, q, o.c.k);
+            if (!isB) {           // the surface sweep ignores boundary particles (BasicSPHSolver.cu:350-362)
+                const float3 cgj = xyz(f.cg);
+                a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
+                a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), gw), li), ml));
+            }
+            if (NEXT == 1) b = add3(b, smul3(mj * (si + f.s), gw));
+            else b = add3(b, smul3(-mj * (si + f.s), gw));
+        }
+        __device__ __forceinline__ void pair_tol(Field f, bool isB, float3 d, float r2, float mj)
+        {
+#pragma clang fp contract(fast)
+            const TolPair t = tol_pair(r2, o.c.k);
+            const float g = tol_gradW_scale(t, o.c.k);
+            if (!isB) {
+                const float m2 = mj * __builtin_amdgcn_rcpf(o.rho0 * o.rho0);
+                const float s = 0.25f * m2 * o.tension * (dii + f.cg.x * f.cg.x + f.cg.y * f.cg.y + f.cg.z * f.cg.z) * tol_surf_scale(t, o.c.k) +
+                                o.airPressure * m2 * g * li * __builtin_amdgcn_rcpf(ml);
+                a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+            }
+            const float sb = (NEXT == 1 ? mj : -mj) * (si + f.s) * g;
+            b = v3(b.x + d.x * sb, b.y + d.y * sb, b.z + d.z * sb);
+        }
+    };
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
+    {
+        const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
+        const float li = len3(cgi);
+        Body body{*this, dot3(cgi, cgi), li, max_eps(li), valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
+        if (!valid) return;
+        float3 v = velIn[i];
+        if (addend) v = add3(v, addend[i]);
+        const float3 vs = add3(v, mul3s(body.a, dt));                 // what the surface sweep alone would have stored
+        float3 vn;
+        if (NEXT == 1) {
+            vn = add3(vs, div3s(body.b, dt));                         // OpCorrect<true>
+        } else {
+            float3 acc = body.b;                                      // OpPressureForce
+            if (len3(acc) > kMaxA) acc = mul3s(mul3s(acc, 1.0f / sqrtf(dot3(acc, acc))), kMaxA);
+            vn = add3(vs, mul3s(acc, dt));
+        }
+        velOut[i] = vn;
+        c.vel4[i] = f4(vn);
+    }
+};
+
 // pressureForce_CUDA, BasicSPHSolver.cu:113-165
 struct OpPressureForce {
     SweepCtx c;

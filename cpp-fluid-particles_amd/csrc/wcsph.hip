@@ -151,8 +151,11 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
         advect(fluids, dt, spaceSize);
         return;
     }
-    for (int ph : {SPHX_PH_W_SEARCH, SPHX_PH_W_PROPS, SPHX_PH_W_SURFACE, SPHX_PH_W_PRESSURE, SPHX_PH_ADVECT})
-        runWcsphPhase(ph, fluids, boundaries, cellStartFluid, cellStartBoundary, spaceSize, cellSize, cellLength, radius, dt,
+    const int fusedTail = 1001;       // internal stage: surface sweep + pressure force in one row walk
+    const bool fuseTail = surface;
+    for (int ph : {(int)SPHX_PH_W_SEARCH, (int)SPHX_PH_W_PROPS, fuseTail ? fusedTail : (int)SPHX_PH_W_SURFACE,
+                   fuseTail ? -1 : (int)SPHX_PH_W_PRESSURE, (int)SPHX_PH_ADVECT})
+        if (ph >= 0) runWcsphPhase(ph, fluids, boundaries, cellStartFluid, cellStartBoundary, spaceSize, cellSize, cellLength, radius, dt,
                       rho0, rhoB, stiff, visc, G, surfaceTensionIntensity, airPressure);
 }
 
@@ -206,6 +209,12 @@ void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& flu
             const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, n) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, n) : n;
             launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
         }
+        return;
+    }
+    if (phase == 1001) {
+        ScopedKernel t("surface_pressure_force");
+        launch_op(OpSurfaceThen<2>{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), c.pterm.addr(), rho0,
+                                   surfaceTensionIntensity, airPressure, dt}, n);
         return;
     }
     if (phase == SPHX_PH_W_PRESSURE) {

@@ -61,6 +61,13 @@ int sphx_slab_step(sphx_slab_group *g, int n, float *ms_total);
  * interesting part starts.  Must be set identically on every rank.  Results do not depend on it.       */
 int sphx_slab_set_rebalance(sphx_slab_group *g, int every_steps, float tolerance);
 
+/* Host-only helpers (no GPU needed): the initial decomposition sphx_slab_create would choose — cuts[world + 1] with
+ * cuts[0] = 0, cuts[world] = params->cells[0], optional counts[world] of fluid particles per slab — and the
+ * re-balancing rule both neighbours of a cut evaluate: -1 = the left slab hands its last column to the right one,
+ * +1 = the opposite, 0 = stay.                                                                          */
+int sphx_slab_plan_cuts(const sphx_params *params, const float *fluid_xyz, int n_fluid, int world, int *cuts, long long *counts);
+int sphx_slab_cut_rule(long long owned_left, long long owned_right, int width_left, int width_right, int ghost, float tolerance);
+
 /* geometry and sizes of local slab `index`: owned cell columns [x0, x1), particles owned / held incl. ghosts */
 int sphx_slab_info(const sphx_slab_group *g, int index, int *x0, int *x1, int *owned, int *held);
 /* owned particles of local slab `index` to host arrays of `capacity` particles (ids: original indices) */

@@ -65,3 +65,30 @@ def test_cut_planes_balance_and_width():
     assert max(counts) - min(counts) <= 200
     with pytest.raises(ValueError):
         M.choose_cuts(cols, 5, 4)
+
+
+def test_native_layer_cut_planning_matches_protocol_driver(sphx):
+    """host-side pieces of the native slab layer (csrc/slab.hip) that need no GPU: its initial cuts equal the ones the
+    Python protocol driver chooses, and the re-balancing rule is consistent from both sides of a cut"""
+    import multi_gpu as M
+    for nx, world, solver in ((24, 4, sphx.DFSPH), (40, 8, sphx.DFSPH), (40, 5, sphx.PBD)):
+        P, fluid, _ = sphx.scene(nx)
+        P.solver = solver
+        cuts, counts = sphx.slab_plan_cuts(P, fluid, world)
+        col = M.cell_column(fluid[:, 0], P.cell_length)
+        want = M.choose_cuts(col, P.cells[0], world, min_width=3 if solver == sphx.PBD else 2)
+        assert cuts == want
+        assert sum(counts) == len(fluid) and max(counts) - min(counts) <= max(counts) * 0.35
+    P, fluid, _ = sphx.scene(8)
+    with pytest.raises(sphx.SphxError):
+        sphx.slab_plan_cuts(P, fluid, 8)               # 9 columns cannot hold 8 slabs
+    # the rule: hand a column to the lighter side, never shrink a slab below ghost + 4 columns, dead band = tolerance
+    assert sphx.slab_cut_rule(1200, 1000, 10, 10) == -1
+    assert sphx.slab_cut_rule(1000, 1200, 10, 10) == +1
+    assert sphx.slab_cut_rule(1040, 1000, 10, 10) == 0
+    assert sphx.slab_cut_rule(1200, 1000, 4, 10) == 0 and sphx.slab_cut_rule(1200, 1000, 5, 10) == -1
+    assert sphx.slab_cut_rule(1000, 1200, 10, 5, ghost=2) == 0 and sphx.slab_cut_rule(1000, 1200, 10, 6, ghost=2) == +1
+    rng = np.random.default_rng(3)
+    for _ in range(200):                                # mirror symmetry: swapping the sides flips the decision
+        a, b = (int(v) for v in rng.integers(1, 5000, 2)); wa, wb = (int(v) for v in rng.integers(2, 12, 2))
+        assert sphx.slab_cut_rule(a, b, wa, wb) == -sphx.slab_cut_rule(b, a, wb, wa)
