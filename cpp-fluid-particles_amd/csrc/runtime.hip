@@ -75,6 +75,8 @@ KernelConsts make_kernel_consts(float R)
     k.rcpR = 1.0f / R;
     k.fastQ = 0;
     k.fastDiv = 0;
+    k.rcpViscDen = 1.0f / k.viscDen;
+    k.fastVisc = 0;
     k.tol = 0;
     k.twoOverR = 2.0f / R;
     k.gradScale = 1.0f / (kPi * R * R * R * R * R);
@@ -95,6 +97,18 @@ __global__ void k_check_q_division(KernelConsts k, unsigned int lastBits, unsign
         bad += (__float_as_uint(div_by_radius<true>(x, k)) != __float_as_uint(x / k.R)) ? 1u : 0u;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(div_by_radius<true>(0.0f, k)) != __float_as_uint(0.0f / k.R)) ? 1u : 0u;
+    if (bad) atomicAdd(mismatches, bad);
+}
+// every float x in {0} U [firstBits, lastBits]: the refined x * (1/den) against the plain quotient
+__global__ void k_check_const_division(float den, float rcp, unsigned int firstBits, unsigned int lastBits, unsigned int* mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    for (unsigned long long b = firstBits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= lastBits; b += stride) {
+        const float x = __uint_as_float((unsigned int)b);
+        bad += (__float_as_uint(div_by_const_refined(x, den, rcp)) != __float_as_uint(x / den)) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(div_by_const_refined(0.0f, den, rcp)) != __float_as_uint(0.0f / den)) ? 1u : 0u;
     if (bad) atomicAdd(mismatches, bad);
 }
 __global__ void k_check_sqrt(unsigned int firstBits, unsigned int lastBits, unsigned int* mismatches)
@@ -160,6 +174,14 @@ void validate_fast_math(KernelConsts& k)
     HIP_CALL(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream()));
     HIP_CALL(hipStreamSynchronize(stream()));
     k.fastQ = (bad == 0) ? 1 : 0;
+    // the viscosity laplacian's division by PI R^6 (numerators 45 (R - r): 0 or >= 45 ulp(R))
+    HIP_CALL(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream()));
+    unsigned int lastV; const float topV = 46.0f * R; std::memcpy(&lastV, &topV, 4);
+    k_check_const_division<<<8192, 256, 0, stream()>>>(k.viscDen, k.rcpViscDen, 0x2b800000u /* 2^-40 */, lastV, d_bad);
+    bad = 1;
+    HIP_CALL(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream()));
+    HIP_CALL(hipStreamSynchronize(stream()));
+    k.fastVisc = (bad == 0 && 45.0f * (R - nextafterf(R, 0.0f)) >= ldexpf(1.0f, -40)) ? 1 : 0;
     (void)hipFree(d_bad);
 }
 
@@ -179,6 +201,8 @@ void fastmath_selftest(float R, unsigned long long samples, unsigned int out[3],
     const float r5 = R * R * R * R * R;
     KernelConsts kf = k; kf.fastDiv = 1;
     k_check_div3<<<8192, 256, 0, stream()>>>(kf, fminf(kPi * kEps * r5, k.stK * kEps), fmaxf(kPi * 2.1f * r5, k.stK * R), samples, d_bad + 2);
+    // ... and over the denominators of the surface sweep's division by max(EPS, |colorGrad|): [2^-20, 2^16]
+    k_check_div3<<<8192, 256, 0, stream()>>>(kf, ldexpf(1.0f, -20), ldexpf(1.0f, 16), samples / 4 + 1, d_bad + 2);
     HIP_CALL(hipMemcpyAsync(out, d_bad, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
     HIP_CALL(hipStreamSynchronize(stream()));
     (void)hipFree(d_bad);

@@ -30,6 +30,8 @@ struct KernelConsts {
     int fastQ;      // 1: x/R == fma-refined x*rcpR for EVERY float x in [0, 2.2R] (checked exhaustively)
     int fastDiv;    // 1: the denominators of gradW / surface gradient stay inside [2^-90, 2^16]
     int q2Free;     // 1: r2 <= tCut implies q <= 2 and r <= R, i.e. row entries never fail a support test
+    float rcpViscDen;   // RN(1 / viscDen)
+    int fastVisc;   // 1: x / viscDen == fma-refined x * rcpViscDen for EVERY float x in {0} U [2^-40, 46 R] (checked exhaustively)
     // --- tolerance arithmetic (sphx_params.reserved[3] = 1): hardware rsq / rcp, fused multiply-adds, constants folded
     int tol;        // 1: row walks use the pair_tol bodies
     float twoOverR;     // 2 / R
@@ -126,6 +128,15 @@ __device__ __forceinline__ float div_by_radius(float x, const KernelConsts& k)
     return __builtin_fmaf(__builtin_fmaf(-k.R, q0, x), k.rcpR, q0);
 }
 
+// x / den for a constant den with y = RN(1/den): the same two refinement steps; valid only where validate_fast_math
+// has compared it with the plain operator for every float of the range in use
+__device__ __forceinline__ float div_by_const_refined(float x, float den, float y)
+{
+    float q0 = x * y;
+    q0 = __builtin_fmaf(__builtin_fmaf(-den, q0, x), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-den, q0, x), y, q0);
+}
+
 // true when this pair must use the plain operators: a positive squared distance below 2^-96 (then
 // r < 2^-48 as well), a non-zero displacement component below 2^-101, or fast paths not validated
 // (positions are frozen while a row is valid, so the row builder evaluates this once per pair and
@@ -163,7 +174,9 @@ __device__ __forceinline__ float3 kGradW(float3 d, float q, const KernelConsts& 
 template <bool FAST>
 __device__ __forceinline__ float kViscLap(float r, const KernelConsts& k)
 {
-    const float l = 45.0f * (k.R - r) / k.viscDen;
+    const float x = 45.0f * (k.R - r);
+    // (row entries have r <= R, so x is 0 or at least 45 ulp(R) > 2^-40: inside the validated range)
+    const float l = (FAST && k.fastVisc) ? div_by_const_refined(x, k.viscDen, k.rcpViscDen) : x / k.viscDen;
     return (FAST || r <= k.R) ? l : 0.0f;
 }
 // surface_tension_kernel_gradient, CUDAFunctions.cuh:82-98

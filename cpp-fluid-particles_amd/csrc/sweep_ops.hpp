@@ -85,18 +85,24 @@ struct OpFluidProps {
     __device__ __forceinline__ Field stage(bool, int j) const { return VISC ? field4(c.vel4, j) : f4zero(); }
     struct Body {
         const OpFluidProps& o; float3 vi; float3 a; float3 cg; float cden; float den;
+        float mRef, volRef;       // this particle's mass and mRef / rho0: the volume of every fluid neighbour of that mass
         template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
             const float r = sqrt_sel<FAST>(r2);
-            if (VISC && !isB)
-                a = add3(a, mul3s(smul3(mj, div3s(sub3(xyz(vj), vi), o.rho0)), kViscLap<FAST>(r, o.c.k)));
+            if (VISC && !isB) {
+                const float3 dv = sub3(xyz(vj), vi);
+                // x / 1.0f is x: the reference scene's rho0 = 1 needs no division (launch-uniform test)
+                a = add3(a, mul3s(smul3(mj, (o.rho0 == 1.0f) ? dv : div3s(dv, o.rho0)), kViscLap<FAST>(r, o.c.k)));
+            }
             if (COLOR || DENS) {
                 const float q = q_of<FAST>(r, o.c.k);
                 const float w = kW<FAST>(q, o.c.k);
                 if (DENS) den += mj * w;
                 if (COLOR) {
-                    const float vol = mj / (isB ? o.rhoB : o.rho0);
+                    // same operands, same quotient: only neighbours of another mass (boundaries) divide
+                    float vol = volRef;
+                    if (__any(isB || mj != mRef)) vol = mj / (isB ? o.rhoB : o.rho0);
                     cg = add3(cg, smul3(vol, kGradW<FAST>(d, q, o.c.k)));
                     cden += vol * w;
                 }
@@ -124,7 +130,8 @@ struct OpFluidProps {
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, (VISC && valid) ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f};
+        const float mRef = valid ? c.posm[i].w : 0.0f;
+        Body b{*this, (VISC && valid) ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f, mRef, mRef / rho0};
         sweep<COLOR || DENS>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!valid) return;
         if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
@@ -141,6 +148,42 @@ struct OpFluidProps {
     }
 };
 
+// Per-particle constants of the surface sweep's pair term (BasicSPHSolver.cu:350-362).  The two coefficients depend on
+// the neighbour only through its mass: for a neighbour of this particle's own mass they are computed once (same
+// operands, same association, same bits).  The three divisions by ml = max(EPS, |colorGrad_i|) share one denominator:
+// the refined-reciprocal division of sph_device.hpp gives the IEEE quotients when ml is in [2^-90, 2^16] and no
+// numerator component is a non-zero value below 2^-101 (tested per pair; otherwise the plain operator).
+struct SurfaceConsts {
+    float dii, li, ml, mRef, tensionRef, airRef; bool mlFast;
+    __device__ __forceinline__ float tension_coef(float mj, float rho0, float tension) const
+    {
+        float c = tensionRef;
+        if (__any(mj != mRef)) c = 0.25f * mj / (rho0 * rho0) * tension;
+        return c;
+    }
+    __device__ __forceinline__ float air_coef(float mj, float rho0, float airPressure) const
+    {
+        float c = airRef;
+        if (__any(mj != mRef)) c = airPressure * mj / (rho0 * rho0);
+        return c;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ float3 over_ml(float3 n) const
+    {
+        if (!FAST || __any(!mlFast || pair_needs_plain_ops(n, 1.0f))) return div3s(n, ml);
+        return div3_sel<true>(n, ml);
+    }
+};
+__device__ __forceinline__ SurfaceConsts surface_consts(float3 cgi, float mRef, float rho0, float tension, float airPressure)
+{
+    SurfaceConsts s;
+    s.li = len3(cgi); s.dii = dot3(cgi, cgi); s.ml = max_eps(s.li); s.mRef = mRef;
+    s.tensionRef = 0.25f * mRef / (rho0 * rho0) * tension;
+    s.airRef = airPressure * mRef / (rho0 * rho0);
+    s.mlFast = s.ml >= 8.0779357e-28f /* 2^-90 */ && s.ml <= 65536.0f;
+    return s;
+}
+
 // surfaceTensionAndAirPressure_CUDA, BasicSPHSolver.cu:332-370.  `velIn` is the velocity the
 // reference kernel would read for particle i (it only reads its own); when `addend` is given the
 // pending element-wise update vel += addend (BasicSPHSolver.cu:219-224) is applied first.
@@ -151,15 +194,15 @@ struct OpSurface {
     using Field = float4;   // neighbour colour gradient
     __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.cg4, j); }
     struct Body {
-        const OpSurface& o; float dii, li, ml; float3 a;
+        const OpSurface& o; SurfaceConsts s; float dii, li, ml; float3 a;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field cg4, bool, float3 d, float r2, float mj, int)
         {
             const float r = sqrt_sel<FAST>(r2);
             const float q = q_of<FAST>(r, o.c.k);
             const float3 cgj = xyz(cg4);
-            a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
-            a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), kGradW<FAST>(d, q, o.c.k)), li), ml));
+            a = add3(a, smul3(s.tension_coef(mj, o.rho0, o.tension) * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
+            a = add3(a, s.over_ml<FAST>(mul3s(smul3(s.air_coef(mj, o.rho0, o.airPressure), kGradW<FAST>(d, q, o.c.k)), li)));
         }
         __device__ __forceinline__ void pair_tol(Field cg4, bool, float3 d, float r2, float mj)
         {
@@ -174,8 +217,8 @@ struct OpSurface {
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
-        const float li = len3(cgi);
-        Body b{*this, dot3(cgi, cgi), li, max_eps(li), v3(0, 0, 0)};
+        const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
+        Body b{*this, sc, sc.dii, sc.li, sc.ml, v3(0, 0, 0)};
         sweep<false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!valid) return;
         float3 v = velIn[i];
@@ -202,7 +245,7 @@ struct OpSurfaceThen {
     struct Field { float4 cg; float s; };
     __device__ __forceinline__ Field stage(bool isB, int j) const { return Field{field4(c.cg4, j), fluid_only(scalar, isB, j)}; }
     struct Body {
-        const OpSurfaceThen& o; float dii, li, ml, si; float3 a; float3 b;
+        const OpSurfaceThen& o; SurfaceConsts s; float dii, li, ml, si; float3 a; float3 b;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field f, bool isB, float3 d, float r2, float mj, int)
         {
@@ -211,8 +254,8 @@ struct OpSurfaceThen {
             const float3 gw = kGradW<FAST>(d, q, o.c.k);
             if (!isB) {           // the surface sweep ignores boundary particles (BasicSPHSolver.cu:350-362)
                 const float3 cgj = xyz(f.cg);
-                a = add3(a, smul3(0.25f * mj / (o.rho0 * o.rho0) * o.tension * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
-                a = add3(a, div3s(mul3s(smul3(o.airPressure * mj / (o.rho0 * o.rho0), gw), li), ml));
+                a = add3(a, smul3(s.tension_coef(mj, o.rho0, o.tension) * (dii + dot3(cgj, cgj)), kSurfGrad<FAST>(d, r, o.c.k)));
+                a = add3(a, s.template over_ml<FAST>(mul3s(smul3(s.air_coef(mj, o.rho0, o.airPressure), gw), li)));
             }
             if (NEXT == 1) b = add3(b, smul3(mj * (si + f.s), gw));
             else b = add3(b, smul3(-mj * (si + f.s), gw));
@@ -235,8 +278,8 @@ struct OpSurfaceThen {
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
-        const float li = len3(cgi);
-        Body body{*this, dot3(cgi, cgi), li, max_eps(li), valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
+        const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
+        Body body{*this, sc, sc.dii, sc.li, sc.ml, valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
         sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
         if (!valid) return;
         float3 v = velIn[i];
@@ -597,6 +640,7 @@ struct OpXsph {
     __device__ __forceinline__ Field stage(bool, int j) const { return field4(c.vel4, j); }
     struct Body {
         const OpXsph& o; float3 vi; float3 a; float3 cg; float cden;
+        float mRef, volRef;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
@@ -604,7 +648,8 @@ struct OpXsph {
             const float w = kW<FAST>(q, o.c.k);
             if (!isB) a = add3(a, mul3s(smul3(mj, sub3(xyz(vj), vi)), w));
             if (COLOR) {
-                const float vol = mj / (isB ? o.rhoB : o.rho0);
+                float vol = volRef;
+                if (__any(isB || mj != mRef)) vol = mj / (isB ? o.rhoB : o.rho0);
                 cg = add3(cg, smul3(vol, kGradW<FAST>(d, q, o.c.k)));
                 cden += vol * w;
             }
@@ -625,7 +670,8 @@ struct OpXsph {
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
-        Body b{*this, valid ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f};
+        const float mRef = valid ? c.posm[i].w : 0.0f;
+        Body b{*this, valid ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, mRef, mRef / rho0};
         sweep<COLOR>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!valid) return;
         velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));   // not the live velocity yet: vel4 untouched
