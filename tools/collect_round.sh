@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): everything profiles/rNN_* is made from, in one call.
+#   tools/collect_round.sh r02
+set -u
+TAG=${1:-r02}
+R=$PWD
+mkdir -p gpurun_out
+bash tools/profile_gpu.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
+python bench.py > gpurun_out/bench_${TAG}_1gpu.json 2> gpurun_out/bench_${TAG}_1gpu.err
+python tools/probe_step.py wcsph263k dfsph1m pbd1m dfsph10m 2>/dev/null | grep -v amdgpu > gpurun_out/probe_$TAG.txt
+python tools/pcie_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/pcie_$TAG.txt
+for s in 1 8; do python bench.py --force-slab --slabs $s --steps 20 2>/dev/null > gpurun_out/bench_${TAG}_loopback_${s}slabs.json; done
+python tools/settle_probe.py 190 300 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_fixed14.txt
+python tools/settle_probe.py 190 350 -1 -1 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_adaptive.txt
+python tools/settle_probe.py 88 450 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_88_fixed14.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -v "PBD:\|amdgpu\|Could not read\|iommu" | tail -4 > gpurun_out/pytest_gpu_tail_$TAG.txt
+cat gpurun_out/pytest_gpu_tail_$TAG.txt; cat gpurun_out/pcie_$TAG.txt; grep "ms/step" gpurun_out/probe_$TAG.txt

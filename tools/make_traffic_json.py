@@ -1,0 +1,24 @@
+"""profiles/traffic.json from the counter passes of tools/profile_gpu.sh (gpurun_out/traffic_<tag>.json).
+   python tools/make_traffic_json.py r02 dfsph_nx190"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, key = sys.argv[1], sys.argv[2]
+src = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % tag)))["k_rate_density"]
+entry = {
+    "kernel": "k_rate<true,2,false> (computeDensityError_CUDA), one launch at 10,288,500 particles",
+    "hbm_bytes_per_launch": src["hbm_bytes_fetch_x2"],
+    "fetch_size_raw_bytes": src["FETCH_SIZE"], "write_size_bytes": src["WRITE_SIZE"],
+    "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes); separate --pmc passes",
+    "valu_busy_frac": src.get("valu_busy_frac"), "ta_busy_frac": src.get("ta_busy_frac"),
+    "l1_line_accesses_per_clk_per_cu": src.get("l1_line_accesses_per_clk_per_cu"),
+    "l2_hit_rate": src["TCC_HIT_sum"] / (src["TCC_HIT_sum"] + src["TCC_MISS_sum"]) if "TCC_HIT_sum" in src else None,
+    "avg_launch_us_rocprof": src.get("avg_launch_us_rocprof"),
+    "source_hash": src["source_hash"],
+    "source": "profiles/%s_rocprofv3_dfsph10m_summary.txt (tools/profile_gpu.sh %s)" % (tag, tag),
+}
+path = os.path.join(ROOT, "profiles", "traffic.json")
+json.dump({key: entry}, open(path, "w"), indent=1)
+print(json.dumps(entry, indent=1))
