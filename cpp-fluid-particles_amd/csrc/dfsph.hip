@@ -43,7 +43,6 @@ float DFSPHSolver::readErrorTotal()
 }
 
 namespace {
-constexpr int kPhaseSurfaceThenWarm = 1000;     // internal stage of the single-device schedule (not part of sphx_phase)
 template <bool DENSITY_MODE, int WARM>
 void launch_rate(const OpRate& op, int n, bool reduce, bool keepAccum = false)
 {
@@ -214,7 +213,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     run(SPHX_PH_FORCE);
     run(SPHX_PH_VISC_COLOR);
     if (surface) {
-        run(kPhaseSurfaceThenWarm);     // one row walk for the surface sweep and the warm-start correction
+        run(SPHX_PH_SURFACE_WARM);     // one row walk for the surface sweep and the warm-start correction
     } else {
         run(SPHX_PH_SURFACE);
         run(SPHX_PH_WARM_CORRECT);
@@ -310,7 +309,8 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         }
         break;
     }
-    case kPhaseSurfaceThenWarm: {
+    case SPHX_PH_SURFACE_WARM: {
+        if (!surface) throw "DFSPHSolver::runPhase: the fused surface stage needs surface effects enabled";
         ScopedKernel t("surface_warm_correct");
         launch_op(OpSurfaceThen<1>{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), denWarmStiff.addr(), rho0,
                                    surfaceTensionIntensity, airPressure, dt}, num);

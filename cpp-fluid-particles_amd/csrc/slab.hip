@@ -518,8 +518,12 @@ struct sphx_slab_group {
         }
         runAll(SPHX_PH_FORCE);
         sweepStage(SPHX_PH_VISC_COLOR, surface ? std::vector<int>{SPHX_F_CG4} : std::vector<int>{});
-        sweepStage(SPHX_PH_SURFACE, {SPHX_F_VEL4});
-        sweepStage(SPHX_PH_WARM_CORRECT, {SPHX_F_VEL4});
+        if (surface) {
+            sweepStage(SPHX_PH_SURFACE_WARM, {SPHX_F_VEL4});      // one row walk for both, one halo instead of two
+        } else {
+            sweepStage(SPHX_PH_SURFACE, {SPHX_F_VEL4});
+            sweepStage(SPHX_PH_WARM_CORRECT, {SPHX_F_VEL4});
+        }
         sweepStage(SPHX_PH_DEN_ERROR_SET, {SPHX_F_KAPPA, SPHX_F_POSF});
         if (!adaptive) {
             for (; itDen < d; ++itDen) {
@@ -549,8 +553,12 @@ struct sphx_slab_group {
         updateLayers();
         // W_PROPS writes the colour gradient (read by W_SURFACE) and the pressure term (read by W_PRESSURE)
         sweepStage(SPHX_PH_W_PROPS, surface ? std::vector<int>{SPHX_F_CG4, SPHX_F_PTERM, SPHX_F_POSF} : std::vector<int>{SPHX_F_PTERM, SPHX_F_POSF});
-        sweepStage(SPHX_PH_W_SURFACE, {});
-        sweepStage(SPHX_PH_W_PRESSURE, {});
+        if (surface) {
+            sweepStage(SPHX_PH_W_SURFACE_PRESSURE, {});
+        } else {
+            sweepStage(SPHX_PH_W_SURFACE, {});
+            sweepStage(SPHX_PH_W_PRESSURE, {});
+        }
         runAll(SPHX_PH_ADVECT);
     }
 

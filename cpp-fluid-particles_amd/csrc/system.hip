@@ -350,7 +350,15 @@ long long SPHSystem::errorTotalFixed()
 
 void SPHSystem::phase(int p)
 {
-    if (p >= SPHX_PH_P_SEARCH) {
+    if (p == SPHX_PH_W_SURFACE_PRESSURE) {
+        auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
+        if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
+        w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                         _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
+                         _sc.surfaceTension, _sc.airPressure);
+        return;
+    }
+    if (p >= SPHX_PH_P_SEARCH && p <= SPHX_PH_P_TAIL) {
         auto* pbd = dynamic_cast<PBDSolver*>(_solver.get());
         if (!pbd) throw "SPHSystem::phase: PBD stages need a PBDSolver";
         if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, _fluidCellStart);
@@ -359,7 +367,7 @@ void SPHSystem::phase(int p)
         if (p == SPHX_PH_P_TAIL) _graph->stepsRun++;
         return;
     }
-    if (p >= SPHX_PH_W_SEARCH || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
+    if ((p >= SPHX_PH_W_SEARCH && p <= SPHX_PH_W_PRESSURE) || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
         if (p == SPHX_PH_W_SEARCH) neighborSearch(_fluids, _fluidCellStart);

@@ -151,7 +151,7 @@ void BasicSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shar
         advect(fluids, dt, spaceSize);
         return;
     }
-    const int fusedTail = 1001;       // internal stage: surface sweep + pressure force in one row walk
+    const int fusedTail = SPHX_PH_W_SURFACE_PRESSURE;       // surface sweep + pressure force in one row walk
     const bool fuseTail = surface;
     for (int ph : {(int)SPHX_PH_W_SEARCH, (int)SPHX_PH_W_PROPS, fuseTail ? fusedTail : (int)SPHX_PH_W_SURFACE,
                    fuseTail ? -1 : (int)SPHX_PH_W_PRESSURE, (int)SPHX_PH_ADVECT})
@@ -211,7 +211,8 @@ void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& flu
         }
         return;
     }
-    if (phase == 1001) {
+    if (phase == SPHX_PH_W_SURFACE_PRESSURE) {
+        if (!surface) throw "BasicSPHSolver::runWcsphPhase: the fused surface stage needs surface effects enabled";
         ScopedKernel t("surface_pressure_force");
         launch_op(OpSurfaceThen<2>{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), c.pterm.addr(), rho0,
                                    surfaceTensionIntensity, airPressure, dt}, n);

@@ -162,7 +162,10 @@ typedef enum sphx_phase {
     SPHX_PH_P_VELOCITY,       /* vel = (pos - pos_last) / dt                    (writes vel mirror) */
     SPHX_PH_P_XSPH,           /* XSPH viscosity (+ colour gradient)             (writes cg)        */
     SPHX_PH_P_SURFACE,        /* surface tension + air pressure                                     */
-    SPHX_PH_P_TAIL            /* gravity, remember positions, predict (advect + clamp)              */
+    SPHX_PH_P_TAIL,           /* gravity, remember positions, predict (advect + clamp)              */
+    /* fused forms (one row walk, same bits): */
+    SPHX_PH_SURFACE_WARM,     /* DFSPH: SPHX_PH_SURFACE + SPHX_PH_WARM_CORRECT (surface effects on; writes vel)     */
+    SPHX_PH_W_SURFACE_PRESSURE/* WCSPH: SPHX_PH_W_SURFACE + SPHX_PH_W_PRESSURE (surface effects on)                */
 } sphx_phase;
 int  sphx_run_phase(sphx_system *sys, int phase);
 /* adaptive DFSPH across processes: the error stages (DIV_ERROR, DEN_ERROR_ACC) accumulate the exact
