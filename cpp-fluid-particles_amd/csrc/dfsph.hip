@@ -288,8 +288,9 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_VISC_COLOR: {
         if (surface) {
             ScopedKernel t("visc_color");
+            // whole-domain systems: the warm stiffness rides in posf.w for the fused surface + warm-start sweep that follows
             launch_op(OpFluidProps<true, true, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), cg.addr(), nullptr, nullptr,
-                                                      nullptr, rho0, rhoB, visc, dt, 0.0f}, num);
+                                                      nullptr, rho0, rhoB, visc, dt, 0.0f, c.isSlab ? nullptr : denWarmStiff.addr()}, num);
         } else {
             ScopedKernel t("viscosity");
             launch_op(OpFluidProps<true, false, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), nullptr, nullptr, nullptr,
@@ -313,7 +314,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         if (!surface) throw "DFSPHSolver::runPhase: the fused surface stage needs surface effects enabled";
         ScopedKernel t("surface_warm_correct");
         launch_op(OpSurfaceThen<1>{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), denWarmStiff.addr(), rho0,
-                                   surfaceTensionIntensity, airPressure, dt}, num);
+                                   surfaceTensionIntensity, airPressure, dt, !c.isSlab}, num);
         break;
     }
     case SPHX_PH_WARM_CORRECT: {

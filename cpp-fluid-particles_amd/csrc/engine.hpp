@@ -94,7 +94,9 @@ struct SweepCache {
     void packBoundary(const SPHParticles& boundaries);
     // make room for `count` boundary slots (contents of the fluid part are kept; pointers change)
     void reserveBoundary(int count);
-    void invalidatePositions() { fluidValid = false; listValid = false; orderValid = false; }
+    // (the tile schedule is only a launch order: it is kept for a few steps, particles drift slowly through the grid)
+    void invalidatePositions() { fluidValid = false; listValid = false; if (++orderAge >= 8) orderValid = false; }
+    int orderAge = 0, orderTiles = 0;
     void ensureTileOrder();
     // build the neighbour rows for the current positions (no-op when valid or disabled)
     void ensureList(const DArray<int>& csF, const DArray<int>& csB);

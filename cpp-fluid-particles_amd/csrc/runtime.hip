@@ -358,8 +358,9 @@ __global__ void k_tile_bucket_place(const int* __restrict__ key, int* __restrict
 
 void SweepCache::ensureTileOrder()
 {
-    if (orderValid || (flags & kFlagLinearTiles) || n <= 0) return;
     const int numTiles = (n + kTile - 1) / kTile;
+    if (orderValid && orderTiles != numTiles) orderValid = false;      // a schedule must be a permutation of the current tiles
+    if (orderValid || (flags & kFlagLinearTiles) || n <= 0) return;
     // y-chunks: about 1.5 MB of (position + one 16-byte field) for three x-layers of a chunk
     const double layerBytes = (double)g.gy * g.gz * 7.0 * 32.0;
     // only worth its ~40 us when three x-layers clearly exceed an XCD's 4 MB L2 (measured: +5 % at
@@ -375,7 +376,7 @@ void SweepCache::ensureTileOrder()
     k_tile_bucket_count<<<blocks_for(numTiles), 256, 0, stream()>>>(fluid4(), n, g, chunkCells, chunks, tileKey.addr(), tileBuckets->addr(), numTiles);
     k_tile_bucket_scan<<<1, 256, 0, stream()>>>(tileBuckets->addr(), buckets);
     k_tile_bucket_place<<<blocks_for(numTiles), 256, 0, stream()>>>(tileKey.addr(), tileBuckets->addr(), tileOrder.addr(), numTiles);
-    orderValid = true;
+    orderValid = true; orderAge = 0; orderTiles = numTiles;
 }
 
 // Row construction, one wave per 64-particle tile.  STREAM: each wave first decides whether its tile
@@ -494,8 +495,8 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.n = n;
     c.vel4 = vel4w();
     c.cg4 = cg4w();
-    c.tileOrder = (orderValid && !(flags & kFlagLinearTiles)) ? tileOrder.addr() : nullptr;
     c.numTiles = (n + kTile - 1) / kTile;
+    c.tileOrder = (orderValid && orderTiles == c.numTiles && !(flags & kFlagLinearTiles)) ? tileOrder.addr() : nullptr;
     c.tile0 = 0; c.lo = 0; c.hi = n;
     if (rangeLo >= 0) {                       // a contiguous sub-range: linear tiles from the first one it touches
         c.lo = std::min(rangeLo, n); c.hi = std::min(std::max(rangeHi, c.lo), n);

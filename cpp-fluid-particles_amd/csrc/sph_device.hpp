@@ -562,6 +562,11 @@ template <class Op> __device__ __forceinline__ auto op_packed_impl(const Op& op,
 template <class Op> __device__ __forceinline__ bool op_packed_impl(const Op&, long) { return false; }
 template <class Op> __device__ __forceinline__ bool op_packed_scalar(const Op& op) { return op_packed_impl(op, 0); }
 
+// the Field of a one-gather sweep: the scalar that came with the position record, plus whatever else the op reads per
+// neighbour (ops with more than a scalar define stage_packed(isBoundary, j, scalar))
+template <class Op> __device__ __forceinline__ auto packed_field(const Op& op, bool isB, int j, float s, int) -> decltype(op.stage_packed(isB, j, s)) { return op.stage_packed(isB, j, s); }
+template <class Op> __device__ __forceinline__ typename Op::Field packed_field(const Op&, bool, int, float s, long) { return scalar_field<typename Op::Field>(s); }
+
 // 16-byte record at byte offset `off` of a unified array: uniform base + 32-bit lane offset
 __device__ __forceinline__ float4 gather16(const float4* __restrict__ base, unsigned int off)
 {
@@ -577,7 +582,7 @@ __device__ __forceinline__ void fetch_pair(const Op& op, const SweepCtx& c, floa
     if (PACKED) {
         const float4 r = gather16(c.posf, off); // fluid: (pos, field); boundary: (pos, mass)
         pj = make_float4(r.x, r.y, r.z, isB ? r.w : m0);
-        f = scalar_field<typename Op::Field>(isB ? 0.0f : r.w);
+        f = packed_field(op, isB, (int)(e & kIndexMask), isB ? 0.0f : r.w, 0);
     } else {
         pj = gather16(c.posm, off);
         f = op.stage(isB, (int)(e & kIndexMask));

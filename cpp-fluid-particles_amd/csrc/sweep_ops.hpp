@@ -81,6 +81,7 @@ struct OpFluidProps {
     const float3* vel; float3* deltaV; float3* colorGrad;
     float* density; float* pressure; float* pterm;
     float rho0, rhoB, visc, dt, stiff;
+    const float* nextScalar = nullptr;   // when set: copied into posf.w, so that the NEXT sweep reads it with the position
     using Field = float4;   // neighbour velocity
     __device__ __forceinline__ Field stage(bool, int j) const { return VISC ? field4(c.vel4, j) : f4zero(); }
     struct Body {
@@ -136,6 +137,7 @@ struct OpFluidProps {
         if (!valid) return;
         if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
         if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
+        if (nextScalar) c.posf[i].w = nextScalar[i];
         if (DENS) {
             density[i] = b.den;
             float p = stiff * (pow7(b.den / rho0) - 1.0f);
@@ -242,8 +244,10 @@ struct OpSurfaceThen {
     const float3* colorGrad; const float3* velIn; const float3* addend; float3* velOut;
     const float* scalar;    // NEXT 1: warm stiffness kappa; NEXT 2: pressure term p / max(EPS, rho^2)
     float rho0, tension, airPressure, dt;
+    bool packedScalar;      // posf.w holds `scalar` for every fluid particle: two gathers per pair instead of three
     struct Field { float4 cg; float s; };
     __device__ __forceinline__ Field stage(bool isB, int j) const { return Field{field4(c.cg4, j), fluid_only(scalar, isB, j)}; }
+    __device__ __forceinline__ Field stage_packed(bool, int j, float s) const { return Field{field4(c.cg4, j), s}; }
     struct Body {
         const OpSurfaceThen& o; SurfaceConsts s; float dii, li, ml, si; float3 a; float3 b;
         template <bool FAST>

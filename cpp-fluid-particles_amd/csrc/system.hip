@@ -520,6 +520,7 @@ float SPHSystem::stepN(int n)
         _graph->tried = true;
         _graph->capturedCount = _fluids->size();
         _graph->capturedGeneration = _solver->graphGeneration();
+        _solver->prepareForCapture();
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             try { enqueueStep(); } catch (...) { ok = false; }

@@ -26,6 +26,7 @@ BasicSPHSolver::~BasicSPHSolver() noexcept {}
 void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; _cache->listValid = false; ++_cache->generation; }
 unsigned int BasicSPHSolver::graphGeneration() const { return _cache->generation; }
+void BasicSPHSolver::prepareForCapture() { _cache->orderAge = 1 << 20; _cache->orderValid = false; }
 void BasicSPHSolver::setToleranceArithmetic(bool on) { _cache->tolerance = on; ++_cache->generation; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
@@ -214,8 +215,9 @@ void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& flu
     if (phase == SPHX_PH_W_SURFACE_PRESSURE) {
         if (!surface) throw "BasicSPHSolver::runWcsphPhase: the fused surface stage needs surface effects enabled";
         ScopedKernel t("surface_pressure_force");
+        // posf.w holds the pressure term since W_PROPS (slab drivers refresh it with the pterm halo)
         launch_op(OpSurfaceThen<2>{ctx, bufferFloat3.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), c.pterm.addr(), rho0,
-                                   surfaceTensionIntensity, airPressure, dt}, n);
+                                   surfaceTensionIntensity, airPressure, dt, true}, n);
         return;
     }
     if (phase == SPHX_PH_W_PRESSURE) {

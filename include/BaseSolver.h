@@ -26,6 +26,9 @@ public:
     // changes whenever host-side state a captured graph depends on changed (buffers reallocated,
     // boundary data rewritten, engine switches); a replaying caller must re-capture
     virtual unsigned int graphGeneration() const { return 0; }
+    // called right before a step is captured into a hipGraph: anything the solver refreshes only every few steps
+    // must be part of the captured step (a replay repeats exactly what was recorded)
+    virtual void prepareForCapture() {}
 
 protected:
     virtual void advect(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize) = 0;

@@ -29,6 +29,7 @@ public:
 
     bool graphSafe() const override { return true; }
     unsigned int graphGeneration() const override;
+    void prepareForCapture() override;
     // engine extensions: the colour gradient left by handleSurface(), and engine switches used by
     // the tests (bit 0: run the reference-structure, unfused sequence of building blocks;
     // bit 1: walk the 27 cells directly instead of the per-step neighbour list;
