@@ -286,6 +286,18 @@ int sphx_row_stats(const sphx_system* h, long long* total, int* longest, int* hi
     return SPHX_OK;
 }
 
+int sphx_rows_stale(const sphx_system* h, int* stale)
+{
+    if (!h || !h->wcsph || !stale) return fail(SPHX_ERR_INVALID, "sphx_rows_stale: bad argument");
+    *stale = 0;
+    const int* flag = h->wcsph->engineStaleFlag();
+    if (!flag) return SPHX_OK;
+    if (hipMemcpyAsync(stale, flag, sizeof(int), hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+        hipStreamSynchronize(sphx::stream()) != hipSuccess)
+        return fail(SPHX_ERR_HIP, "sphx_rows_stale: copy failed");
+    return SPHX_OK;
+}
+
 int sphx_iters(const sphx_system* h, int* div, int* den)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "null system");

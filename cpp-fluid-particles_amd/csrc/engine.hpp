@@ -73,7 +73,9 @@ struct SweepCache {
     bool isSlab = false;
     float skin = 0.0f;                       // absolute length
     std::unique_ptr<DArray<float>> posBuild; // (x, y, z, -) of every fluid particle when the rows were built
-    DArray<int> staleFlag;
+    std::unique_ptr<DArray<int>> rowCell;    // ... and the cell its row was built around
+    DArray<int> staleFlag;                   // two flags: [activeFlag] is raised by the coming position updates; [2] counts rebuilds
+    int activeFlag = 0;
     float staleLimit2() const { return (0.45f * skin) * (0.45f * skin); }
     bool fluidValid = false;
     bool boundaryValid = false;
@@ -100,6 +102,8 @@ struct SweepCache {
     void ensureTileOrder();
     // build the neighbour rows for the current positions (no-op when valid or disabled)
     void ensureList(const DArray<int>& csF, const DArray<int>& csB);
+    void rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB);
+    void launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext);
     SweepCtx ctx(const DArray<int>& csF, const DArray<int>& csB) const;
     bool fused() const { return (flags & kFlagUnfused) == 0; }
     const float4* fluid4() const { return reinterpret_cast<const float4*>(posm.addr()); }

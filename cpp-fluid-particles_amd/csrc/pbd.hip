@@ -42,10 +42,30 @@ void PBDSolver::initializePosLast(const DArray<float3>& posFluid)
 void PBDSolver::configureSkin(float radius)
 {
     SweepCache& c = cache();
-    float factor = 0.1f;
+    float factor = 0.05f;
     if (const char* e = getenv("SPHX_PBD_SKIN")) factor = (float)atof(e);
-    c.skinRows = !c.isSlab && factor > 0.0f;
+    c.skinRows = !c.isSlab && factor > 0.0f && skinWanted;
     c.skin = c.skinRows ? factor * radius : 0.0f;
+}
+
+void PBDSolver::tune(int stepsSinceLastCall)
+{
+    SweepCache& c = cache();
+    if (c.isSlab || getenv("SPHX_PBD_SKIN_FIXED")) return;
+    tuneSteps += stepsSinceLastCall;
+    if (tuneSteps < 32) return;
+    if (skinWanted && c.skinRows) {
+        int rebuilds = 0;
+        HIP_CALL(hipMemcpyAsync(&rebuilds, c.staleFlag.addr(2), sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));
+        HIP_CALL(hipStreamSynchronize(sphx::stream()));
+        const int fired = rebuilds - lastRebuilds;
+        lastRebuilds = rebuilds;
+        if (fired > tuneSteps * maxIter / 2) { skinWanted = false; skinOffSteps = 0; c.listValid = false; ++c.generation; }
+    } else if (!skinWanted) {
+        skinOffSteps += tuneSteps;
+        if (skinOffSteps >= 256) { skinWanted = true; c.listValid = false; ++c.generation; }
+    }
+    tuneSteps = 0;
 }
 
 // PBDSolver::updateNeighborhood, PBDSolver.cu:81-87: carry last positions through this step's sort
@@ -86,6 +106,7 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     auto iter = 0;
     while (iter < maxIterations) {
         c.ensureList(cellStartFluid, cellStartBoundary);
+        if (iter > 0) c.rebuildIfStale(cellStartFluid, cellStartBoundary);
         const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
         {
             ScopedKernel t("pbd_lambda");
@@ -113,8 +134,8 @@ void PBDSolver::applyDelta(std::shared_ptr<SPHParticles>& fluids, float3 spaceSi
     SweepCache& c = cache();
     const bool skin = c.skinRows && c.skin > 0.0f && c.listValid && c.posBuild;
     launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num,
-                             skin ? reinterpret_cast<const float4*>(c.posBuild->addr()) : nullptr, skin ? c.staleFlag.addr() : nullptr,
-                             c.staleLimit2());
+                             skin ? reinterpret_cast<const float4*>(c.posBuild->addr()) : nullptr, skin ? c.rowCell->addr() : nullptr, c.g,
+                             skin ? c.staleFlag.addr(c.activeFlag) : nullptr, c.staleLimit2());
     if (!skin) c.listValid = false;
 }
 
@@ -163,6 +184,7 @@ void PBDSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_pt
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
     c.ensureList(cellStartFluid, cellStartBoundary);
+    c.rebuildIfStale(cellStartFluid, cellStartBoundary);      // the last position update may have outrun the skin
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     DArray<float3>& cg = colorGradientBuffer();
     if (surface) {

@@ -381,11 +381,21 @@ void SweepCache::ensureTileOrder()
 
 // Row construction, one wave per 64-particle tile.  STREAM: each wave first decides whether its tile
 // can use LDS-streamed entries (fmt 2), records that in tileFmt, and stages candidates through LDS.
+// Skin rows (PBD): `refresh` non-null makes the build CONDITIONAL on the device flag refresh[0] ("a particle has moved
+// too far since the rows were built"): not raised -> every wave leaves at once; raised -> the rows are rebuilt for
+// the current positions, which become the new reference positions.  refresh[1] is the flag the coming position
+// updates will raise; it is cleared here.  No host round trip, so the schedule stays graph-replayable.
 template <bool STREAM>
-__global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt)
+__global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned int* nbr, int* nbrCount, int* tileFmt,
+                                                           float4* posBuild, int* rowCell, const int* flagNow, int* flagNext, int* rebuilds)
 {
     __shared__ float4 pos[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
     __shared__ unsigned int stage[STREAM ? 1 : kWideBlock / kTile][STREAM ? 1 : kRowStage * kTile];
+    if (flagNext && blockIdx.x == 0 && threadIdx.x == 0) {
+        *flagNext = 0;
+        if (rebuilds && *flagNow != 0) *rebuilds += 1;      // diagnostics: conditional rebuilds since creation
+    }
+    if (flagNow && *flagNow == 0) return;      // launch-uniform
     const int tile = wave_tile(c);
     if (tile < 0) return;                  // whole wave past the end
     const int i = tile * kTile + (int)(threadIdx.x & 63);
@@ -397,13 +407,19 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
     }
     build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n,
                         STREAM ? nullptr : stage[threadIdx.x >> 6]);
+    if (posBuild && i < c.n) {
+        const float4 p = c.posm[i];
+        posBuild[i] = p;
+        const int3 c0 = cell_of(xyz4(p), c.g);
+        rowCell[i] = cell_id(c0.x, c0.y, c0.z, c.g);
+    }
 }
 
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
-      staleFlag(1u)
+      staleFlag(3u)
 {
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
@@ -506,7 +522,8 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     }
     c.posf = posfw();
     const bool skinNow = skinRows && skin > 0.0f && use;
-    c.stale = skinNow ? staleFlag.addr() : nullptr;
+    c.stale = skinNow ? staleFlag.addr(activeFlag) : nullptr;
+    c.rowCell = (skinNow && rowCell) ? rowCell->addr() : nullptr;
     c.buildCut = k.tCut;
     if (skinRows && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
@@ -530,17 +547,37 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     c.nbr = nullptr;
     listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");
+    const bool skinMode = skinRows && skin > 0.0f;
+    if (skinMode) {          // remember where every particle is: the position updates measure against it
+        if (!posBuild) { posBuild.reset(new DArray<float>(4u * (unsigned)capN)); rowCell.reset(new DArray<int>((unsigned)capN)); ++generation; }
+        HIP_CALL(hipMemsetAsync(staleFlag.addr(), 0, 2 * sizeof(int), stream()));
+        activeFlag = 0;
+    }
+    launchBuild(c, skinMode ? reinterpret_cast<float4*>(posBuild->addr()) : nullptr, nullptr, nullptr);
+    listValid = true;
+}
+
+void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext)
+{
     unsigned int* rows = reinterpret_cast<unsigned int*>(nbr->addr());
     if (allowTiles && (flags & kFlagTiles))
-        k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
+        k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
     else
-        k_build_list<false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr());
-    if (skinRows && skin > 0.0f) {          // remember where every particle was: the position updates measure against it
-        if (!posBuild) { posBuild.reset(new DArray<float>(4u * (unsigned)capN)); ++generation; }
-        HIP_CALL(hipMemsetAsync(staleFlag.addr(), 0, sizeof(int), stream()));
-        ew_copy(posBuild->addr(), posm.addr(), sizeof(float) * 4u * (size_t)n);
-    }
-    listValid = true;
+        k_build_list<false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
+}
+
+// Skin rows between two Jacobi iterations: rebuild on the device if (and only if) the last position update raised the flag
+void SweepCache::rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB)
+{
+    if (!(skinRows && skin > 0.0f) || !listValid || !nbr || !posBuild || n <= 0) return;
+    const int keepLo = rangeLo, keepHi = rangeHi;
+    rangeLo = rangeHi = -1;
+    SweepCtx c = ctx(csF, csB);
+    rangeLo = keepLo; rangeHi = keepHi;
+    c.nbr = nullptr; c.stale = nullptr;
+    ScopedKernel t("rebuild_rows_if_stale");
+    launchBuild(c, reinterpret_cast<float4*>(posBuild->addr()), staleFlag.addr(activeFlag), staleFlag.addr(activeFlag ^ 1));
+    activeFlag ^= 1;
 }
 
 // ------------------------------------------------------------------------------ KernelTimer

@@ -451,6 +451,9 @@ struct SweepCtx {
     // predicate.  `stale` (device flag) is raised when some particle moved farther than half the skin since the
     // build: the rows may then miss a pair, and every sweep walks the cells directly until the next build.
     const int* stale;                       // nullptr: ordinary rows (positions frozen since the build)
+    const int* rowCell;                     // skin rows: the cell each particle's row was built around.  The reference walks the
+                                            // 27 cells around the cell of the CURRENT position (PBDSolver.cu:139-141 on moved
+                                            // positions), so a row is only valid while its particle stays in that cell
     float buildCut;                         // squared cutoff the row builder accepts candidates with
     int numTiles;                           // tiles this launch covers
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
@@ -671,7 +674,11 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
     const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);    // stale skin rows: direct walks (launch-uniform)
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
-    const bool useRow = rows && valid && cnt <= c.cap;
+    bool useRow = rows && valid && cnt <= c.cap;
+    if (skin && useRow) {                   // (normally never fails: the position update asks for a rebuild on a crossing)
+        const int3 cNow = cell_of(pi, c.g);
+        useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
+    }
     const unsigned int* row = rows ? c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63) : nullptr;
     // tile format is wave-uniform (i>>6 is the same for all lanes of the wave)
     const int fmt = (rows && ldsPos && c.tileFmt) ? c.tileFmt[__builtin_amdgcn_readfirstlane(i >> 6)] : 0;

@@ -746,11 +746,12 @@ static __global__ void k_kick_remember_advect(float3* __restrict__ pos, float3* 
     vel[i] = v;
 }
 // pos += deltaPos; enforceBoundary_CUDA(pos): PBDSolver.cu:212-223, :247-253 (also refreshes posm)
-// With skin rows (posBuild != nullptr) the update also checks how far the particle is from where the rows were
-// built; beyond the limit the rows may miss a pair and `stale` sends every later sweep to the direct cell walk.
+// With skin rows (posBuild != nullptr) the update also checks how far the particle is from where its row was built and
+// whether it is still in the cell the row was built around; if not, `stale` asks for a rebuild before the next sweep.
 static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __restrict__ posm, float4* __restrict__ posf,
                                            const float3* __restrict__ dpos, float3 space, int n,
-                                           const float4* __restrict__ posBuild, int* __restrict__ stale, float limit2)
+                                           const float4* __restrict__ posBuild, const int* __restrict__ rowCell, GridDesc g,
+                                           int* __restrict__ stale, float limit2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -762,7 +763,9 @@ static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __r
     posf[i] = make_float4(p.x, p.y, p.z, 0.0f);
     if (posBuild) {
         const float3 d = sub3(p, xyz(posBuild[i]));
-        if (!(dot3(d, d) <= limit2)) *stale = 1;      // also raised for a NaN
+        const int3 cNow = cell_of(p, g);
+        // beyond the skin's allowance (also for a NaN), or in another cell than the one the row was built around
+        if (!(dot3(d, d) <= limit2) || cell_id(cNow.x, cNow.y, cNow.z, g) != rowCell[i]) *stale = 1;
     }
 }
 // vel = (pos - posLast) / dt, PBDSolver.cu:55-60
@@ -802,9 +805,10 @@ inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLas
     if (n > 0) k_kick_remember_advect<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, posLast, dv, dt, space, n);
 }
 inline void launch_apply_delta_clamp(float3* pos, float4* posm, float4* posf, const float3* dpos, float3 space, int n,
-                                     const float4* posBuild = nullptr, int* stale = nullptr, float limit2 = 0.0f)
+                                     const float4* posBuild = nullptr, const int* rowCell = nullptr, GridDesc g = GridDesc{},
+                                     int* stale = nullptr, float limit2 = 0.0f)
 {
-    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n, posBuild, stale, limit2);
+    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n, posBuild, rowCell, g, stale, limit2);
 }
 inline void launch_velocity_from_displacement(float3* vel, float4* vel4, const float3* pos, const float3* posLast, float dt, int n)
 {

@@ -498,6 +498,7 @@ float SPHSystem::step()
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
     _graph->stepsRun++;
+    _solver->tune(1);
     return milliseconds;
 }
 
@@ -554,5 +555,6 @@ float SPHSystem::stepN(int n)
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
     _graph->stepsRun += n;
+    _solver->tune(n);
     return milliseconds + extra;
 }

@@ -34,6 +34,7 @@ void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void* BasicSPHSolver::enginePos4() const { return _cache->posm.addr(); }
 void* BasicSPHSolver::enginePosf() const { return _cache->posf.addr(); }
 const int* BasicSPHSolver::engineRowCounts() const { return _cache->nbrCount.addr(); }
+const int* BasicSPHSolver::engineStaleFlag() const { return (_cache->skinRows && _cache->skin > 0.0f) ? _cache->staleFlag.addr(2) : nullptr; }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
 void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }

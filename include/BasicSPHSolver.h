@@ -49,6 +49,7 @@ public:
     void* enginePosf() const;
     // per-particle neighbour-row lengths of the most recent row build (bench statistics)
     const int* engineRowCounts() const;
+    const int* engineStaleFlag() const;     // device counter of conditional skin-row rebuilds (nullptr when not in use)
     // reserve the boundary part of the engine's unified neighbour arrays (called once by SPHSystem
     // before any engine pointer is handed out; otherwise done lazily by the first step)
     void reserveBoundary(int count);

@@ -28,6 +28,7 @@ public:
     void initializePosLast(const DArray<float3>& posFluid);
 
     bool graphSafe() const override { return posLastInitialized; }
+    void tune(int stepsSinceLastCall) override;
     const DArray<float3>& getPosLast() const { return fluidPosLast; }
     // engine extension (snapshot restore): the last positions were written through the raw pointer
     void markPosLastInitialized() { posLastInitialized = true; }
@@ -53,6 +54,11 @@ private:
     void updateNeighborhood(const std::shared_ptr<SPHParticles>& particles);
     void applyDelta(std::shared_ptr<SPHParticles>& fluids, float3 spaceSize, int num);
     void configureSkin(float radius);
+    // skin-row controller: rows with a skin pay off while particles stay in their cells between Jacobi iterations;
+    // when the device-side rebuild counter shows that most iterations rebuild anyway, plain per-iteration rebuilds
+    // (shorter rows) are cheaper.  Checked every 32 steps, retried after 256.
+    bool skinWanted = true;
+    int tuneSteps = 0, skinOffSteps = 0, lastRebuilds = 0;
 
     bool posLastInitialized = false;
     const int maxIter;

@@ -168,16 +168,20 @@ def test_tile_schedule_is_only_a_schedule(sphx, oracle, solver, monkeypatch):
         compare(sphx, oracle, gs, os_, names, "tile schedule solver %d step %d" % (solver, s + 1))
 
 
-@pytest.mark.parametrize("skin", ["0", "0.002", "0.1", "0.4"])
-def test_pbd_skin_rows_are_exact(sphx, oracle, skin, monkeypatch):
-    """PBD builds its neighbour rows once per step with an enlarged cutoff (skin) and re-tests every pair per sweep;
-    when a particle moves farther than the skin allows, a device flag sends the sweeps to direct cell walks.
-    skin 0 = a rebuild per Jacobi iteration (the r01 behaviour); 0.002 R = practically always stale; 0.1 R = the
-    default; 0.4 R = long rows.  All equal the oracle bit for bit on a violent splash."""
+@pytest.mark.parametrize("skin,speed", [("0", 1.0), ("0.002", 1.0), ("0.05", 1.0), ("0.4", 1.0)])
+def test_pbd_skin_rows_are_exact(sphx, oracle, skin, speed, monkeypatch):
+    """PBD builds its neighbour rows once per step with an enlarged cutoff (skin) and re-tests every pair per sweep.
+    The position update of every Jacobi iteration watches, on the device, whether a particle has moved farther than
+    the skin allows or has left the cell its row was built around (the reference walks the 27 cells around the cell of
+    the CURRENT position, PBDSolver.cu:139-141); if so the next iteration starts with a rebuild, otherwise the rows are
+    kept.  skin 0 = an unconditional rebuild per iteration (the r01 behaviour).  A violent splash (speed 1) rebuilds in
+    practically every iteration; a slow one (speed 0.02) keeps rows across iterations.  All equal the oracle bit for bit."""
     monkeypatch.setenv("SPHX_PBD_SKIN", skin)
+    monkeypatch.setenv("SPHX_PBD_SKIN_FIXED", "1")          # no controller: this test pins the mode
     P, fluid, boundary = sphx.scene(12)
     P.solver = sphx.PBD; P.pbd_iters = 5; P.dt = 0.002
     pos, vel = _splash_state(len(fluid), P, 333)
+    vel = (vel * np.float32(speed)).astype(np.float32)
     Po = same_params(oracle.Params(), P)
     gs = sphx.System(P, pos, boundary, ctor_step=False)
     os_ = oracle.System(Po, pos, boundary, ctor_step=False)
@@ -188,10 +192,55 @@ def test_pbd_skin_rows_are_exact(sphx, oracle, skin, monkeypatch):
     for s in range(5):
         gs.step(); os_.step()
         compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "skin %s step %d" % (skin, s + 1))
+    rebuilds_eager = gs.rows_stale()
     gs.step_n(3)
     for _ in range(3):
         os_.step()
     compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "skin %s graph replay" % skin)
+    assert rebuilds_eager >= 0
+
+
+@pytest.mark.parametrize("skin", ["0.05", "0.3"])
+def test_pbd_skin_rows_kept_across_iterations(sphx, oracle, skin, monkeypatch):
+    """the dam-break column landing gently (nx = 12: contact after ~50 steps): particles move a little in every Jacobi
+    iteration, mostly inside their cells, so rows are re-used across iterations and only sometimes rebuilt"""
+    monkeypatch.setenv("SPHX_PBD_SKIN", skin)
+    monkeypatch.setenv("SPHX_PBD_SKIN_FIXED", "1")
+    def tweak(P):
+        P.pbd_iters = 4
+    gs, os_, P = make_pair(sphx, oracle, 12, sphx.PBD, tweak=tweak)
+    iterations = 0
+    for s in range(1, 91):
+        gs.step(); os_.step()
+        iterations += 4
+        if s % 10 == 0 or s > 80:
+            compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "gentle landing skin %s step %d" % (skin, s))
+    rebuilds = gs.rows_stale()
+    assert 0 < rebuilds < iterations, "expected some, not all, iterations to rebuild: %d of %d" % (rebuilds, iterations)
+
+
+def test_pbd_skin_controller_switches_modes_exactly(sphx, oracle):
+    """the host-side controller reads the device-side rebuild counter every 32 steps and turns skin rows off while
+    most iterations rebuild anyway (violent phase), back on later; whatever it decides, results equal the oracle"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.PBD; P.pbd_iters = 3; P.dt = 0.002
+    pos, vel = _splash_state(len(fluid), P, 91)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    gs.step(); os_.step()
+    ids = gs.get(sphx.F_ID)
+    last = (pos - np.float32(P.dt) * vel).astype(np.float32)[ids]
+    gs.set(sphx.F_POS_LAST, last); os_.set(oracle.F_POS_LAST, last)
+    for block in range(5):                      # 5 x 40 steps: crosses several controller periods, eager and replayed
+        if block % 2 == 0:
+            for _ in range(40):
+                gs.step()
+        else:
+            gs.step_n(40)
+        for _ in range(40):
+            os_.step()
+        compare(sphx, oracle, gs, os_, ["POS", "VEL", "DENSITY", "ID", "POS_LAST"], "controller block %d" % block)
 
 
 def test_dfsph_fixed_iterations_and_graph_replay(sphx, oracle):
