@@ -17,7 +17,7 @@ tot, mx, hist = s.row_stats()
 print("skin %%s R: free fall %%.3f ms/step, %%d in-step rebuilds in 60 steps | post-impact %%.3f ms/step, %%d rebuilds in 60 steps | row mean %%.1f max %%d" %% (os.environ.get("SPHX_PBD_SKIN", "0.1"), a[0], a[1], b2[0], b2[1], tot / s.n, mx))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), nx)
 for skin in ("0", "0.03", "0.05", "0.1", "0.2"):
-    env = dict(os.environ, SPHX_PBD_SKIN=skin)
+    env = dict(os.environ, SPHX_PBD_SKIN=skin, SPHX_PBD_SKIN_FIXED="1")     # fixed skins: the controller is what this probe informs
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     hits = [l for l in out.stdout.splitlines() if l.startswith("skin")]
     print(hits[-1] if hits else out.stderr[-300:])
