@@ -132,3 +132,30 @@ def test_obstacle_samplers(sphx):
     assert d.min() > 0.02 / 8 and d.min(axis=1).max() <= 0.0205
     with pytest.raises(sphx.SphxError):
         sphx.sample_sphere(c, -1.0, 0.01)
+
+
+def test_bench_refuses_cpu_and_checks_traffic_provenance(tmp_path, monkeypatch):
+    """bench.py has no CPU path (it must fail loudly without a HIP device), and it only reports the committed PMC
+    traffic figure when that figure was measured on the source tree the library was built from"""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    import sphx as S
+    if S.device_count() == 0:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+        assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import engine_source_hash
+    h = engine_source_hash()
+    assert len(h) == 16 and h == engine_source_hash()
+    entry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["dfsph_nx190"]
+    got, valu = bench.read_traffic("dfsph_nx190")
+    if entry["source_hash"] == h:
+        assert got == entry["hbm_bytes_per_launch"] and got > 4.5e8       # more than the algorithmic 0.45 GB
+    else:
+        assert got is None and valu is None                               # stale evidence is not reported
+    assert bench.read_traffic("no_such_workload") == (None, None)
+    assert bench.step_bytes_per_particle("dfsph", 1, 4, 0) == 1000 and bench.step_bytes_per_particle("pbd", 0, 0, 4) == 788

@@ -320,6 +320,39 @@ def test_static_obstacles_boundary_mass_and_trajectory(sphx, oracle, solver):
     assert d < 0.04, "the block must come within the support radius of the sphere obstacle"
 
 
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_trajectory_bit_exact_other_constants(sphx, oracle, solver):
+    """every scalar away from the reference scene's values: rest density != 1 (the divisions by rho0 that the scene's
+    rho0 = 1 lets the engine skip), another support radius and cell length (the validated fast division / sqrt paths are
+    per radius), other boundary density, mass, stiffness, viscosity, surface coefficients, tilted gravity"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = solver
+    P.radius = 0.05; P.cell_length = 1.03 * P.radius
+    for a in range(3):
+        P.cells[a] = int(np.ceil(P.space[a] / P.cell_length))
+    P.rho0 = 1.3; P.rho_boundary = 1.9; P.m0 = 9.1e-5; P.stiff = 15.0; P.visc = 1.1e-3
+    P.surface_tension = 2.3e-4; P.air_pressure = 3.1e-4
+    P.gravity[0] = 1.0; P.gravity[1] = -9.0; P.gravity[2] = 0.5
+    P.dt = 0.001; P.pbd_iters = 4; P.pbd_xsph_c = 0.07; P.pbd_relaxation = 0.6
+    pos, vel = _splash_state(len(fluid), P, 55 + solver)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    ids = gs.get(sphx.F_ID)
+    assert_bit_equal(ids, os_.get(oracle.F_ID), "ids")
+    gs.set(sphx.F_VEL, vel[ids]); os_.set(oracle.F_VEL, vel[ids])
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else []) + (FIELDS_PBD if solver == 2 else [])
+    for s in range(6):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, names, "other constants solver %d step %d" % (solver, s + 1))
+        if solver == 1:
+            assert gs.iters() == os_.iters()
+    gs.step_n(3)
+    for _ in range(3):
+        os_.step()
+    compare(sphx, oracle, gs, os_, names, "other constants solver %d graph" % solver)
+
+
 def test_single_particle(sphx, oracle):
     P, fluid, boundary = sphx.scene(8)
     P.solver = sphx.DFSPH
