@@ -67,7 +67,7 @@ void DFSPHSolver::computeDensityAlpha(std::shared_ptr<SPHParticles>& fluids, con
     const int num = (int)fluids->size();
     if (num <= 0) return;
     ScopedKernel t("density_alpha");
-    OpDfsphHead op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, 0}};
+    OpDfsphHeadT<false> op{c.ctx(cellStartFluid, cellStartBoundary), nullptr, fluids->getDensityPtr(), alpha.addr(), RateOut{nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, 0}};
     launch_dfsph_head<false>(op, num);
 }
 
@@ -268,7 +268,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     switch (phase) {
     case SPHX_PH_HEAD: {
         ScopedKernel t("density_alpha_diverr");
-        OpDfsphHead op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+        OpDfsphHeadT<true> op{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
                        RateOut{error.addr(), bufferFloat.addr(), nullptr, nullptr, dt, rho0, c.posfw(), sumLo, sumHi}};
         launch_dfsph_head<true>(op, num);
         break;

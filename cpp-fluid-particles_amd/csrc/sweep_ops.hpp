@@ -377,16 +377,17 @@ __device__ __forceinline__ long long finish_rate(const RateOut& r, int i, float 
 
 // computeDensityAlpha_CUDA (DFSPHSolver.cu:212-249), optionally fused with the first
 // computeDivergenceError_CUDA (:261-306), whose inputs (density_i, alpha_i) are this lane's own.
-struct OpDfsphHead {
+template <bool RATE>     // RATE: fused with the first divergence error (the velocity gather exists only then)
+struct OpDfsphHeadT {
     SweepCtx c;
     const float3* vel; float* density; float* alpha;
     RateOut out;
     using Field = float4;   // neighbour velocity
-    __device__ __forceinline__ Field stage(bool, int j) const { return vel ? field4(c.vel4, j) : f4zero(); }
+    __device__ __forceinline__ Field stage(bool, int j) const { return RATE ? field4(c.vel4, j) : f4zero(); }
     struct Body {
-        const OpDfsphHead& o; float vix, viy, viz;   // own velocity as scalars: a float3 member keeps the whole struct in memory
+        const OpDfsphHeadT& o; float vix, viy, viz;   // own velocity as scalars: a float3 member keeps the whole struct in memory
         float den, sl, e; float3 gs;
-        bool withRate;
+        static constexpr bool withRate = RATE;
         template <bool FAST>
         __device__ __forceinline__ void pair(Field vj, bool isB, float3 d, float r2, float mj, int)
         {
@@ -426,9 +427,9 @@ struct OpDfsphHead {
     };
 };
 template <bool WITH_RATE, bool STREAM>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const OpDfsphHead o, int n)
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const OpDfsphHeadT<WITH_RATE> o, int n)
 {
-    __shared__ BlockLds<OpDfsphHead, STREAM> lds;
+    __shared__ BlockLds<OpDfsphHeadT<WITH_RATE>, STREAM> lds;
     const int wave = threadIdx.x >> 6;
     const int tile = wave_tile(o.c);
     if (tile < 0) return;
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     const bool valid = in_range(o.c, i);
     long long fixed = 0;
     const float3 own = (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0);
-    OpDfsphHead::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0), WITH_RATE};
+    typename OpDfsphHeadT<WITH_RATE>::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0)};
     sweep<true>(o, o.c, STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr, i, valid, own_pos(o.c, i, valid), b);
     if (valid) {
         const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool WITH_RATE>
-inline void launch_dfsph_head(const OpDfsphHead& o, int n)
+inline void launch_dfsph_head(const OpDfsphHeadT<WITH_RATE>& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
