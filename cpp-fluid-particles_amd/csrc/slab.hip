@@ -682,9 +682,18 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         std::vector<int> col((size_t)n_fluid);
         for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
         const std::vector<int> cuts = choose_cuts(col, gx, world, ghost + 1);
-        std::vector<long long> perSlab((size_t)world, 0);
-        for (int c : col) { int r = 0; while (r + 1 < world && c >= cuts[r + 1]) ++r; if (c >= 0 && c < gx) perSlab[r]++; }
-        const long long most = *std::max_element(perSlab.begin(), perSlab.end());
+        // capacity of every slab: the most particles any slab HOLDS at the start (owned + ghost columns), room for two more
+        // columns (a cut may move towards it on either side), and 25 % for the fluid piling up
+        std::vector<long long> perColumn((size_t)gx, 0);
+        for (int c : col) if (c >= 0 && c < gx) perColumn[c]++;
+        long long most = 0;
+        for (int r = 0; r < world; ++r) {
+            long long heldHere = 0;
+            for (int x = std::max(cuts[r] - ghost, 0); x < std::min(cuts[r + 1] + ghost, gx); ++x) heldHere += perColumn[x];
+            most = std::max(most, heldHere);
+        }
+        const long long densestColumn = gx > 0 ? *std::max_element(perColumn.begin(), perColumn.end()) : 0;
+        most += 2 * densestColumn;
 
         for (int r = first_rank; r < first_rank + local_ranks; ++r) {
             std::unique_ptr<Slab> S(new Slab());
@@ -693,7 +702,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             s.cellsPerColumn = gy * gz; s.gx = gx; s.cellLength = P.cell_length;
             s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
             s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
-            s.capacity = (int)std::min<long long>((long long)(most * 1.3) + 4096, 2000000000LL);
+            s.capacity = (int)std::min<long long>((long long)(most * 1.25) + 4096, 2000000000LL);
             // The slab's engine works on the WHOLE grid (cell tables are a few tens of MB even at 10 M particles) and
             // holds the whole boundary set, whose masses it computes like any system (SPHSystem.cu:69-71): only the
             // particles it is handed are local.  Cut planes are then just two numbers of this driver and may move.

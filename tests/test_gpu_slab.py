@@ -139,3 +139,25 @@ def test_native_slab_layer_moving_cuts(sphx, oracle, solver, adaptive):
     assert_bit_equal(p, rp, "moving cuts pos"); assert_bit_equal(v, rv, "moving cuts vel"); assert_bit_equal(d, rd, "moving cuts density")
     if solver == "dfsph":
         assert it == rit
+
+
+def test_native_slab_layer_config3_size_matches_single_system(sphx):
+    """BASELINE config 3's size (1,022,208 particles, DFSPH v=1 d=4) over 8 loopback slabs with cuts re-balanced every
+    step: bit-identical to the plain single-device system (itself oracle-identical at small sizes)"""
+    P, fluid, boundary = sphx.scene(88)
+    P.solver = sphx.DFSPH; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    steps = 4
+    ref = sphx.System(P, fluid, boundary)            # constructor step = step 1
+    ref.step_n(steps - 1)
+    order = np.argsort(ref.get(sphx.F_ID))
+    rp, rv, rd = ref.get(sphx.F_POS)[order], ref.get(sphx.F_VEL)[order], ref.get(sphx.F_DENSITY)[order]
+    ref.close()
+    g = sphx.SlabGroup(P, fluid, boundary, 8)
+    g.set_rebalance(1, 0.0)
+    g.step(steps)
+    ids, p, v, d = g.gather_all()
+    held = sum(g.info(i)[3] for i in range(8)); owned = sum(g.info(i)[2] for i in range(8))
+    g.close()
+    assert owned == len(fluid) and held > owned
+    assert np.array_equal(ids, np.arange(len(fluid), dtype=np.int32))
+    assert_bit_equal(p, rp, "8 slabs pos"); assert_bit_equal(v, rv, "8 slabs vel"); assert_bit_equal(d, rd, "8 slabs density")
