@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -41,10 +42,14 @@ struct RcclApi {
     bool load(std::string& why)
     {
         if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
-        }
+        // SPHX_RCCL_LIBRARY: a specific RCCL build (or the test suite's stand-in, tests/mock_rccl.cpp)
+        const char* chosen = std::getenv("SPHX_RCCL_LIBRARY");
+        if (chosen && *chosen) lib = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
         if (!lib) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
         auto sym = [&](const char* n) { return dlsym(lib, n); };
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");

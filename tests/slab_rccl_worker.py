@@ -1,0 +1,49 @@
+"""One rank of the native slab layer on its RCCL transport (spawned by tests/test_gpu_slab.py, one process per rank).
+argv: rank world nx steps seed solver adaptive(0|1) rebalance(0|1) outdir.  The communicator token travels through a
+file in outdir, as a launcher's side channel would carry it."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401  (first: the engine and RCCL must bind to the HIP runtime torch loads, as in bench.py)
+
+import slab_worker  # puts the package on sys.path
+import sphx
+
+
+def main():
+    rank, world, nx, steps, seed = (int(a) for a in sys.argv[1:6])
+    solver, adaptive, rebalance, outdir = sys.argv[6], sys.argv[7] == "1", sys.argv[8] == "1", sys.argv[9]
+    sphx.set_device(0)
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, adaptive)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    token_file = os.path.join(outdir, "token")
+    if rank == 0:
+        token = sphx.rccl_unique_id()
+        with open(token_file + ".part", "wb") as f:
+            f.write(token)
+        os.rename(token_file + ".part", token_file)
+    else:
+        t0 = time.time()
+        while not os.path.exists(token_file):
+            if time.time() - t0 > 300:
+                raise SystemExit("rank %d: no communicator token" % rank)
+            time.sleep(0.05)
+        token = open(token_file, "rb").read()
+    g = sphx.SlabGroup(P, pos, boundary, world, first_rank=rank, local_ranks=1, rccl_id=token, velocity=vel)
+    if rebalance:
+        g.set_rebalance(1, 0.0)
+    cuts = set()
+    for _ in range(steps):
+        g.step()
+        cuts.add(g.info(0)[:2])
+    ids, p, v, d = g.gather_all()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), ids=ids, pos=p, vel=v, density=d, iters=np.array(g.iters()),
+             distinct_cuts=len(cuts), held=g.info(0)[3])
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
