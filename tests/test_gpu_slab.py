@@ -158,6 +158,28 @@ def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world,
         assert any(int(p["distinct_cuts"]) > 1 for p in parts), "the cuts must have moved"
 
 
+def test_bench_launch_line_two_ranks(tmp_path):
+    """the driver's N > 1 command line — python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 — end to
+    end on the one-GPU box: both ranks on device 0 (SPHX_BENCH_DEVICE), the RCCL calls served by the test stand-in.
+    Rank 0 must print exactly one JSON line that carries the contract's keys for the whole job."""
+    import json, os, subprocess, sys
+    from test_slab_cpu import _free_port
+    env = dict(os.environ)
+    env.update(SPHX_RCCL_LIBRARY=os.path.join(slab_worker.ROOT, "tests", "libmock_rccl.so"), SPHX_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(slab_worker.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--nx", "40"]
+    out = subprocess.run(cmd, env=env, cwd=slab_worker.ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 2 and r["unit"] == "steps/s" and r["scaling"] == "strong"
+    assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1000.0) < 1.0
+    assert r["config"]["particles"] == 40 * 60 * 40 and "2 x-slabs" in r["config"]["decomposition"]
+    assert r["roofline"] and r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
+
+
 @pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("pbd", False), ("dfsph", True)])
 def test_native_slab_layer_moving_cuts(sphx, oracle, solver, adaptive):
     """cut re-balancing forced to act every step with zero tolerance (4 slabs, a splash that sloshes along x): columns
