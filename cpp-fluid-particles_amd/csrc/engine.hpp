@@ -31,6 +31,27 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 // kFlagLinearTiles: launch tiles in array order instead of the (y-chunk, x) schedule
 enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4, kFlagLinearTiles = 8 };
 
+// The neighbour rows are the one array that outgrows DArray's 32-bit element count (cap = 96 entries per particle:
+// 2^32 entries at 44.7 M particles): a plain device allocation with a 64-bit length.  Not zero-filled: the builder
+// writes every slot a sweep reads (rows are read up to nbrCount only).
+struct RowStore {
+    explicit RowStore(unsigned long long entries_) : entries(entries_)
+    {
+        void* raw = nullptr;
+        const hipError_t e = hipMalloc(&raw, sizeof(unsigned int) * (size_t)(entries ? entries : 1ull));
+        if (e != hipSuccess || !raw) {
+            report_hip_error(e, __FILE__, __LINE__);
+            throw DeviceAllocError("neighbour rows: hipMalloc of " + std::to_string(sizeof(unsigned int) * entries) + " bytes failed");
+        }
+        rows = static_cast<unsigned int*>(raw);
+    }
+    RowStore(const RowStore&) = delete;
+    RowStore& operator=(const RowStore&) = delete;
+    ~RowStore() { HIP_CALL(hipFree(rows)); }
+    unsigned long long entries;
+    unsigned int* rows = nullptr;
+};
+
 struct SweepCache {
     explicit SweepCache(int num);
     int n;
@@ -48,7 +69,7 @@ struct SweepCache {
     DArray<int> tileKey;                     // bucket of each tile while the schedule is built
     std::unique_ptr<DArray<int>> tileBuckets; // histogram / cursors of the (y-chunk, x) buckets
     bool orderValid = false;
-    std::unique_ptr<DArray<int>> nbr;        // allocated on first use
+    std::unique_ptr<RowStore> nbr;           // allocated on first use
     // Unified neighbour space: posm, posf, vel4 and cg4 hold [capN fluid slots | nbCap boundary slots].
     // A row entry carries ONE index into it, so a sweep gathers with a uniform base pointer and a
     // 32-bit offset, with no per-entry pointer select; the boundary tails of vel4 / cg4 stay +0.

@@ -504,7 +504,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.csB = csB.addr(); c.bposm = boundary4(); c.bOff = capN;
     const bool use = listValid && nbr && !(flags & kFlagNoList);
     if (use) { c.csF = listCsF; c.csB = listCsB; }   // rows (and tile tables) are tied to these tables
-    c.nbr = use ? reinterpret_cast<const unsigned int*>(nbr->addr()) : nullptr;
+    c.nbr = use ? nbr->rows : nullptr;
     c.nbrCount = nbrCount.addr();
     c.cap = cap;
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
@@ -536,9 +536,8 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     // sized for the CAPACITY, not the current count: sphx_set_count may raise n up to capN later
     // (slab drivers do so every step) and the rows of all ceil(n/64) tiles must fit
     const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
-    if (entries > 0xfffffff0ull) { flags |= kFlagNoList; ++generation; return; }   // beyond DArray's 32-bit length
     if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; ++generation; return; }
-    if (!nbr || (unsigned long long)nbr->length() < entries) { nbr.reset(new DArray<int>((unsigned)entries)); ++generation; }
+    if (!nbr || nbr->entries < entries) { nbr.reset(); nbr.reset(new RowStore(entries)); ++generation; }
     ensureTileOrder();
     const int keepLo = rangeLo, keepHi = rangeHi;
     rangeLo = rangeHi = -1;                    // rows are always built for every particle
@@ -559,7 +558,7 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
 
 void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext)
 {
-    unsigned int* rows = reinterpret_cast<unsigned int*>(nbr->addr());
+    unsigned int* rows = nbr->rows;
     if (allowTiles && (flags & kFlagTiles))
         k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
     else

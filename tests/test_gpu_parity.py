@@ -541,6 +541,29 @@ def test_10m_path_smoke(sphx):
     s.close()
 
 
+def test_rows_beyond_32bit_entry_count(sphx):
+    """49,152,000 particles (nx = 320): cap x particles = 4.7e9 row entries, past a 32-bit element count (the row
+    store has a 64-bit length; round 1 fell back to direct walks beyond 44.7 M particles).  Two WCSPH steps through
+    the rows equal two steps of direct 27-cell walks (engine flag 2, oracle-checked at small sizes) bit for bit."""
+    P, fluid, boundary = sphx.scene(320)
+    n = 320 * 480 * 320
+    assert len(fluid) == n and ((n + 63) // 64) * 64 * 96 > 2 ** 32
+    P.solver = sphx.WCSPH; P.dt = 0.001
+    out = []
+    for flags in (0, 2):
+        Q = P.copy(); Q.reserved[0] = flags
+        s = sphx.System(Q, fluid, boundary)
+        s.step()
+        if flags == 0:
+            pairs, longest, _ = s.row_stats()
+            assert pairs > 20 * n and 0 < longest <= 96, "the sweeps must have walked rows"
+            _size_independent_checks(sphx, s, P, n)
+        out.append([s.get(f) for f in (sphx.F_POS, sphx.F_DENSITY, sphx.F_ID)])
+        s.close()
+    for a, b, nm in zip(out[0], out[1], ["pos", "density", "id"]):
+        assert_bit_equal(a, b, "49M rows vs direct walks " + nm)
+
+
 @pytest.mark.parametrize("solver", [0, 1])
 def test_raised_count_rows_fit_capacity(sphx, solver):
     """sphx_set_count may raise the active count after the neighbour rows were first built (slab
