@@ -687,8 +687,9 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         std::vector<int> col((size_t)n_fluid);
         for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
         const std::vector<int> cuts = choose_cuts(col, gx, world, ghost + 1);
-        // capacity of every slab: the most particles any slab HOLDS at the start (owned + ghost columns), room for two more
-        // columns (a cut may move towards it on either side), and 25 % for the fluid piling up
+        // capacity of every slab: twice the most particles any slab HOLDS at the start (owned + ghost columns, plus two
+        // columns: a cut may move towards it on either side) — the fluid piles up against a wall while the cuts follow
+        // it with a delay — but never more than the whole scene plus its ghost copies.  ~560 B of HBM per slot.
         std::vector<long long> perColumn((size_t)gx, 0);
         for (int c : col) if (c >= 0 && c < gx) perColumn[c]++;
         long long most = 0;
@@ -707,7 +708,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             s.cellsPerColumn = gy * gz; s.gx = gx; s.cellLength = P.cell_length;
             s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
             s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
-            s.capacity = (int)std::min<long long>((long long)(most * 1.25) + 4096, 2000000000LL);
+            s.capacity = (int)std::min<long long>(std::min<long long>(2 * most, (long long)n_fluid + 4LL * ghost * densestColumn) + 4096, 2000000000LL);
             // The slab's engine works on the WHOLE grid (cell tables are a few tens of MB even at 10 M particles) and
             // holds the whole boundary set, whose masses it computes like any system (SPHSystem.cu:69-71): only the
             // particles it is handed are local.  Cut planes are then just two numbers of this driver and may move.
