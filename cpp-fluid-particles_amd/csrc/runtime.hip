@@ -421,7 +421,7 @@ SweepCache::SweepCache(int num)
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
       staleFlag(3u)
 {
-    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = v; }
+    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; }   // rows are stored in chunks of 4
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
 }
 

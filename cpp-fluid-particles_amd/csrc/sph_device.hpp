@@ -425,6 +425,18 @@ constexpr unsigned int kStreamBoundaryBit = 0x10000000u;  // fmt 2: 30..29 group
 constexpr unsigned int kStreamPlainBit = 0x08000000u;
 constexpr unsigned int kStreamSlotMask = 0x07ffffffu;
 
+// Row storage.  Entry k of particle i lives at
+//     ((i >> 6) * cap/4 + (k >> 2)) * 256 + (i & 63) * 4 + (k & 3)          (32-bit words)
+// i.e. rows are cut into chunks of 4 entries = 16 bytes and chunk s of the 64 particles of a tile is one contiguous KB.
+// Two ways to walk it, both fully coalesced:
+//   lane per particle : a lane reads its own chunk with one 16-byte load (the wave reads the whole KB);
+//   quad per particle : the 4 lanes of a quad read the 4 entries of one chunk (a wave = 16 particles reads 256 bytes);
+//                       the 4 neighbours of a chunk are consecutive accepted candidates, i.e. (almost) adjacent
+//                       records, so the quad's gathers share cache lines (walk_row_quad).
+constexpr int kRowChunk = 4;
+__device__ __forceinline__ size_t row_base_offset(int i, int cap) { return ((size_t)(i >> 6) * (size_t)cap) * 64u + (size_t)(i & 63) * kRowChunk; }
+__device__ __forceinline__ size_t row_entry_offset(int k) { return (size_t)(k >> 2) * 256u + (unsigned)(k & 3); }
+
 // XCD-aware block order: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each XCD
 // has its own L2.  Logical block = (b % 8) * chunk + b / 8 gives every XCD one contiguous run of
 // logical blocks = one spatial slab of the cell-sorted particles, so the neighbour data an XCD
@@ -616,8 +628,13 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
     int t = 0;
     for (; t + kAhead <= cnt; t += kAhead) {
         unsigned int e[kAhead];
+        if constexpr (kAhead == kRowChunk) {      // t is a multiple of 4: one 16-byte load
+            const uint4 ch = *reinterpret_cast<const uint4*>(row + (size_t)(t >> 2) * 256u);
+            e[0] = ch.x; e[1] = ch.y; e[2] = ch.z; e[3] = ch.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) e[u] = row[(size_t)(t + u) * 64u];
+            for (int u = 0; u < kAhead; ++u) e[u] = row[row_entry_offset(t + u)];
+        }
         float4 pj[kAhead];
         typename Op::Field f[kAhead];
 #pragma unroll
@@ -647,7 +664,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
         }
     }
     for (; t < cnt; ++t) {
-        const unsigned int e = row[(size_t)t * 64u];
+        const unsigned int e = row[row_entry_offset(t)];
         const bool isB = (e & kBoundaryBit) != 0u;
         if (!WANT_BOUNDARY && isB) continue;
         float4 pj; typename Op::Field fj;
@@ -679,7 +696,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
-    const unsigned int* row = rows ? c.nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63) : nullptr;
+    const unsigned int* row = rows ? c.nbr + row_base_offset(i, c.cap) : nullptr;
     // tile format is wave-uniform (i>>6 is the same for all lanes of the wave)
     const int fmt = (rows && ldsPos && c.tileFmt) ? c.tileFmt[__builtin_amdgcn_readfirstlane(i >> 6)] : 0;
     if (fmt == 2) {
@@ -705,7 +722,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                 const bool isB = (e & kStreamBoundaryBit) != 0u;
                 const int slot = (int)(e & kStreamSlotMask);
                 ++k;
-                const unsigned int next = (k < cnt) ? row[(size_t)k * 64u] : 0xffffffffu;
+                const unsigned int next = (k < cnt) ? row[row_entry_offset(k)] : 0xffffffffu;
                 if (WANT_BOUNDARY || !isB) {
                     const float4 pj = ldsPos[slot];
                     const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
@@ -759,7 +776,7 @@ constexpr int kRowStage = 32;      // entries per lane staged in LDS by the row 
 __device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage, unsigned int* row, int lane, int cnt, unsigned int e)
 {
     if (stage && cnt < kRowStage) stage[cnt * 64 + lane] = e;
-    else if (cnt < c.cap) row[(size_t)cnt * 64u] = e;
+    else if (cnt < c.cap) row[row_entry_offset(cnt)] = e;
 }
 // `stage`: this wave's LDS staging area of kRowStage x 64 entries (or nullptr).  A lane appends at its own count, so
 // written straight to the wave-interleaved global layout the 64 lanes touch 64 different 256-byte lines at any
@@ -772,7 +789,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     const int lane = threadIdx.x & 63;
     const float4 self = valid ? c.posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float3 pi = v3(self.x, self.y, self.z);
-    unsigned int* row = nbr + ((size_t)(i >> 6) * (size_t)c.cap) * 64u + (unsigned)(i & 63);
+    unsigned int* row = nbr + row_base_offset(i, c.cap);
     int cnt = 0;
     const int3 c0 = cell_of(pi, c.g);
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
@@ -856,14 +873,16 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
         if (streamed) wave_lds_fence();
     }
     if (valid) nbrCount[i] = cnt;
-    if (stage) {                                  // one coalesced 256-byte store per entry index
-        wave_lds_fence();
+    if (stage) {                                  // one coalesced 1 KB store per chunk index (slots past a row's end hold
+        wave_lds_fence();                         // stale stage contents: readers never look past nbrCount)
         int top = valid ? min(min(cnt, c.cap), kRowStage) : 0;
         const int own = top;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
-        for (int k = 0; k < top; ++k)
-            if (k < own) row[(size_t)k * 64u] = stage[k * 64 + lane];
+        for (int k = 0; k < top; k += kRowChunk)
+            if (k < own)
+                *reinterpret_cast<uint4*>(row + (size_t)(k >> 2) * 256u) =
+                    make_uint4(stage[k * 64 + lane], stage[(k + 1) * 64 + lane], stage[(k + 2) * 64 + lane], stage[(k + 3) * 64 + lane]);
     }
 }
 

@@ -206,6 +206,72 @@ __global__ void __launch_bounds__(T) k_g32o(Consts c, const float4* __restrict__
 }
 
 // ---- L16: block-staged neighbour ranges in LDS, 16-bit slot rows ------------------------------------------
+
+// ---- QG: G lanes per particle.  A wave holds 64/G particles; in one step the G lanes of a particle evaluate G CONSECUTIVE
+// row entries, i.e. neighbours that sit next to each other in memory, so the lanes of a quad (G = 4) share cache lines.
+// The per-particle sum stays sequential in row order: the G terms are added one after the other (quad broadcasts).
+template <int G>
+__device__ __forceinline__ float group_term(float t, int e, int lane)
+{
+    if (G == 4) {
+        switch (e) {
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0x00, 0xf, 0xf, true));
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0x55, 0xf, 0xf, true));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xAA, 0xf, 0xf, true));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xFF, 0xf, 0xf, true));
+        }
+    }
+    return __shfl(t, (lane & ~(G - 1)) + e, 64);
+}
+
+template <int G, int E, int U, bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_qg(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                            const unsigned int* __restrict__ rows, const int* __restrict__ tileSteps,
+                                            float* __restrict__ out, int n, int numTilesQ, int capSteps)
+{
+    // E entries per lane per step (consecutive), U steps in flight; a step of a particle covers G * E consecutive entries
+    constexpr int PPW = 64 / G;                     // particles per wave
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTilesQ) return;
+    const int lane = threadIdx.x & 63;
+    const int ip = tile * PPW + lane / G;
+    const int i = min(ip, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const unsigned int* row = rows + ((size_t)tile * capSteps) * (64u * E) + (unsigned)lane * E;
+    const int steps = tileSteps[tile];
+    float e = 0.0f;
+    for (int s = 0; s < steps; s += U) {
+        unsigned int idx[U][E];
+        float4 pj[U][E], vj[U][E];
+        float t[U][E];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < E; ++k) idx[u][k] = (s + u < steps) ? row[(size_t)(s + u) * (64u * E) + k] : (unsigned)n;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                pj[u][k] = gather16(posm, idx[u][k] << 4);
+                vj[u][k] = TWO ? gather16(vel4, idx[u][k] << 4) : make_float4(pj[u][k].w, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < E; ++k) t[u][k] = pair_term<EXACT>(c, pi, vi, pj[u][k], vj[u][k]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < E; ++k) e += group_term<G>(t[u][k], g, lane);
+    }
+    if (ip < n && (lane % G) == 0) out[i] = e;
+}
+
 struct BlockRanges { int start[9]; int len[9]; int base[9]; int total; };
 
 template <int T, bool EXACT, bool TWO>
@@ -430,6 +496,34 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dRowsL[v], sets[v].rows.data(), sizeof(uint4) * sets[v].rows.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(dRanges[v], sets[v].ranges.data(), sizeof(BlockRanges) * sets[v].ranges.size(), hipMemcpyHostToDevice));
     }
+
+    // QG rows: [tile of 64/G particles][step][lane = particle * G + g][E entries]; padded with the dummy particle n
+    struct QSet { int G, E, U; int numTiles; int capSteps; unsigned int* dRows; int* dSteps; };
+    static const int qcfg[6][3] = {{4, 1, 2}, {4, 1, 4}, {4, 2, 2}, {4, 2, 1}, {8, 1, 4}, {2, 2, 2}};
+    QSet qsets[6];
+    for (int v = 0; v < 6; ++v) {
+        QSet& Q = qsets[v];
+        Q.G = qcfg[v][0]; Q.E = qcfg[v][1]; Q.U = qcfg[v][2];
+        const int ppw = 64 / Q.G, per = Q.G * Q.E;
+        Q.numTiles = (n + ppw - 1) / ppw;
+        Q.capSteps = kCap / per;
+        std::vector<unsigned int> rq((size_t)Q.numTiles * Q.capSteps * 64 * Q.E, (unsigned)n);
+        std::vector<int> steps(Q.numTiles, 0);
+        double slots = 0;
+        for (int i = 0; i < n; ++i) {
+            const int tile = i / ppw, p = i % ppw, m = cnt[i];
+            steps[tile] = std::max(steps[tile], (m + per - 1) / per);
+            for (int t = 0; t < m; ++t) {
+                const int st = t / per, g = (t % per) / Q.E, k = t % Q.E;
+                rq[(((size_t)tile * Q.capSteps + st) * 64 + p * Q.G + g) * Q.E + k] = (unsigned)nbr[i][t];
+            }
+        }
+        for (int t = 0; t < Q.numTiles; ++t) slots += steps[t] * 64.0 * Q.E;
+        printf("Q%dx%d rows: %d tiles, padding x%.2f\n", Q.G, Q.E, Q.numTiles, slots / pairs);
+        CK(hipMalloc(&Q.dRows, sizeof(unsigned int) * rq.size())); CK(hipMalloc(&Q.dSteps, sizeof(int) * Q.numTiles));
+        CK(hipMemcpy(Q.dRows, rq.data(), sizeof(unsigned int) * rq.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(Q.dSteps, steps.data(), sizeof(int) * Q.numTiles, hipMemcpyHostToDevice));
+    }
     float4* dPV;
     {
         std::vector<float4> pv(2 * (size_t)(n + 1));
@@ -483,6 +577,25 @@ int main(int argc, char** argv)
             run(tag("G32 "), exact, two, [&] { PICK(k_g32, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsG, dCnt, dOut, n, numTiles); });
             run(tag("G32c"), exact, two, [&] { PICK(k_g32c, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
             run(tag("G32i"), exact, two, [&] { PICK(k_g32i, dim3(gridG), dim3(256), 0, st, c, dPV, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
+            for (int v = 0; v < 6; ++v) {
+                const QSet& Q = qsets[v];
+                const unsigned gridQ = xcd_grid(Q.numTiles * 64, 256);
+                snprintf(nm, sizeof(nm), "Q%dx%d u%d %s %s", Q.G, Q.E, Q.U, exact ? "exact" : "tol", two ? "2f" : "1f");
+#define LQ(GG, EE, UU, EX, TW) hipLaunchKernelGGL((k_qg<GG, EE, UU, EX, TW>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps)
+#define LQ2(GG, EE, UU) do { if (exact) { if (two) LQ(GG, EE, UU, true, true); else LQ(GG, EE, UU, true, false); } else { if (two) LQ(GG, EE, UU, false, true); else LQ(GG, EE, UU, false, false); } } while (0)
+                run(nm, exact, two, [&] {
+                    switch (v) {
+                    case 0: LQ2(4, 1, 2); break;
+                    case 1: LQ2(4, 1, 4); break;
+                    case 2: LQ2(4, 2, 2); break;
+                    case 3: LQ2(4, 2, 1); break;
+                    case 4: LQ2(8, 1, 4); break;
+                    default: LQ2(2, 2, 2); break;
+                    }
+                });
+#undef LQ2
+#undef LQ
+            }
             for (int v = 0; v < (argc > 5 ? 2 : 0); ++v) {
                 const int T = sets[v].T, slots = sets[v].slots + 1;
                 const size_t ldsBytes = (size_t)slots * 16 * (two ? 2 : 1);
