@@ -29,7 +29,8 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 //                  gradient in the fused sweeps)
 // kFlagTiles: LDS-streamed tiles (sph_device.hpp, entry format 2)
 // kFlagLinearTiles: launch tiles in array order instead of the (y-chunk, x) schedule
-enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4, kFlagLinearTiles = 8 };
+// kFlagNoQuad: lane-per-particle walks everywhere (no quad-per-particle sweep variants)
+enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4, kFlagLinearTiles = 8, kFlagNoQuad = 16 };
 
 // The neighbour rows are the one array that outgrows DArray's 32-bit element count (cap = 96 entries per particle:
 // 2^32 entries at 44.7 M particles): a plain device allocation with a 64-bit length.  Not zero-filled: the builder

@@ -508,6 +508,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.nbrCount = nbrCount.addr();
     c.cap = cap;
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
+    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? 1 : 0;
     c.n = n;
     c.vel4 = vel4w();
     c.cg4 = cg4w();

@@ -467,6 +467,7 @@ struct SweepCtx {
                                             // 27 cells around the cell of the CURRENT position (PBDSolver.cu:139-141 on moved
                                             // positions), so a row is only valid while its particle stays in that cell
     float buildCut;                         // squared cutoff the row builder accepts candidates with
+    int quad;                               // sweeps with a quad-per-particle variant use it (walk_row_quad)
     int numTiles;                           // tiles this launch covers
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
@@ -766,6 +767,126 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
     walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
         body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
     });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Quad-per-particle walk.  The 4 lanes of a quad work on ONE particle: in a step, lane g evaluates entry 4s + g of its
+// row.  The 4 entries of a chunk are consecutive accepted candidates of the cell walk, i.e. records that lie next to
+// each other in the cell-sorted arrays, so the quad's gathers fall into one or two cache lines (lane-per-particle
+// gathers touch ~50 lines per instruction and are bound by the L1's line rate: profiles/r02_ubench_sweep_structure.txt).
+// The per-particle sums stay strictly in row order: each lane computes the term of its entry into a zeroed copy of the
+// accumulators, then every lane of the quad adds the 4 terms one after the other (quad broadcasts), so all 4 lanes
+// hold the same running sums as the lane-per-particle walk would.  (0 + t == t bit for bit, and a running sum that
+// started at +0 is never -0, so routing a term through a zeroed accumulator changes nothing.)
+// A Body opts in with  template <class F> void each_acc(Body& other, F f)  calling f(mine, others) per accumulator.
+template <int G> __device__ __forceinline__ int quad_bcast_i(int v)
+{
+    constexpr int ctrl = G == 0 ? 0x00 : (G == 1 ? 0x55 : (G == 2 ? 0xAA : 0xFF));      // quad_perm:[G,G,G,G]
+    return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+}
+template <int G> __device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<G>(__float_as_int(v))); }
+
+template <int G, class Body>
+__device__ __forceinline__ void quad_accumulate(Body& body, Body& term, const int use)
+{
+    const bool on = quad_bcast_i<G>(use) != 0;
+    body.each_acc(term, [&](float& a, float& t) { const float tq = quad_bcast_f<G>(t); a = on ? a + tq : a; });
+}
+
+template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
+__device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowq, const int cnt,
+                                              const float m0, const bool allPlain, const float3 pi, Body& body)
+{
+    constexpr int U = 4;                       // chunks in flight
+    const int g = threadIdx.x & 3;
+    int steps = (cnt + kRowChunk - 1) >> 2;    // the same in the 4 lanes of a quad; the wave runs to its longest row
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    for (int s = 0; s < steps; s += U) {
+        unsigned int e[U];
+        int ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = (4 * (s + u) + g < cnt) ? 1 : 0;
+            e[u] = ok[u] ? rowq[(size_t)(s + u) * 256u] : 0u;      // past the end: record 0, evaluated and dropped
+        }
+        float4 pj[U];
+        typename Op::Field f[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (4 * (s + u) >= steps * 4) break;   // wave-uniform
+            const bool isB = (e[u] & kBoundaryBit) != 0u;
+            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+            const float r2 = dot3(d, d);
+            int use = ok[u];
+            if (!WANT_BOUNDARY && isB) use = 0;
+            if (SKIN && r2 > c.k.tCut) use = 0;
+            Body term = body;
+            term.each_acc(term, [](float& a, float&) { a = 0.0f; });
+            if (TOL) term.pair_tol(f[u], isB, d, r2, pj[u].w);
+            else {
+                const bool plain = use != 0 && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u);
+                pair_dispatch(term, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
+            }
+            quad_accumulate<0>(body, term, use);
+            quad_accumulate<1>(body, term, use);
+            quad_accumulate<2>(body, term, use);
+            quad_accumulate<3>(body, term, use);
+        }
+    }
+}
+
+// The particle of this lane's quad in a quad-per-particle launch: one block of 4 waves per tile, wave w takes the
+// particles [16 w, 16 w + 16) of the tile.  -1: the block is past the end.
+__device__ __forceinline__ int quad_particle(const SweepCtx& c)
+{
+    const int lt = logical_block();
+    if (lt >= c.numTiles) return -1;
+    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
+    return tile * kTile + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+}
+
+// sweep() for a quad-per-particle launch (rows in global memory only; no LDS-streamed tiles)
+template <bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
+{
+    const bool skin = c.stale != nullptr;
+    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);
+    const bool allPlain = !fast_paths_enabled(c.k);
+    const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
+    bool useRow = rows && valid && cnt <= c.cap;
+    if (skin && useRow) {
+        const int3 cNow = cell_of(pi, c.g);
+        useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
+    }
+    const bool packed = op_packed_scalar<Op>(op) && c.posf && c.massUniform && *c.massUniform != 0;
+    const float m0 = packed ? c.posm[0].w : 0.0f;
+    // every lane takes part in the row walk (wave-wide shuffles); lanes without a row run it with an empty one
+    const unsigned int* rowq = rows ? c.nbr + row_base_offset(valid ? i : 0, c.cap) + (threadIdx.x & 3) : nullptr;
+    const int len = useRow ? cnt : 0;
+    if (rows) {
+        if (c.k.tol) {
+            if (skin) {
+                if (packed) walk_row_quad<true, WANT_BOUNDARY, true, true>(op, c, rowq, len, m0, allPlain, pi, body);
+                else walk_row_quad<false, WANT_BOUNDARY, true, true>(op, c, rowq, len, m0, allPlain, pi, body);
+            } else {
+                if (packed) walk_row_quad<true, WANT_BOUNDARY, false, true>(op, c, rowq, len, m0, allPlain, pi, body);
+                else walk_row_quad<false, WANT_BOUNDARY, false, true>(op, c, rowq, len, m0, allPlain, pi, body);
+            }
+        } else if (skin) {
+            if (packed) walk_row_quad<true, WANT_BOUNDARY, true, false>(op, c, rowq, len, m0, allPlain, pi, body);
+            else walk_row_quad<false, WANT_BOUNDARY, true, false>(op, c, rowq, len, m0, allPlain, pi, body);
+        } else {
+            if (packed) walk_row_quad<true, WANT_BOUNDARY, false, false>(op, c, rowq, len, m0, allPlain, pi, body);
+            else walk_row_quad<false, WANT_BOUNDARY, false, false>(op, c, rowq, len, m0, allPlain, pi, body);
+        }
+    }
+    if (valid && !useRow)      // no rows, or this particle's row overflowed / went stale: the 4 lanes walk the cells alike
+        walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+            body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
+        });
 }
 
 // Row construction for one wave = one tile.  Same walk as walk_cells; the three z-adjacent cells of

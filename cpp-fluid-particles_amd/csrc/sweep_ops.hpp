@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op o
 }
 // grid of a sweep launch: one wave per tile of the launch's range, padded to a multiple of 8 blocks
 inline unsigned int sweep_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kTile, kWideBlock); }
+inline unsigned int quad_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kWideBlock, kWideBlock); }   // one block per tile
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
@@ -485,8 +486,24 @@ struct OpRate {
             const f2 t = f2{pa.w, pb.w} * ((vix - f2{va.x, vb.x}) * g.x + (viy - f2{va.y, vb.y}) * g.y + (viz - f2{va.z, vb.z}) * g.z);
             e += t.x; e += t.y;
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(e, other.e); }
     };
 };
+// quad-per-particle variant (walk_row_quad): two divergent gathers per pair make this sweep the one that gains most
+template <bool DENSITY_MODE, int WARM>
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate_quad(const OpRate o, int n)
+{
+    const int i = quad_particle(o.c);
+    if (i < 0) return;
+    (void)n;
+    const bool valid = in_range(o.c, i);
+    long long fixed = 0;
+    const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
+    OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
+    sweep_quad<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
+    if (valid && (threadIdx.x & 3) == 0) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
+    if (o.out.accum) accumulate_error(fixed, o.out.accum);
+}
 template <bool DENSITY_MODE, int WARM, bool STREAM>
 __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate o, int n)
 {
@@ -509,6 +526,7 @@ inline void launch_rate_kernel(const OpRate& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && o.c.quad) k_rate_quad<DENSITY_MODE, WARM><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
