@@ -648,7 +648,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
             if (!__any(allPlain || (flags & kPlainBit) != 0u)) {
 #pragma unroll
                 for (int u = 0; u < kAhead; u += 2)
-                    body.pair2(f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
+                    body.pair2(body, body, f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
                 continue;
             }
         }
@@ -786,54 +786,86 @@ template <int G> __device__ __forceinline__ int quad_bcast_i(int v)
 }
 template <int G> __device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<G>(__float_as_int(v))); }
 
-template <int G, class Body>
-__device__ __forceinline__ void quad_accumulate(Body& body, Body& term, const int use)
+// adds the 4 lanes' terms to every lane's running sums, in lane order.  A dropped term (entry past the row's end,
+// skipped boundary, pair beyond the support) is replaced by +0 first: x + (+0) == x for every x but -0, and a running
+// sum that started at +0 cannot be -0.
+template <class Body>
+__device__ __forceinline__ void quad_accumulate(Body& body, Body& term, const bool use)
 {
-    const bool on = quad_bcast_i<G>(use) != 0;
-    body.each_acc(term, [&](float& a, float& t) { const float tq = quad_bcast_f<G>(t); a = on ? a + tq : a; });
+    body.each_acc(term, [&](float& a, float& t) {
+        const float tz = use ? t : 0.0f;
+        a += quad_bcast_f<0>(tz); a += quad_bcast_f<1>(tz); a += quad_bcast_f<2>(tz); a += quad_bcast_f<3>(tz);
+    });
 }
 
 template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
 __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowq, const int cnt,
                                               const float m0, const bool allPlain, const float3 pi, Body& body)
 {
-    constexpr int U = 4;                       // chunks in flight
+#ifndef SPHX_QUAD_U
+#define SPHX_QUAD_U 4
+#endif
+#ifndef SPHX_QUAD_PAIR2
+#define SPHX_QUAD_PAIR2 0      // packed two-chunk evaluation: -21 % VALU instructions but 90 instead of 72 VGPRs; measured slower
+#endif
+    constexpr int U = SPHX_QUAD_U;             // chunks in flight
     const int g = threadIdx.x & 3;
     int steps = (cnt + kRowChunk - 1) >> 2;    // the same in the 4 lanes of a quad; the wave runs to its longest row
 #pragma unroll
     for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    const int lastChunk = c.cap / kRowChunk - 1;
     for (int s = 0; s < steps; s += U) {
         unsigned int e[U];
-        int ok[U];
+        bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ok[u] = (4 * (s + u) + g < cnt) ? 1 : 0;
-            e[u] = ok[u] ? rowq[(size_t)(s + u) * 256u] : 0u;      // past the end: record 0, evaluated and dropped
+            // unconditional load (chunks past this row's end hold stale entries; past the wave's last chunk the index
+            // is clamped into the tile's slab), then: past the end -> record 0, evaluated and dropped
+            ok[u] = 4 * (s + u) + g < cnt;
+            const unsigned int raw = rowq[(size_t)min(s + u, lastChunk) * 256u];
+            e[u] = ok[u] ? raw : 0u;
         }
         float4 pj[U];
         typename Op::Field f[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
+        if constexpr (SPHX_QUAD_PAIR2 && has_pair2<Body>() && WANT_BOUNDARY && !SKIN && !TOL && U % 2 == 0) {
+            // two chunks per packed evaluation: lane g holds entries 4s+g and 4(s+1)+g; their terms go to separate
+            // zeroed accumulators and are added chunk by chunk, entry by entry
+            bool fast = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u) fast = fast && !(ok[u] && (e[u] & kPlainBit) != 0u);
+            if (!__any(allPlain || !fast)) {
+#pragma unroll
+                for (int u = 0; u < U; u += 2) {
+                    if (s + u >= steps) break;       // wave-uniform
+                    Body ta = body, tb = body;
+                    ta.each_acc(ta, [](float& a, float&) { a = 0.0f; });
+                    tb.each_acc(tb, [](float& a, float&) { a = 0.0f; });
+                    body.pair2(ta, tb, f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
+                    quad_accumulate(body, ta, ok[u]);
+                    quad_accumulate(body, tb, ok[u + 1]);
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (4 * (s + u) >= steps * 4) break;   // wave-uniform
+            if (s + u >= steps) break;             // wave-uniform
             const bool isB = (e[u] & kBoundaryBit) != 0u;
             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
             const float r2 = dot3(d, d);
-            int use = ok[u];
-            if (!WANT_BOUNDARY && isB) use = 0;
-            if (SKIN && r2 > c.k.tCut) use = 0;
+            bool use = ok[u];
+            if (!WANT_BOUNDARY && isB) use = false;
+            if (SKIN && r2 > c.k.tCut) use = false;
             Body term = body;
             term.each_acc(term, [](float& a, float&) { a = 0.0f; });
             if (TOL) term.pair_tol(f[u], isB, d, r2, pj[u].w);
             else {
-                const bool plain = use != 0 && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u);
+                const bool plain = use && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u);
                 pair_dispatch(term, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
             }
-            quad_accumulate<0>(body, term, use);
-            quad_accumulate<1>(body, term, use);
-            quad_accumulate<2>(body, term, use);
-            quad_accumulate<3>(body, term, use);
+            quad_accumulate(body, term, use);
         }
     }
 }

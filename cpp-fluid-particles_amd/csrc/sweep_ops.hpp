@@ -326,15 +326,16 @@ struct OpPressureForce {
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
         static constexpr bool kPair2 = true;      // (rows never hold the particle itself, so no j == i test)
-        __device__ __forceinline__ void pair2(Field ta, Field tb, bool, bool, float3 pi, float4 pa, float4 pb)
+        __device__ __forceinline__ void pair2(Body& A, Body& B, Field ta, Field tb, bool, bool, float3 pi, float4 pa, float4 pb) const
         {
             const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
             const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
             const f2 s = -f2{pa.w, pb.w} * (pti + f2{ta, tb});
             const f2 cx = s * g.x, cy = s * g.y, cz = s * g.z;
-            a = add3(a, v3(cx.x, cy.x, cz.x));
-            a = add3(a, v3(cx.y, cy.y, cz.y));
+            A.a = add3(A.a, v3(cx.x, cy.x, cz.x));
+            B.a = add3(B.a, v3(cx.y, cy.y, cz.y));
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
@@ -412,7 +413,7 @@ struct OpDfsphHeadT {
             if (withRate) e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
         }
         static constexpr bool kPair2 = true;
-        __device__ __forceinline__ void pair2(Field va, Field vb, bool isBa, bool isBb, float3 pi, float4 pa, float4 pb)
+        __device__ __forceinline__ void pair2(Body& A, Body& B, Field va, Field vb, bool isBa, bool isBb, float3 pi, float4 pa, float4 pb) const
         {
             const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
             const f2 m = f2{pa.w, pb.w};
@@ -422,8 +423,13 @@ struct OpDfsphHeadT {
             const f2 s2 = gx * gx + gy * gy + gz * gz;
             f2 r = splat2(0.0f);
             if (withRate) r = m * ((vix - f2{va.x, vb.x}) * gw.x + (viy - f2{va.y, vb.y}) * gw.y + (viz - f2{va.z, vb.z}) * gw.z);
-            den += dw.x; gs = add3(gs, v3(gx.x, gy.x, gz.x)); if (!isBa) sl += s2.x; if (withRate) e += r.x;
-            den += dw.y; gs = add3(gs, v3(gx.y, gy.y, gz.y)); if (!isBb) sl += s2.y; if (withRate) e += r.y;
+            A.den += dw.x; A.gs = add3(A.gs, v3(gx.x, gy.x, gz.x)); if (!isBa) A.sl += s2.x; if (withRate) A.e += r.x;
+            B.den += dw.y; B.gs = add3(B.gs, v3(gx.y, gy.y, gz.y)); if (!isBb) B.sl += s2.y; if (withRate) B.e += r.y;
+        }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
+        {
+            f(den, other.den); f(gs.x, other.gs.x); f(gs.y, other.gs.y); f(gs.z, other.gs.z); f(sl, other.sl);
+            if (withRate) f(e, other.e);
         }
     };
 };
@@ -479,19 +485,24 @@ struct OpRate {
             e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
         }
         static constexpr bool kPair2 = true;
-        __device__ __forceinline__ void pair2(Field va, Field vb, bool, bool, float3 pi, float4 pa, float4 pb)
+        __device__ __forceinline__ void pair2(Body& A, Body& B, Field va, Field vb, bool, bool, float3 pi, float4 pa, float4 pb) const
         {
             const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
             const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
             const f2 t = f2{pa.w, pb.w} * ((vix - f2{va.x, vb.x}) * g.x + (viy - f2{va.y, vb.y}) * g.y + (viz - f2{va.z, vb.z}) * g.z);
-            e += t.x; e += t.y;
+            A.e += t.x; B.e += t.y;
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(e, other.e); }
     };
 };
 // quad-per-particle variant (walk_row_quad): two divergent gathers per pair make this sweep the one that gains most
+#ifndef SPHX_QUAD_WAVES
+#define SPHX_QUAD_ATTR
+#else
+#define SPHX_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(SPHX_QUAD_WAVES, SPHX_QUAD_WAVES)))
+#endif
 template <bool DENSITY_MODE, int WARM>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate_quad(const OpRate o, int n)
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) SPHX_QUAD_ATTR k_rate_quad(const OpRate o, int n)
 {
     const int i = quad_particle(o.c);
     if (i < 0) return;
@@ -554,15 +565,16 @@ struct OpCorrect {
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
         static constexpr bool kPair2 = true;
-        __device__ __forceinline__ void pair2(Field ka, Field kb, bool, bool, float3 pi, float4 pa, float4 pb)
+        __device__ __forceinline__ void pair2(Body& A, Body& B, Field ka, Field kb, bool, bool, float3 pi, float4 pa, float4 pb) const
         {
             const Pair2 p = pair2_geometry(pi, pa, pb, o.c.k);
             const f2x3 g = kGradW_fast2(p.d, p.q, o.c.k);
             const f2 s = f2{pa.w, pb.w} * (ki + f2{ka, kb});
             const f2 cx = s * g.x, cy = s * g.y, cz = s * g.z;
-            a = add3(a, v3(cx.x, cy.x, cz.x));
-            a = add3(a, v3(cx.y, cy.y, cz.y));
+            A.a = add3(A.a, v3(cx.x, cy.x, cz.x));
+            B.a = add3(B.a, v3(cx.y, cy.y, cz.y));
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {

@@ -11,6 +11,14 @@ out, tag = sys.argv[1], sys.argv[2]
 bench_args = sys.argv[3:]
 
 
+def is_density_rate(name, warm2=False):
+    """the dominant kernel: computeDensityError's sweep, k_rate<true, W, ...> or its quad-per-particle variant
+    k_rate_quad<true, W> (W = 2: the iterations after the first)"""
+    import re
+    m = re.search(r"k_rate(_quad)?<(true|\(bool\)1), (\d)", name)
+    return bool(m) and (not warm2 or m.group(3) == "2")
+
+
 def find(sub, pat):
     hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
     return hits[0] if hits else None
@@ -47,7 +55,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     print("\n== %s per dispatch (raw counter units: KiB; gfx950 FETCH_SIZE under-reads wide streams by 2x)" % ctr)
     for k, (tot, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:25]:
         print("%-112s %6d launches  avg %12.1f KiB" % (k, n, tot / n))
-        if "k_rate<true" in k or "k_rate<(bool)1" in k:
+        if is_density_rate(k):
             traffic.setdefault("k_rate_density", {})[ctr] = tot / n * 1024.0
 # VALU / cache passes: per-dispatch averages of the sweep kernels
 extra = {}
@@ -58,14 +66,14 @@ for sub in ("valu", "cache"):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for r in csv.DictReader(open(cc)):
         k = short(r["Kernel_Name"])
-        if "k_rate<" in k or "OpCorrect" in k or "k_build_list" in k or "k_dfsph_head" in k:
+        if "k_rate" in k or "OpCorrect" in k or "k_build_list" in k or "k_dfsph_head" in k:
             a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
     print("\n== %s pass, per-dispatch averages" % sub)
     for k, d in acc.items():
         print(k)
         for cname, (tot, cnt) in sorted(d.items()):
             print("   %-36s %18.1f  (avg of %d)" % (cname, tot / cnt, cnt))
-            if "k_rate<true" in k or "k_rate<(bool)1" in k:
+            if is_density_rate(k, warm2=True):
                 extra[cname] = tot / cnt
 if traffic:
     kr = traffic["k_rate_density"]
@@ -79,7 +87,7 @@ if traffic:
         us = None
         if stats:
             for r in csv.DictReader(open(stats)):
-                if "k_rate<true, 2" in r["Name"] or "k_rate<(bool)1, 2" in r["Name"]:
+                if is_density_rate(r["Name"], warm2=True):
                     us = float(r["AverageNs"]) / 1e3
         if us:
             kr["avg_launch_us_rocprof"] = us
