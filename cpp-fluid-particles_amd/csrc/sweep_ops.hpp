@@ -22,20 +22,42 @@ struct BlockLds {
     typename Op::Field field[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
 };
 
-template <class Op, bool STREAM>
 #ifndef SPHX_MINWAVES
 #define SPHX_MINWAVES 1
 #endif
+// which sweeps have a quad-per-particle variant switched on (SweepCtx::quad; SweepCache picks the mask)
+enum QuadBits { kQuadRate = 1, kQuadHead = 2, kQuadProps = 4, kQuadCorrect = 8, kQuadPressure = 16, kQuadLambda = 32,
+                kQuadDelta = 64, kQuadXsph = 128, kQuadSurface = 256 };
+template <class Op> __host__ __device__ constexpr auto op_quad_bit_impl(int) -> decltype(Op::kQuadBit) { return Op::kQuadBit; }
+template <class Op> __host__ __device__ constexpr int op_quad_bit_impl(long) { return 0; }
+template <class Op> __host__ __device__ constexpr int op_quad_bit() { return op_quad_bit_impl<Op>(0); }
+
+template <class Op, bool STREAM, bool QUAD = false>
 __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op op, int n)
 {
-    __shared__ BlockLds<Op, STREAM> lds;
-    const int wave = threadIdx.x >> 6;
-    const int tile = wave_tile(op.c);
-    if (tile < 0) return;                  // whole wave past the end (wave-uniform)
-    const int i = tile * kTile + (int)(threadIdx.x & 63);
     (void)n;
-    op(i, in_range(op.c, i), STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
+    if constexpr (QUAD) {
+        const int i = quad_particle(op.c);
+        if (i < 0) return;
+        op.template operator()<true>(i, in_range(op.c, i), nullptr, nullptr);
+    } else {
+        __shared__ BlockLds<Op, STREAM> lds;
+        const int wave = threadIdx.x >> 6;
+        const int tile = wave_tile(op.c);
+        if (tile < 0) return;                  // whole wave past the end (wave-uniform)
+        const int i = tile * kTile + (int)(threadIdx.x & 63);
+        op(i, in_range(op.c, i), STREAM ? lds.pos[wave] : nullptr, STREAM ? lds.field[wave] : nullptr);
+    }
 }
+// the sweep of one particle in either launch shape; in a quad launch only lane 0 of the quad stores the results
+template <bool QUAD, bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep_any(const Op& op, const SweepCtx& c, float4* lp, typename Op::Field* lf, int i, bool valid,
+                                          float3 pi, Body& body)
+{
+    if constexpr (QUAD) sweep_quad<WANT_BOUNDARY>(op, c, i, valid, pi, body);
+    else sweep<WANT_BOUNDARY>(op, c, lp, lf, i, valid, pi, body);
+}
+template <bool QUAD> __device__ __forceinline__ bool stores_results(bool valid) { return valid && (!QUAD || (threadIdx.x & 3) == 0); }
 // grid of a sweep launch: one wave per tile of the launch's range, padded to a multiple of 8 blocks
 inline unsigned int sweep_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kTile, kWideBlock); }
 inline unsigned int quad_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kWideBlock, kWideBlock); }   // one block per tile
@@ -44,7 +66,10 @@ inline void launch_op(const Op& op, int n)
 {
     if (n <= 0 || op.c.numTiles <= 0) return;
     if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
-    else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+    else if constexpr (op_quad_bit<Op>() != 0) {
+        if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) k_run_op<Op, false, true><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+        else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+    } else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
 }
 
 // wave-level sum of the fixed-point |error| terms, one atomic per wave
@@ -129,13 +154,21 @@ struct OpFluidProps {
                 }
             }
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
+        {
+            if (VISC) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
+            if (COLOR) { f(cg.x, other.cg.x); f(cg.y, other.cg.y); f(cg.z, other.cg.z); f(cden, other.cden); }
+            if (DENS) f(den, other.den);
+        }
     };
+    static constexpr int kQuadBit = kQuadProps;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float mRef = valid ? c.posm[i].w : 0.0f;
         Body b{*this, (VISC && valid) ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f, mRef, mRef / rho0};
-        sweep<COLOR || DENS>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, COLOR || DENS>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         if (VISC) deltaV[i] = mul3s(smul3(visc, b.a), dt);
         if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
         if (nextScalar) c.posf[i].w = nextScalar[i];
@@ -337,11 +370,13 @@ struct OpPressureForce {
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
+    static constexpr int kQuadBit = kQuadPressure;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, i, valid ? pterm[i] : 0.0f, v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         float3 a = b.a;
         if (len3(a) > kMaxA) a = mul3s(mul3s(a, 1.0f / sqrtf(dot3(a, a))), kMaxA);
         vel[i] = add3(vel[i], mul3s(a, dt));
@@ -456,10 +491,30 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool WITH_RATE>
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_quad(const OpDfsphHeadT<WITH_RATE> o, int n)
+{
+    const int i = quad_particle(o.c);
+    if (i < 0) return;
+    (void)n;
+    const bool valid = in_range(o.c, i);
+    long long fixed = 0;
+    const float3 own = (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0);
+    typename OpDfsphHeadT<WITH_RATE>::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0)};
+    sweep_quad<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
+    if (stores_results<true>(valid)) {
+        const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
+        o.density[i] = b.den;
+        o.alpha[i] = al;
+        if (WITH_RATE) fixed = finish_rate<false, 0>(o.out, i, b.e, b.den, al);
+    }
+    if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
+}
+template <bool WITH_RATE>
 inline void launch_dfsph_head(const OpDfsphHeadT<WITH_RATE>& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.quad & kQuadHead)) k_dfsph_head_quad<WITH_RATE><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_dfsph_head<WITH_RATE, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -497,12 +552,10 @@ struct OpRate {
 };
 // quad-per-particle variant (walk_row_quad): two divergent gathers per pair make this sweep the one that gains most
 #ifndef SPHX_QUAD_WAVES
-#define SPHX_QUAD_ATTR
-#else
-#define SPHX_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(SPHX_QUAD_WAVES, SPHX_QUAD_WAVES)))
+#define SPHX_QUAD_WAVES 8      // waves per SIMD the register budget is cut for (64 VGPRs, 16 bytes of scratch): measured 4 % faster than 7
 #endif
 template <bool DENSITY_MODE, int WARM>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) SPHX_QUAD_ATTR k_rate_quad(const OpRate o, int n)
+__global__ void __launch_bounds__(kWideBlock, SPHX_QUAD_WAVES) k_rate_quad(const OpRate o, int n)
 {
     const int i = quad_particle(o.c);
     if (i < 0) return;
@@ -512,7 +565,7 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) SPHX_QUAD_ATTR k_ra
     const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
     OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
     sweep_quad<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
-    if (valid && (threadIdx.x & 3) == 0) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
+    if (stores_results<true>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool DENSITY_MODE, int WARM, bool STREAM>
@@ -537,7 +590,7 @@ inline void launch_rate_kernel(const OpRate& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-    else if (o.c.nbr && o.c.quad) k_rate_quad<DENSITY_MODE, WARM><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.quad & kQuadRate)) k_rate_quad<DENSITY_MODE, WARM><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -576,11 +629,13 @@ struct OpCorrect {
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
+    static constexpr int kQuadBit = kQuadCorrect;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, valid ? kappa[i] : 0.0f, v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         const float3 vn = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
         vel[i] = vn;
         c.vel4[i] = f4(vn);
@@ -619,12 +674,18 @@ struct OpLambda {
             gs = v3(gs.x - gr.x, gs.y - gr.y, gs.z - gr.z);
             sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
+        {
+            f(den, other.den); f(gs.x, other.gs.x); f(gs.y, other.gs.y); f(gs.z, other.gs.z); f(sl, other.sl);
+        }
     };
+    static constexpr int kQuadBit = kQuadLambda;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         density[i] = b.den;
         float lam = (b.den > rho0) ? (-(b.den / rho0 - 1.0f) / (dot3(b.gs, b.gs) + b.sl + kEps)) : 0.0f;
         lam *= relaxation;
@@ -654,12 +715,15 @@ struct OpDeltaPos {
             const float s = mj * (li + lj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
+    static constexpr int kQuadBit = kQuadDelta;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, valid ? lambda[i] : 0.0f, v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         deltaPos[i] = div3s(b.a, rho0);
     }
 };
@@ -702,13 +766,20 @@ struct OpXsph {
                 cden += vol * w;
             }
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
+        {
+            f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z);
+            if (COLOR) { f(cg.x, other.cg.x); f(cg.y, other.cg.y); f(cg.z, other.cg.z); f(cden, other.cden); }
+        }
     };
+    static constexpr int kQuadBit = kQuadXsph;
+    template <bool QUAD = false>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float mRef = valid ? c.posm[i].w : 0.0f;
         Body b{*this, valid ? vel[i] : v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, mRef, mRef / rho0};
-        sweep<COLOR>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, COLOR>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         velOut[i] = add3(b.vi, div3s(smul3(xsphC, b.a), rho0));   // not the live velocity yet: vel4 untouched
         if (COLOR) { const float3 g = div3s(b.cg, max_eps(b.cden)); colorGrad[i] = g; c.cg4[i] = f4(g); }
     }
