@@ -38,7 +38,7 @@ RATE_KERNEL_BYTES_PER_PARTICLE = 44
 # flop model of SURVEY.md §8d for one accepted pair of the rate sweep: gradW ~ 40 (1 sqrt + divisions counted as 1
 # each) + (v_i - v_j).gradW, mass factor and accumulation ~ 10
 RATE_KERNEL_FLOP_PER_PAIR = 50
-DOMINANT_SPAN = "density_error"  # k_rate<DENSITY_MODE>: computeDensityError_CUDA, DFSPHSolver.cu:94-116
+DOMINANT_SPAN = "density_error"  # k_rate_quad<DENSITY_MODE> (k_rate<> without rows): computeDensityError_CUDA, DFSPHSolver.cu:94-116
 
 
 def step_bytes_per_particle(solver, v, d, k):
@@ -289,7 +289,7 @@ def main():
         achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
         traffic, valu_busy = read_traffic("%s_nx%d" % (solver, args.nx))
         flops = RATE_KERNEL_FLOP_PER_PAIR * nb_free_fall["pairs"] / (avg_ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s')" % span,
+        result["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s')" % span,
                               "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                               "avg_launch_ms": avg_ms, "launches": launches,
@@ -297,8 +297,9 @@ def main():
                               "valu": {"pairs_per_launch": nb_free_fall["pairs"], "flop_per_pair_model": RATE_KERNEL_FLOP_PER_PAIR,
                                        "achieved_TFLOPs": flops, "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
                                        "valu_busy_frac_pmc": valu_busy},
-                              "limiter": "divergent 16-byte neighbour gathers (vector-memory address/L1 line rate), see "
-                                         "profiles/r02_ubench_sweep_structure.txt"}
+                              "limiter": "VALU issue (bit-exact IEEE pair arithmetic, ~97 % of the issue slots) with the quad-per-particle "
+                                         "walk; the lane-per-particle walk it replaced was bound by the L1's line-access rate "
+                                         "(profiles/r02_ubench_sweep_structure.txt, profiles/r02_ubench_quad_walk.txt)"}
     else:
         result["roofline"] = None
 

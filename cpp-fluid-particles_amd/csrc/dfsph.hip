@@ -19,7 +19,7 @@ using namespace sphx;
 DFSPHSolver::DFSPHSolver(int num, float defaultDensityErrorThreshold, float defaultDivergenceErrorThreshold,
                          int defaultMaxIter)
     : BasicSPHSolver(num), alpha((unsigned)num), bufferFloat((unsigned)num), error((unsigned)num),
-      denWarmStiff((unsigned)num), scratch((unsigned)num), errorAccum(2u),
+      denWarmStiff((unsigned)num), scratch((unsigned)num), errorAccum(2u * kErrorSlots * kErrorSlotStride),
       densityErrorThreshold(defaultDensityErrorThreshold), divergenceErrorThreshold(defaultDivergenceErrorThreshold),
       maxIter(defaultMaxIter)
 {
@@ -28,18 +28,19 @@ DFSPHSolver::~DFSPHSolver() noexcept {}
 
 long long DFSPHSolver::readErrorTotalFixed()
 {
-    unsigned long long acc = 0;
-    HIP_CALL(hipMemcpyAsync(&acc, errorAccum.addr(), sizeof(acc), hipMemcpyDeviceToHost, sphx::stream()));
+    // kErrorSlots partial sums, one cache line apart (accumulate_error, sweep_ops.hpp): exact integers, any order
+    static_assert(sizeof(unsigned long long) == 8, "64-bit accumulators");
+    std::vector<unsigned long long> slots((size_t)kErrorSlots * kErrorSlotStride);
+    HIP_CALL(hipMemcpyAsync(slots.data(), errorAccum.addr(), sizeof(unsigned long long) * slots.size(), hipMemcpyDeviceToHost, sphx::stream()));
     HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    unsigned long long acc = 0;
+    for (int k = 0; k < kErrorSlots; ++k) acc += slots[(size_t)k * kErrorSlotStride];
     return (long long)acc;
 }
 
 float DFSPHSolver::readErrorTotal()
 {
-    unsigned long long acc = 0;
-    HIP_CALL(hipMemcpyAsync(&acc, errorAccum.addr(), sizeof(acc), hipMemcpyDeviceToHost, sphx::stream()));
-    HIP_CALL(hipStreamSynchronize(sphx::stream()));
-    return (float)((double)(long long)acc * (1.0 / 4294967296.0));
+    return (float)((double)readErrorTotalFixed() * (1.0 / 4294967296.0));
 }
 
 namespace {
@@ -49,7 +50,7 @@ void launch_rate(const OpRate& op, int n, bool reduce, bool keepAccum = false)
     if (n <= 0) return;
     OpRate o = op;
     if (!reduce) o.out.accum = nullptr;
-    else if (!keepAccum) HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long), sphx::stream()));
+    else if (!keepAccum) HIP_CALL(hipMemsetAsync(o.out.accum, 0, sizeof(unsigned long long) * kErrorSlots * kErrorSlotStride, sphx::stream()));
     launch_rate_kernel<DENSITY_MODE, WARM>(o, n);
 }
 }  // namespace

@@ -77,7 +77,7 @@ private:
     DArray<float> error;
     DArray<float> denWarmStiff;
     DArray<float> scratch;         // permutation target for denWarmStiff
-    DArray<int> errorAccum;        // 2 ints = one 64-bit fixed-point accumulator
+    DArray<int> errorAccum;        // 64-bit fixed-point accumulators: kErrorSlots partial sums, one cache line apart
     const float densityErrorThreshold;
     const float divergenceErrorThreshold;
     const int maxIter;

@@ -20,12 +20,15 @@ def test_sweep_kernels_have_no_spills_and_uniform_base_gathers():
         if not m:
             continue
         name, vgpr, occ, scratch, lds = m.group(1), int(m.group(2)), int(m.group(4)), int(m.group(5)), int(m.group(6))
-        assert scratch == 0, "scratch spill in " + name
-        if "k_rate<true, 2, false>" in name:          # the dominant kernel, global-gather variant
+        if "k_rate_quad<" in name:
+            # deliberately compiled for 8 waves/SIMD (64 VGPRs): a handful of spilled dwords buys the extra wave
+            # (measured 4 % faster than the spill-free 7-wave build)
+            assert scratch <= 32 and occ >= 8 and lds == 0, l
+        else:
+            assert scratch == 0, "scratch spill in " + name
+        if "k_rate_quad<true, 2>" in name:            # the dominant kernel (quad-per-particle walk)
             seen_rate = True
-            assert lds == 0 and occ >= 7 and vgpr <= 72, l
             mix = out[i + 1]
             assert "main loop" in mix
-            assert re.search(r"gathers uniform-base 8, per-lane-base 0", mix), mix
-            assert re.search(r"row loads 4", mix), mix
+            assert re.search(r"gathers uniform-base 8, per-lane-base 0", mix), mix      # 4 chunks x (position + velocity)
     assert seen_rate

@@ -8,11 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, key = sys.argv[1], sys.argv[2]
 src = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % tag)))["k_rate_density"]
 entry = {
-    "kernel": "k_rate<true,2,false> (computeDensityError_CUDA), one launch at 10,288,500 particles",
+    "kernel": "k_rate_quad<true,2> (computeDensityError_CUDA, quad-per-particle walk), one launch at 10,288,500 particles",
     "hbm_bytes_per_launch": src["hbm_bytes_fetch_x2"],
     "fetch_size_raw_bytes": src["FETCH_SIZE"], "write_size_bytes": src["WRITE_SIZE"],
     "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes); separate --pmc passes",
-    "valu_busy_frac": src.get("valu_busy_frac"), "ta_busy_frac": src.get("ta_busy_frac"),
+    "valu_busy_frac": min(1.0, src["valu_busy_frac"]) if src.get("valu_busy_frac") is not None else None,
+    "valu_busy_note": "SQ_ACTIVE_INST_VALU x4 / (kernel cycles x 1024 SIMDs), capped at 1 (raw %.3f); VALU issue slots SQ_INSTS_VALU x4 / same = %.3f"
+                      % (src.get("valu_busy_frac") or 0.0, src.get("valu_issue_frac") or (src.get("SQ_INSTS_VALU", 0.0) * 4.0 / (src.get("kernel_cycles", 1.0) * 1024.0))),
+    "ta_busy_frac": src.get("ta_busy_frac"),
+    "l1_hit_rate": 1.0 - src["TCP_TCC_READ_REQ_sum"] / src["TCP_TOTAL_CACHE_ACCESSES_sum"] if "TCP_TCC_READ_REQ_sum" in src else None,
     "l1_line_accesses_per_clk_per_cu": src.get("l1_line_accesses_per_clk_per_cu"),
     "l2_hit_rate": src["TCC_HIT_sum"] / (src["TCC_HIT_sum"] + src["TCC_MISS_sum"]) if "TCC_HIT_sum" in src else None,
     "avg_launch_us_rocprof": src.get("avg_launch_us_rocprof"),

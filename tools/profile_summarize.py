@@ -83,6 +83,8 @@ if traffic:
         cycles = extra["GRBM_GUI_ACTIVE"] / 8.0
         kr["kernel_cycles"] = cycles
         kr["valu_busy_frac"] = extra["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
+        if "SQ_INSTS_VALU" in extra:       # issue slots: one wave64 VALU instruction occupies a SIMD for 4 clocks
+            kr["valu_issue_frac"] = extra["SQ_INSTS_VALU"] * 4.0 / (cycles * 1024.0)
         stats = find("stats", "*kernel_stats.csv")
         us = None
         if stats:
