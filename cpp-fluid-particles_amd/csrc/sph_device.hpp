@@ -798,6 +798,69 @@ __device__ __forceinline__ void quad_accumulate(Body& body, Body& term, const bo
     });
 }
 
+// U consecutive chunks [s, s + U) of the quad's row, straight-line: all row loads, then all gathers, then the terms in
+// order.  (No early exit inside: a conditional between the chunks makes the compiler sink each chunk's loads next to
+// their use, and the walk becomes load -> wait -> compute per chunk.)
+#ifndef SPHX_QUAD_PAIR2
+#define SPHX_QUAD_PAIR2 0      // packed two-chunk evaluation: -21 % VALU instructions but 90 instead of 72 VGPRs; measured slower
+#endif
+template <int U, bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
+__device__ __forceinline__ void quad_chunks(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowq, const int cnt,
+                                            const int s, const float m0, const bool allPlain, const float3 pi, Body& body)
+{
+    const int g = threadIdx.x & 3;
+    unsigned int e[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // unconditional load (chunks past this row's end hold stale entries), then: past the end -> record 0,
+        // evaluated and dropped
+        ok[u] = 4 * (s + u) + g < cnt;
+        const unsigned int raw = rowq[(size_t)(s + u) * 256u];
+        e[u] = ok[u] ? raw : 0u;
+    }
+    float4 pj[U];
+    typename Op::Field f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
+    if constexpr (SPHX_QUAD_PAIR2 && has_pair2<Body>() && WANT_BOUNDARY && !SKIN && !TOL && U % 2 == 0) {
+        // two chunks per packed evaluation: lane g holds entries 4s+g and 4(s+1)+g; their terms go to separate
+        // zeroed accumulators and are added chunk by chunk, entry by entry
+        bool fast = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) fast = fast && !(ok[u] && (e[u] & kPlainBit) != 0u);
+        if (!__any(allPlain || !fast)) {
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                Body ta = body, tb = body;
+                ta.each_acc(ta, [](float& a, float&) { a = 0.0f; });
+                tb.each_acc(tb, [](float& a, float&) { a = 0.0f; });
+                body.pair2(ta, tb, f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
+                quad_accumulate(body, ta, ok[u]);
+                quad_accumulate(body, tb, ok[u + 1]);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool isB = (e[u] & kBoundaryBit) != 0u;
+        const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+        const float r2 = dot3(d, d);
+        bool use = ok[u];
+        if (!WANT_BOUNDARY && isB) use = false;
+        if (SKIN && r2 > c.k.tCut) use = false;
+        Body term = body;
+        term.each_acc(term, [](float& a, float&) { a = 0.0f; });
+        if (TOL) term.pair_tol(f[u], isB, d, r2, pj[u].w);
+        else {
+            const bool plain = use && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u);
+            pair_dispatch(term, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
+        }
+        quad_accumulate(body, term, use);
+    }
+}
+
 template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
 __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowq, const int cnt,
                                               const float m0, const bool allPlain, const float3 pi, Body& body)
@@ -805,69 +868,13 @@ __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, c
 #ifndef SPHX_QUAD_U
 #define SPHX_QUAD_U 4
 #endif
-#ifndef SPHX_QUAD_PAIR2
-#define SPHX_QUAD_PAIR2 0      // packed two-chunk evaluation: -21 % VALU instructions but 90 instead of 72 VGPRs; measured slower
-#endif
     constexpr int U = SPHX_QUAD_U;             // chunks in flight
-    const int g = threadIdx.x & 3;
     int steps = (cnt + kRowChunk - 1) >> 2;    // the same in the 4 lanes of a quad; the wave runs to its longest row
 #pragma unroll
     for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
-    const int lastChunk = c.cap / kRowChunk - 1;
-    for (int s = 0; s < steps; s += U) {
-        unsigned int e[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // unconditional load (chunks past this row's end hold stale entries; past the wave's last chunk the index
-            // is clamped into the tile's slab), then: past the end -> record 0, evaluated and dropped
-            ok[u] = 4 * (s + u) + g < cnt;
-            const unsigned int raw = rowq[(size_t)min(s + u, lastChunk) * 256u];
-            e[u] = ok[u] ? raw : 0u;
-        }
-        float4 pj[U];
-        typename Op::Field f[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) fetch_pair<PACKED, Op>(op, c, m0, e[u], pj[u], f[u]);
-        if constexpr (SPHX_QUAD_PAIR2 && has_pair2<Body>() && WANT_BOUNDARY && !SKIN && !TOL && U % 2 == 0) {
-            // two chunks per packed evaluation: lane g holds entries 4s+g and 4(s+1)+g; their terms go to separate
-            // zeroed accumulators and are added chunk by chunk, entry by entry
-            bool fast = true;
-#pragma unroll
-            for (int u = 0; u < U; ++u) fast = fast && !(ok[u] && (e[u] & kPlainBit) != 0u);
-            if (!__any(allPlain || !fast)) {
-#pragma unroll
-                for (int u = 0; u < U; u += 2) {
-                    if (s + u >= steps) break;       // wave-uniform
-                    Body ta = body, tb = body;
-                    ta.each_acc(ta, [](float& a, float&) { a = 0.0f; });
-                    tb.each_acc(tb, [](float& a, float&) { a = 0.0f; });
-                    body.pair2(ta, tb, f[u], f[u + 1], (e[u] & kBoundaryBit) != 0u, (e[u + 1] & kBoundaryBit) != 0u, pi, pj[u], pj[u + 1]);
-                    quad_accumulate(body, ta, ok[u]);
-                    quad_accumulate(body, tb, ok[u + 1]);
-                }
-                continue;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (s + u >= steps) break;             // wave-uniform
-            const bool isB = (e[u] & kBoundaryBit) != 0u;
-            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
-            const float r2 = dot3(d, d);
-            bool use = ok[u];
-            if (!WANT_BOUNDARY && isB) use = false;
-            if (SKIN && r2 > c.k.tCut) use = false;
-            Body term = body;
-            term.each_acc(term, [](float& a, float&) { a = 0.0f; });
-            if (TOL) term.pair_tol(f[u], isB, d, r2, pj[u].w);
-            else {
-                const bool plain = use && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u] & kPlainBit) != 0u);
-                pair_dispatch(term, allPlain || plain, f[u], isB, d, r2, pj[u].w, (int)(e[u] & kIndexMask));
-            }
-            quad_accumulate(body, term, use);
-        }
-    }
+    int s = 0;
+    for (; s + U <= steps; s += U) quad_chunks<U, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowq, cnt, s, m0, allPlain, pi, body);
+    for (; s < steps; ++s) quad_chunks<1, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowq, cnt, s, m0, allPlain, pi, body);
 }
 
 // The particle of this lane's quad in a quad-per-particle launch: one block of 4 waves per tile, wave w takes the

@@ -7,7 +7,7 @@ for name in which:
     nx, solver = cfg[name]
     P, f, b = sphx.scene(nx)
     P.solver = solver; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4; P.pbd_iters = 4
-    P.reserved[0] = int(os.environ.get("FLAGS", "0"))
+    P.reserved[0] = int(os.environ.get("FLAGS", "0")); P.reserved[3] = int(os.environ.get("TOL", "0"))
     if solver == sphx.WCSPH: P.dt = 0.001
     t = time.time(); s = sphx.System(P, f, b); print(name, "n", s.n, "nb", s.nb, "create %.2fs" % (time.time() - t), flush=True)
     s.step()
