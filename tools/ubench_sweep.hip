@@ -272,6 +272,72 @@ __global__ void __launch_bounds__(256) k_qg(Consts c, const float4* __restrict__
     if (ip < n && (lane % G) == 0) out[i] = e;
 }
 
+// ---- CQ: lane-per-particle arithmetic and accumulation (as G32c), but the gathers are issued quad-cooperatively: in
+// gather k the 4 lanes of a quad fetch the 4 entries of particle k of the quad (adjacent records), park them in LDS and
+// every lane then reads its own 4 records back.  Rows in the engine's chunk layout: [tile][chunk][lane][4].
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_cq(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                            const unsigned int* __restrict__ rows, const int* __restrict__ cnt,
+                                            float* __restrict__ out, int n, int numTiles, int capChunks)
+{
+    constexpr int kStride = 64 * 4 + 4;                 // float4 slots per source index k, padded
+    __shared__ float4 lpos[4][4 * kStride];             // [wave][k][quad * 4 + entry]   (linear in the lane when written)
+    __shared__ float4 lvel[TWO ? 4 : 1][TWO ? 4 * kStride : 1];
+    const int wave = threadIdx.x >> 6;
+    const int tile = logical_block() * 4 + wave;
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63, l = lane & 3;
+    const int ip = tile * 64 + lane;
+    const int i = min(ip, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const int m = ip < n ? cnt[i] : 0;
+    int chunks = (m + 3) >> 2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) chunks = max(chunks, __shfl_xor(chunks, off, 64));
+    const unsigned int* tileRows = rows + (size_t)tile * capChunks * 256u;
+    // counts of the 4 particles of my quad
+    int mk[4];
+    mk[0] = __builtin_amdgcn_mov_dpp(m, 0x00, 0xf, 0xf, true); mk[1] = __builtin_amdgcn_mov_dpp(m, 0x55, 0xf, 0xf, true);
+    mk[2] = __builtin_amdgcn_mov_dpp(m, 0xAA, 0xf, 0xf, true); mk[3] = __builtin_amdgcn_mov_dpp(m, 0xFF, 0xf, 0xf, true);
+    float e = 0.0f;
+    for (int s = 0; s < chunks; ++s) {
+        const unsigned int* ch = tileRows + (size_t)s * 256u;
+        unsigned int idx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                    // entry 4s + l of particle k of my quad
+            const unsigned int raw = ch[((lane & ~3) + k) * 4 + l];
+            idx[k] = (4 * s + l < mk[k]) ? raw : (unsigned)n;
+        }
+        float4 pj[4], vj[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pj[k] = gather16(posm, idx[k] << 4);
+            if (TWO) vj[k] = gather16(vel4, idx[k] << 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lpos[wave][k * kStride + lane] = pj[k];
+            if (TWO) lvel[wave][k * kStride + lane] = vj[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 qj[4], wj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                    // my particle = index l of the quad; its entry t
+            qj[t] = lpos[wave][l * kStride + (lane & ~3) + t];
+            wj[t] = TWO ? lvel[wave][l * kStride + (lane & ~3) + t] : make_float4(qj[t].w, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e += pair_term<EXACT>(c, pi, vi, qj[t], wj[t]);   // padded entries: the dummy record, term +-0
+    }
+    if (ip < n) out[i] = e;
+}
+
 struct BlockRanges { int start[9]; int len[9]; int base[9]; int total; };
 
 template <int T, bool EXACT, bool TWO>
@@ -576,6 +642,7 @@ int main(int argc, char** argv)
     } while (0)
             run(tag("G32 "), exact, two, [&] { PICK(k_g32, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsG, dCnt, dOut, n, numTiles); });
             run(tag("G32c"), exact, two, [&] { PICK(k_g32c, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
+            run(tag("CQ  "), exact, two, [&] { PICK(k_cq, dim3(gridG), dim3(256), 0, st, c, dPos, dVel, reinterpret_cast<const unsigned int*>(dRowsGc), dCnt, dOut, n, numTiles, kCap / 4); });
             run(tag("G32i"), exact, two, [&] { PICK(k_g32i, dim3(gridG), dim3(256), 0, st, c, dPV, dRowsGc, dTileChunks4, dOut, n, numTiles, kCap / 4); });
             for (int v = 0; v < 6; ++v) {
                 const QSet& Q = qsets[v];
