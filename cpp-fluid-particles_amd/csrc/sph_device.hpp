@@ -932,6 +932,10 @@ __device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, cons
 // a (dx,dy) column are contiguous in memory, so when they hold no boundary particles the fluid
 // ranges are visited as one run (identical order).  With `ldsPos` (streamed tile, fmt 2) the wave
 // stages one dx group at a time, candidates are read from LDS and entries carry (group, slot).
+#ifndef SPHX_BUILD_AHEAD
+#define SPHX_BUILD_AHEAD 4
+#endif
+constexpr int kBuildAhead = SPHX_BUILD_AHEAD;
 constexpr int kRowStage = 32;      // entries per lane staged in LDS by the row builder (longer rows continue in global memory)
 __device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage, unsigned int* row, int lane, int cnt, unsigned int e)
 {
@@ -994,13 +998,13 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                     const int cell = base + z;
                     const int e = c.csF[cell + step];
                     int j = c.csF[cell];
-                    // four candidates per trip: the loads are independent, the appends stay in order
-                    for (; j + 4 <= e; j += 4) {
-                        float4 pj[4];
+                    // kBuildAhead candidates per trip: the loads are independent, the appends stay in order
+                    for (; j + kBuildAhead <= e; j += kBuildAhead) {
+                        float4 pj[kBuildAhead];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) pj[u] = streamed ? ldsPos[j + u + fShift] : c.posm[j + u];
+                        for (int u = 0; u < kBuildAhead; ++u) pj[u] = streamed ? ldsPos[j + u + fShift] : c.posm[j + u];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < kBuildAhead; ++u) {
                             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
                             const float r2 = dot3(d, d);
                             if (r2 > c.buildCut || j + u == i) continue;
