@@ -81,6 +81,7 @@ struct SweepCache {
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)
     int flags = 0;
     int quadMask = 1;                        // QuadBits (sweep_ops.hpp): sweeps that run quad-per-particle when rows exist
+    int duoMask = 0;                         // QuadBits: sweeps that run with two lanes per particle
     // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
     // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
     unsigned int generation = 0;

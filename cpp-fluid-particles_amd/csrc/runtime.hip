@@ -424,6 +424,7 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; }   // rows are stored in chunks of 4
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
+    if (const char* e = getenv("SPHX_DUO_MASK")) duoMask = atoi(e);            // ... and which with two lanes per particle
 }
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
@@ -510,6 +511,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.cap = cap;
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
     c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? quadMask : 0;
+    c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? duoMask : 0;
     c.n = n;
     c.vel4 = vel4w();
     c.cg4 = cg4w();

@@ -467,7 +467,8 @@ struct SweepCtx {
                                             // 27 cells around the cell of the CURRENT position (PBDSolver.cu:139-141 on moved
                                             // positions), so a row is only valid while its particle stays in that cell
     float buildCut;                         // squared cutoff the row builder accepts candidates with
-    int quad;                               // sweeps with a quad-per-particle variant use it (walk_row_quad)
+    int quad;                               // QuadBits: sweeps that run quad-per-particle (walk_row_quad)
+    int duo;                                // QuadBits: sweeps that run two lanes per particle (walk_row_duo); quad wins where both are set
     int numTiles;                           // tiles this launch covers
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
@@ -923,6 +924,143 @@ __device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, cons
         }
     }
     if (valid && !useRow)      // no rows, or this particle's row overflowed / went stale: the 4 lanes walk the cells alike
+        walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+            body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
+        });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Duo walk: TWO lanes per particle.  Lane h of a pair evaluates entries h and h + 2 of every chunk (so the two lanes
+// gather adjacent records in each instruction and a quad touches 2 x ~1.2 lines instead of ~3.5), both with the packed
+// two-entry arithmetic where the body has it.  The running sums are handed back and forth: entry order is
+// lane0.A, lane1.A, lane0.B, lane1.B, and every hop is  a = swap(a) + term  executed by both lanes (the lane that does
+// not own the slot computes a value nobody reads).  After every chunk the sums sit in lane 1, which stores the results.
+__device__ __forceinline__ float duo_swap_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
+
+template <class Body>
+__device__ __forceinline__ void duo_hops(Body& body, Body& ta, Body& tb, const bool okA, const bool okB)
+{
+    // dropped terms become +0 (see quad_accumulate)
+    ta.each_acc(ta, [&](float& a, float&) { a = okA ? a : 0.0f; });
+    tb.each_acc(tb, [&](float& a, float&) { a = okB ? a : 0.0f; });
+    body.each_acc(ta, [&](float& a, float& t) { a = duo_swap_f(a) + t; a = duo_swap_f(a) + t; });
+    body.each_acc(tb, [&](float& a, float& t) { a = duo_swap_f(a) + t; a = duo_swap_f(a) + t; });
+}
+
+template <int U, bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
+__device__ __forceinline__ void duo_chunks(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowd, const int cnt,
+                                           const int s, const float m0, const bool allPlain, const float3 pi, Body& body)
+{
+    const int h = threadIdx.x & 1;
+    unsigned int e[U][2];
+    bool ok[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            ok[u][w] = 4 * (s + u) + h + 2 * w < cnt;
+            const unsigned int raw = rowd[(size_t)(s + u) * 256u + 2 * w];
+            e[u][w] = ok[u][w] ? raw : 0u;
+        }
+    float4 pj[U][2];
+    typename Op::Field f[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) fetch_pair<PACKED, Op>(op, c, m0, e[u][w], pj[u][w], f[u][w]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        Body ta = body, tb = body;
+        ta.each_acc(ta, [](float& a, float&) { a = 0.0f; });
+        tb.each_acc(tb, [](float& a, float&) { a = 0.0f; });
+        bool useA = ok[u][0], useB = ok[u][1];
+        const bool isBa = (e[u][0] & kBoundaryBit) != 0u, isBb = (e[u][1] & kBoundaryBit) != 0u;
+        bool done = false;
+        if constexpr (has_pair2<Body>() && WANT_BOUNDARY && !SKIN && !TOL) {
+            const bool plain = (useA && (e[u][0] & kPlainBit) != 0u) || (useB && (e[u][1] & kPlainBit) != 0u);
+            if (!__any(allPlain || plain)) {
+                body.pair2(ta, tb, f[u][0], f[u][1], isBa, isBb, pi, pj[u][0], pj[u][1]);
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                Body& t = w ? tb : ta;
+                bool& use = w ? useB : useA;
+                const bool isB = w ? isBb : isBa;
+                const float3 d = sub3(pi, v3(pj[u][w].x, pj[u][w].y, pj[u][w].z));
+                const float r2 = dot3(d, d);
+                if (!WANT_BOUNDARY && isB) use = false;
+                if (SKIN && r2 > c.k.tCut) use = false;
+                if (TOL) t.pair_tol(f[u][w], isB, d, r2, pj[u][w].w);
+                else {
+                    const bool plain = use && (SKIN ? pair_needs_plain_ops(d, r2) : (e[u][w] & kPlainBit) != 0u);
+                    pair_dispatch(t, allPlain || plain, f[u][w], isB, d, r2, pj[u][w].w, (int)(e[u][w] & kIndexMask));
+                }
+            }
+        }
+        duo_hops(body, ta, tb, useA, useB);
+    }
+}
+
+template <bool PACKED, bool WANT_BOUNDARY, bool SKIN, bool TOL, class Op, class Body>
+__device__ __forceinline__ void walk_row_duo(const Op& op, const SweepCtx& c, const unsigned int* __restrict__ rowd, const int cnt,
+                                             const float m0, const bool allPlain, const float3 pi, Body& body)
+{
+    constexpr int U = 2;                       // chunks in flight = 4 entries per lane
+    int steps = (cnt + kRowChunk - 1) >> 2;    // the same in both lanes of a pair; the wave runs to its longest row
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    int s = 0;
+    for (; s + U <= steps; s += U) duo_chunks<U, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowd, cnt, s, m0, allPlain, pi, body);
+    for (; s < steps; ++s) duo_chunks<1, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowd, cnt, s, m0, allPlain, pi, body);
+}
+
+// The particle of this lane's pair in a duo launch: a block of 4 waves covers two tiles, wave w takes the particles
+// [32 (w & 1), +32) of tile 2 b + (w >> 1).  -1: the wave is past the end.
+__device__ __forceinline__ int duo_particle(const SweepCtx& c)
+{
+    const int lt = logical_block() * 2 + (int)(threadIdx.x >> 7);
+    if (lt >= c.numTiles) return -1;
+    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
+    return tile * kTile + (int)((threadIdx.x >> 6) & 1) * 32 + (int)((threadIdx.x & 63) >> 1);
+}
+
+template <bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep_duo(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
+{
+    const bool skin = c.stale != nullptr;
+    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);
+    const bool allPlain = !fast_paths_enabled(c.k);
+    const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
+    bool useRow = rows && valid && cnt <= c.cap;
+    if (skin && useRow) {
+        const int3 cNow = cell_of(pi, c.g);
+        useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
+    }
+    const bool packed = op_packed_scalar<Op>(op) && c.posf && c.massUniform && *c.massUniform != 0;
+    const float m0 = packed ? c.posm[0].w : 0.0f;
+    const unsigned int* rowd = rows ? c.nbr + row_base_offset(valid ? i : 0, c.cap) + (threadIdx.x & 1) : nullptr;
+    const int len = useRow ? cnt : 0;
+    if (rows) {
+        if (c.k.tol) {
+            if (skin) {
+                if (packed) walk_row_duo<true, WANT_BOUNDARY, true, true>(op, c, rowd, len, m0, allPlain, pi, body);
+                else walk_row_duo<false, WANT_BOUNDARY, true, true>(op, c, rowd, len, m0, allPlain, pi, body);
+            } else {
+                if (packed) walk_row_duo<true, WANT_BOUNDARY, false, true>(op, c, rowd, len, m0, allPlain, pi, body);
+                else walk_row_duo<false, WANT_BOUNDARY, false, true>(op, c, rowd, len, m0, allPlain, pi, body);
+            }
+        } else if (skin) {
+            if (packed) walk_row_duo<true, WANT_BOUNDARY, true, false>(op, c, rowd, len, m0, allPlain, pi, body);
+            else walk_row_duo<false, WANT_BOUNDARY, true, false>(op, c, rowd, len, m0, allPlain, pi, body);
+        } else {
+            if (packed) walk_row_duo<true, WANT_BOUNDARY, false, false>(op, c, rowd, len, m0, allPlain, pi, body);
+            else walk_row_duo<false, WANT_BOUNDARY, false, false>(op, c, rowd, len, m0, allPlain, pi, body);
+        }
+    }
+    if (valid && !useRow)      // both lanes walk the cells alike: the sums end up in lane 1 as well
         walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
             body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
         });

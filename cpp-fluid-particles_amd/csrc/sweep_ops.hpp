@@ -32,14 +32,15 @@ template <class Op> __host__ __device__ constexpr auto op_quad_bit_impl(int) -> 
 template <class Op> __host__ __device__ constexpr int op_quad_bit_impl(long) { return 0; }
 template <class Op> __host__ __device__ constexpr int op_quad_bit() { return op_quad_bit_impl<Op>(0); }
 
-template <class Op, bool STREAM, bool QUAD = false>
+// MODE: 0 lane per particle, 1 quad per particle, 2 duo (two lanes per particle)
+template <class Op, bool STREAM, int MODE = 0>
 __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op op, int n)
 {
     (void)n;
-    if constexpr (QUAD) {
-        const int i = quad_particle(op.c);
+    if constexpr (MODE != 0) {
+        const int i = MODE == 1 ? quad_particle(op.c) : duo_particle(op.c);
         if (i < 0) return;
-        op.template operator()<true>(i, in_range(op.c, i), nullptr, nullptr);
+        op.template operator()<MODE>(i, in_range(op.c, i), nullptr, nullptr);
     } else {
         __shared__ BlockLds<Op, STREAM> lds;
         const int wave = threadIdx.x >> 6;
@@ -50,24 +51,31 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op o
     }
 }
 // the sweep of one particle in either launch shape; in a quad launch only lane 0 of the quad stores the results
-template <bool QUAD, bool WANT_BOUNDARY, class Op, class Body>
+template <int MODE, bool WANT_BOUNDARY, class Op, class Body>
 __device__ __forceinline__ void sweep_any(const Op& op, const SweepCtx& c, float4* lp, typename Op::Field* lf, int i, bool valid,
                                           float3 pi, Body& body)
 {
-    if constexpr (QUAD) sweep_quad<WANT_BOUNDARY>(op, c, i, valid, pi, body);
+    if constexpr (MODE == 1) sweep_quad<WANT_BOUNDARY>(op, c, i, valid, pi, body);
+    else if constexpr (MODE == 2) sweep_duo<WANT_BOUNDARY>(op, c, i, valid, pi, body);
     else sweep<WANT_BOUNDARY>(op, c, lp, lf, i, valid, pi, body);
 }
-template <bool QUAD> __device__ __forceinline__ bool stores_results(bool valid) { return valid && (!QUAD || (threadIdx.x & 3) == 0); }
+// quad: every lane holds the sums, lane 0 stores; duo: the sums end in lane 1 of the pair
+template <int MODE> __device__ __forceinline__ bool stores_results(bool valid)
+{
+    return valid && (MODE == 0 || (MODE == 1 && (threadIdx.x & 3) == 0) || (MODE == 2 && (threadIdx.x & 1) == 1));
+}
 // grid of a sweep launch: one wave per tile of the launch's range, padded to a multiple of 8 blocks
 inline unsigned int sweep_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kTile, kWideBlock); }
 inline unsigned int quad_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kWideBlock, kWideBlock); }   // one block per tile
+inline unsigned int duo_grid(const SweepCtx& c) { return xcd_grid(((c.numTiles + 1) / 2) * kWideBlock, kWideBlock); }   // one block per two tiles
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
     if (n <= 0 || op.c.numTiles <= 0) return;
     if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
     else if constexpr (op_quad_bit<Op>() != 0) {
-        if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) k_run_op<Op, false, true><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+        if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) k_run_op<Op, false, 1><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+        else if (op.c.nbr && (op.c.duo & op_quad_bit<Op>())) k_run_op<Op, false, 2><<<duo_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
         else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
     } else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
 }
@@ -169,7 +177,7 @@ struct OpFluidProps {
         }
     };
     static constexpr int kQuadBit = kQuadProps;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float mRef = valid ? c.posm[i].w : 0.0f;
@@ -378,7 +386,7 @@ struct OpPressureForce {
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
     static constexpr int kQuadBit = kQuadPressure;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, i, valid ? pterm[i] : 0.0f, v3(0, 0, 0)};
@@ -497,18 +505,18 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     }
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
-template <bool WITH_RATE>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_quad(const OpDfsphHeadT<WITH_RATE> o, int n)
+template <bool WITH_RATE, int MODE>
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_group(const OpDfsphHeadT<WITH_RATE> o, int n)
 {
-    const int i = quad_particle(o.c);
+    const int i = MODE == 1 ? quad_particle(o.c) : duo_particle(o.c);
     if (i < 0) return;
     (void)n;
     const bool valid = in_range(o.c, i);
     long long fixed = 0;
     const float3 own = (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0);
     typename OpDfsphHeadT<WITH_RATE>::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0)};
-    sweep_quad<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
-    if (stores_results<true>(valid)) {
+    sweep_any<MODE, true>(o, o.c, nullptr, nullptr, i, valid, own_pos(o.c, i, valid), b);
+    if (stores_results<MODE>(valid)) {
         const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
         o.density[i] = b.den;
         o.alpha[i] = al;
@@ -521,7 +529,8 @@ inline void launch_dfsph_head(const OpDfsphHeadT<WITH_RATE>& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-    else if (o.c.nbr && (o.c.quad & kQuadHead)) k_dfsph_head_quad<WITH_RATE><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.quad & kQuadHead)) k_dfsph_head_group<WITH_RATE, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.duo & kQuadHead)) k_dfsph_head_group<WITH_RATE, 2><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_dfsph_head<WITH_RATE, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -572,7 +581,21 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_QUAD_WAVES) k_rate_quad(const
     const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
     OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
     sweep_quad<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
-    if (stores_results<true>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
+    if (stores_results<1>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
+    if (o.out.accum) accumulate_error(fixed, o.out.accum);
+}
+template <bool DENSITY_MODE, int WARM>
+__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate_duo(const OpRate o, int n)
+{
+    const int i = duo_particle(o.c);
+    if (i < 0) return;
+    (void)n;
+    const bool valid = in_range(o.c, i);
+    long long fixed = 0;
+    const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
+    OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
+    sweep_duo<true>(o, o.c, i, valid, own_pos(o.c, i, valid), b);
+    if (stores_results<2>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool DENSITY_MODE, int WARM, bool STREAM>
@@ -598,6 +621,7 @@ inline void launch_rate_kernel(const OpRate& o, int n)
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else if (o.c.nbr && (o.c.quad & kQuadRate)) k_rate_quad<DENSITY_MODE, WARM><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.duo & kQuadRate)) k_rate_duo<DENSITY_MODE, WARM><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
 
@@ -637,7 +661,7 @@ struct OpCorrect {
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
     static constexpr int kQuadBit = kQuadCorrect;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, valid ? kappa[i] : 0.0f, v3(0, 0, 0)};
@@ -687,7 +711,7 @@ struct OpLambda {
         }
     };
     static constexpr int kQuadBit = kQuadLambda;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, 0.0f, 0.0f, v3(0, 0, 0)};
@@ -725,7 +749,7 @@ struct OpDeltaPos {
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
     static constexpr int kQuadBit = kQuadDelta;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         Body b{*this, valid ? lambda[i] : 0.0f, v3(0, 0, 0)};
@@ -780,7 +804,7 @@ struct OpXsph {
         }
     };
     static constexpr int kQuadBit = kQuadXsph;
-    template <bool QUAD = false>
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float mRef = valid ? c.posm[i].w : 0.0f;

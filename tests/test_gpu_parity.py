@@ -126,15 +126,20 @@ def test_trajectory_bit_exact_disordered(sphx, oracle, solver):
 
 
 @pytest.mark.parametrize("solver", [0, 1, 2])
-@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (4, None), (5, None), (0, "8"), (4, "8"), (16, None), (0, "quad-all"), (0, "quad-all-8")])
+@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (4, None), (5, None), (0, "8"), (4, "8"), (16, None), (0, "quad-all"), (0, "quad-all-8"), (0, "duo-all"), (0, "duo-all-8")])
 def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
     """the fused/unfused schedules (bit 0), the neighbour-list vs direct 27-cell walks (bit 1), the
     LDS-staged tiles vs global gathers (bit 2 = on), the per-lane overflow fallback of the list (tiny
-    capacity), lane-per-particle walks only (bit 4) and quad-per-particle walks in EVERY sweep that has the variant
-    (SPHX_QUAD_MASK; the default switches it on for the DFSPH rate sweeps only) all produce the oracle's bits."""
+    capacity), lane-per-particle walks only (bit 4), quad-per-particle walks in EVERY sweep that has the variant
+    (SPHX_QUAD_MASK; the default switches it on for the DFSPH rate sweeps only) and two-lanes-per-particle walks
+    (SPHX_DUO_MASK; off by default) all produce the oracle's bits."""
     if cap and cap.startswith("quad-all"):
         monkeypatch.setenv("SPHX_QUAD_MASK", "255")
         cap = cap[9:] or None
+    if cap and cap.startswith("duo-all"):        # two lanes per particle in every sweep that has the variant
+        monkeypatch.setenv("SPHX_QUAD_MASK", "0")
+        monkeypatch.setenv("SPHX_DUO_MASK", "255")
+        cap = cap[8:] or None
     if cap:
         monkeypatch.setenv("SPHX_NBR_CAP", cap)
     P, fluid, boundary = sphx.scene(12)
