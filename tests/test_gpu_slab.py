@@ -133,7 +133,7 @@ def _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, li
 
 
 @pytest.mark.parametrize("world,solver,adaptive,rebalance", [(2, "dfsph", False, False), (3, "dfsph", True, True), (4, "wcsph", False, True),
-                                                             (3, "pbd", False, True)])
+                                                             (3, "pbd", False, True), (8, "dfsph", True, True)])
 def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world, solver, adaptive, rebalance):
     """the RCCL transport as bench.py --gpus N drives it — one process per slab, every neighbour remote, the token
     handed over a side channel, grouped ncclSend/ncclRecv on the communication stream, ncclAllReduce of the adaptive
@@ -143,7 +143,7 @@ def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world,
     import os
     library = os.path.join(slab_worker.ROOT, "tests", "libmock_rccl.so")
     assert os.path.exists(library), "tests/libmock_rccl.so is built by __graft_entry__.build() (make -C tests)"
-    nx, steps, seed = 16, 7, 31
+    nx, steps, seed = (32 if world == 8 else 16), 7, 31          # 8 ranks: the shape of the driver's --gpus 8 run
     parts = _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, library)
     ids = np.concatenate([p["ids"] for p in parts])
     assert np.array_equal(np.sort(ids), np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
@@ -154,7 +154,7 @@ def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world,
     assert_bit_equal(np.concatenate([p["density"] for p in parts])[order], rd, "rccl ranks density")
     if solver == "dfsph":
         assert all(tuple(p["iters"]) == rit for p in parts)
-    if rebalance:
+    if rebalance and world < 8:        # (8 narrow slabs: the rule's minimum width keeps the cuts where they are)
         assert any(int(p["distinct_cuts"]) > 1 for p in parts), "the cuts must have moved"
 
 
