@@ -659,6 +659,38 @@ int sphx_slab_rccl_unique_id(char id128[128])
     });
 }
 
+// The decomposition of a scene: cut planes and the particle capacity every slab's engine is created with.
+// capacity: twice the most particles any slab HOLDS at the start (owned + ghost columns, plus two columns: a cut may
+// move towards it on either side) — the fluid piles up against a wall while the cuts follow it with a delay — but never
+// more than the whole scene plus its ghost copies.  ~560 B of HBM per slot.  Pure host arithmetic on the global scene,
+// so every rank arrives at the same numbers.
+struct SlabPlan { std::vector<int> cuts; std::vector<long long> owned; long long capacity = 0; };
+static SlabPlan plan_slabs(const sphx_params& P, const float* fluid_xyz, int n_fluid, int world)
+{
+    const int gx = P.cells[0];
+    const int ghost = P.solver == SPHX_PBD ? 2 : 1;
+    // columns by the engine's expression on the host (IEEE division, truncation)
+    auto column_of = [&](float x) { volatile float q = x / P.cell_length; return (int)q; };
+    std::vector<int> col((size_t)n_fluid);
+    for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
+    SlabPlan plan;
+    plan.cuts = choose_cuts(col, gx, world, ghost + 1);
+    std::vector<long long> perColumn((size_t)std::max(gx, 1), 0);
+    for (int c : col) if (c >= 0 && c < gx) perColumn[c]++;
+    plan.owned.assign((size_t)world, 0);
+    long long most = 0;
+    for (int r = 0; r < world; ++r) {
+        long long heldHere = 0;
+        for (int x = std::max(plan.cuts[r] - ghost, 0); x < std::min(plan.cuts[r + 1] + ghost, gx); ++x) heldHere += perColumn[x];
+        for (int x = std::max(plan.cuts[r], 0); x < std::min(plan.cuts[r + 1], gx); ++x) plan.owned[r] += perColumn[x];
+        most = std::max(most, heldHere);
+    }
+    const long long densestColumn = *std::max_element(perColumn.begin(), perColumn.end());
+    most += 2 * densestColumn;
+    plan.capacity = std::min<long long>(std::min<long long>(2 * most, (long long)n_fluid + 4LL * ghost * densestColumn) + 4096, 2000000000LL);
+    return plan;
+}
+
 int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const float* fluid_vel, int n_fluid,
                      const float* boundary_xyz, int n_boundary, int world, int first_rank, int local_ranks,
                      const char* rccl_id128, int flags, sphx_slab_group** out)
@@ -682,24 +714,9 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         if (rccl_id128) G->transport.reset(new RcclTransport(first_rank, world, rccl_id128));
         else G->transport.reset(new LoopbackTransport());
 
-        // columns by the engine's expression on the host (IEEE division, truncation)
+        const SlabPlan plan = plan_slabs(P, fluid_xyz, n_fluid, world);
+        const std::vector<int>& cuts = plan.cuts;
         auto column_of = [&](float x) { volatile float q = x / P.cell_length; return (int)q; };
-        std::vector<int> col((size_t)n_fluid);
-        for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
-        const std::vector<int> cuts = choose_cuts(col, gx, world, ghost + 1);
-        // capacity of every slab: twice the most particles any slab HOLDS at the start (owned + ghost columns, plus two
-        // columns: a cut may move towards it on either side) — the fluid piles up against a wall while the cuts follow
-        // it with a delay — but never more than the whole scene plus its ghost copies.  ~560 B of HBM per slot.
-        std::vector<long long> perColumn((size_t)gx, 0);
-        for (int c : col) if (c >= 0 && c < gx) perColumn[c]++;
-        long long most = 0;
-        for (int r = 0; r < world; ++r) {
-            long long heldHere = 0;
-            for (int x = std::max(cuts[r] - ghost, 0); x < std::min(cuts[r + 1] + ghost, gx); ++x) heldHere += perColumn[x];
-            most = std::max(most, heldHere);
-        }
-        const long long densestColumn = gx > 0 ? *std::max_element(perColumn.begin(), perColumn.end()) : 0;
-        most += 2 * densestColumn;
 
         for (int r = first_rank; r < first_rank + local_ranks; ++r) {
             std::unique_ptr<Slab> S(new Slab());
@@ -708,7 +725,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             s.cellsPerColumn = gy * gz; s.gx = gx; s.cellLength = P.cell_length;
             s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
             s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
-            s.capacity = (int)std::min<long long>(std::min<long long>(2 * most, (long long)n_fluid + 4LL * ghost * densestColumn) + 4096, 2000000000LL);
+            s.capacity = (int)plan.capacity;
             // The slab's engine works on the WHOLE grid (cell tables are a few tens of MB even at 10 M particles) and
             // holds the whole boundary set, whose masses it computes like any system (SPHSystem.cu:69-71): only the
             // particles it is handed are local.  Cut planes are then just two numbers of this driver and may move.
@@ -735,12 +752,14 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             hip_ok(hipHostMalloc((void**)&s.hInts, 8 * sizeof(int), hipHostMallocDefault), "pinned ints");
             // initial distribution: this slab's particles in generation order, ids = global generation index
             std::vector<float> p0, v0; std::vector<int> id0;
-            for (int i = 0; i < n_fluid; ++i)
-                if (col[i] >= s.x0 && col[i] < s.x1) {
+            for (int i = 0; i < n_fluid; ++i) {
+                const int ci = column_of(fluid_xyz[3 * (size_t)i]);
+                if (ci >= s.x0 && ci < s.x1) {
                     p0.insert(p0.end(), {fluid_xyz[3 * (size_t)i], fluid_xyz[3 * (size_t)i + 1], fluid_xyz[3 * (size_t)i + 2]});
                     if (fluid_vel) v0.insert(v0.end(), {fluid_vel[3 * (size_t)i], fluid_vel[3 * (size_t)i + 1], fluid_vel[3 * (size_t)i + 2]});
                     id0.push_back(i);
                 }
+            }
             const int m = (int)id0.size();
             if (m > s.capacity) die("slab: capacity too small for the initial distribution");
             hipStream_t st = sphx::stream();
@@ -824,16 +843,18 @@ int sphx_slab_plan_cuts(const sphx_params* params, const float* fluid_xyz, int n
 {
     if (!params || (n_fluid && !fluid_xyz) || n_fluid < 0 || world < 1 || !cuts) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_plan_cuts: bad argument");
     return slab_guarded("sphx_slab_plan_cuts", [&] {
-        auto column_of = [&](float x) { volatile float q = x / params->cell_length; return (int)q; };
-        std::vector<int> col((size_t)n_fluid);
-        for (int i = 0; i < n_fluid; ++i) col[i] = column_of(fluid_xyz[3 * (size_t)i]);
-        const int ghost = params->solver == SPHX_PBD ? 2 : 1;
-        const std::vector<int> c = choose_cuts(col, params->cells[0], world, ghost + 1);
-        for (int r = 0; r <= world; ++r) cuts[r] = c[r];
-        if (counts) {
-            for (int r = 0; r < world; ++r) counts[r] = 0;
-            for (int x : col) { int r = 0; while (r + 1 < world && x >= c[r + 1]) ++r; if (x >= 0 && x < params->cells[0]) counts[r]++; }
-        }
+        const SlabPlan plan = plan_slabs(*params, fluid_xyz, n_fluid, world);
+        for (int r = 0; r <= world; ++r) cuts[r] = plan.cuts[r];
+        if (counts) for (int r = 0; r < world; ++r) counts[r] = plan.owned[r];
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_slab_plan_capacity(const sphx_params* params, const float* fluid_xyz, int n_fluid, int world, long long* capacity)
+{
+    if (!params || (n_fluid && !fluid_xyz) || n_fluid < 0 || world < 1 || !capacity) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_plan_capacity: bad argument");
+    return slab_guarded("sphx_slab_plan_capacity", [&] {
+        *capacity = plan_slabs(*params, fluid_xyz, n_fluid, world).capacity;
         return (int)SPHX_OK;
     });
 }

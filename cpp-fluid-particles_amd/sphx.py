@@ -268,7 +268,7 @@ def sample_triangles(tri, spacing):
 SLAB_NO_OVERLAP, SLAB_SWEEP_GHOSTS = 1, 2
 SLAB_EXPORTS = ["sphx_slab_rccl_unique_id", "sphx_slab_create", "sphx_slab_destroy", "sphx_slab_step", "sphx_slab_info",
                 "sphx_slab_gather", "sphx_slab_iters", "sphx_slab_system", "sphx_slab_wait_seconds", "sphx_slab_set_rebalance",
-                "sphx_slab_plan_cuts", "sphx_slab_cut_rule"]
+                "sphx_slab_plan_cuts", "sphx_slab_plan_capacity", "sphx_slab_cut_rule"]
 
 
 def slab_plan_cuts(params, fluid, world):
@@ -279,6 +279,16 @@ def slab_plan_cuts(params, fluid, world):
     f.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _check(f(C.byref(params), fluid.ctypes.data, len(fluid), world, cuts, counts))
     return list(cuts), list(counts)
+
+
+def slab_plan_capacity(params, fluid, world):
+    """particle capacity of every slab's engine for this scene and slab count (host-only, no GPU needed)"""
+    fluid = np.ascontiguousarray(fluid, np.float32).reshape(-1, 3)
+    cap = C.c_longlong()
+    f = lib().sphx_slab_plan_capacity
+    f.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    _check(f(C.byref(params), fluid.ctypes.data, len(fluid), world, C.byref(cap)))
+    return cap.value
 
 
 def slab_cut_rule(owned_left, owned_right, width_left, width_right, ghost=1, tolerance=0.05):

@@ -66,6 +66,10 @@ int sphx_slab_set_rebalance(sphx_slab_group *g, int every_steps, float tolerance
  * re-balancing rule both neighbours of a cut evaluate: -1 = the left slab hands its last column to the right one,
  * +1 = the opposite, 0 = stay.                                                                          */
 int sphx_slab_plan_cuts(const sphx_params *params, const float *fluid_xyz, int n_fluid, int world, int *cuts, long long *counts);
+/* ... and the particle capacity each slab's engine would be created with (the same on every rank): twice the most
+ * particles a slab holds at the start (owned + ghost columns + two columns of head-room for a moving cut), at most the
+ * whole scene.  A slab that outgrows it makes sphx_slab_step fail with SPHX_ERR_STATE.                       */
+int sphx_slab_plan_capacity(const sphx_params *params, const float *fluid_xyz, int n_fluid, int world, long long *capacity);
 int sphx_slab_cut_rule(long long owned_left, long long owned_right, int width_left, int width_right, int ghost, float tolerance);
 
 /* geometry and sizes of local slab `index`: owned cell columns [x0, x1), particles owned / held incl. ghosts */

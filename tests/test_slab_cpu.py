@@ -67,6 +67,29 @@ def test_cut_planes_balance_and_width():
         M.choose_cuts(cols, 5, 4)
 
 
+def test_native_layer_slab_capacity_covers_ghosts_and_moving_cuts(sphx):
+    """every slab's engine is created with room for what the slab HOLDS (owned + ghost columns), for the columns a
+    moving cut can hand it, and for the fluid piling up — the r02 sizing from the owned count alone failed at
+    BASELINE config 3's size over 8 slabs (5.5 columns per slab: ghosts are 36 % on top)"""
+    import multi_gpu as M
+    for nx, world, solver in ((88, 8, sphx.DFSPH), (88, 2, sphx.DFSPH), (40, 5, sphx.PBD), (24, 1, sphx.WCSPH)):
+        P, fluid, _ = sphx.scene(nx)
+        P.solver = solver
+        n = len(fluid)
+        cap = sphx.slab_plan_capacity(P, fluid, world)
+        cuts, counts = sphx.slab_plan_cuts(P, fluid, world)
+        ghost = 2 if solver == sphx.PBD else 1
+        col = M.cell_column(fluid[:, 0], P.cell_length)
+        per_column = np.bincount(col, minlength=P.cells[0])
+        held = [int(per_column[max(a - ghost, 0):min(b + ghost, P.cells[0])].sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert [int(per_column[a:b].sum()) for a, b in zip(cuts[:-1], cuts[1:])] == counts
+        # a cut moving by one column on either side, then 25 % more particles in the same columns
+        assert cap >= 1.25 * (max(held) + 2 * int(per_column.max())) or cap >= n
+        assert cap <= n + 4 * ghost * int(per_column.max()) + 4096        # never more than the scene plus its ghost copies
+        if world == 1:
+            assert cap >= n
+
+
 def test_native_layer_cut_planning_matches_protocol_driver(sphx):
     """host-side pieces of the native slab layer (csrc/slab.hip) that need no GPU: its initial cuts equal the ones the
     Python protocol driver chooses, and the re-balancing rule is consistent from both sides of a cut"""
