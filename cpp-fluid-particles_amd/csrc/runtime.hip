@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
                                                            float4* posBuild, int* rowCell, const int* flagNow, int* flagNext, int* rebuilds)
 {
     __shared__ float4 pos[STREAM ? kWideBlock / kTile : 1][STREAM ? kGroupSlots : 1];
-    __shared__ unsigned int stage[STREAM ? 1 : kWideBlock / kTile][STREAM ? 1 : kRowStage * kTile];
+    __shared__ unsigned int stage[(STREAM || SPHX_BUILD_REGSTAGE) ? 1 : kWideBlock / kTile][(STREAM || SPHX_BUILD_REGSTAGE) ? 1 : kRowStage * kTile];
     if (flagNext && blockIdx.x == 0 && threadIdx.x == 0) {
         *flagNext = 0;
         if (rebuilds && *flagNow != 0) *rebuilds += 1;      // diagnostics: conditional rebuilds since creation
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
         if ((threadIdx.x & 63) == 0) tileFmt[i >> 6] = streamed ? 2 : 0;
     }
     build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n,
-                        STREAM ? nullptr : stage[threadIdx.x >> 6]);
+                        (STREAM || SPHX_BUILD_REGSTAGE) ? nullptr : stage[threadIdx.x >> 6]);
     if (posBuild && i < c.n) {
         const float4 p = c.posm[i];
         posBuild[i] = p;

@@ -1075,12 +1075,23 @@ __device__ __forceinline__ void sweep_duo(const Op& op, const SweepCtx& c, const
 #endif
 constexpr int kBuildAhead = SPHX_BUILD_AHEAD;
 constexpr int kRowStage = 32;      // entries per lane staged in LDS by the row builder (longer rows continue in global memory)
-__device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage, unsigned int* row, int lane, int cnt, unsigned int e)
+#ifndef SPHX_BUILD_REGSTAGE
+#define SPHX_BUILD_REGSTAGE 1      // a lane collects 4 entries in registers and stores its own 16-byte chunks; 0: rows staged in LDS,
+                                   // one KB per chunk and tile stored at the end (2 % slower at 10 M, 13 % at 263 k: LDS caps the occupancy at 5)
+#endif
+__device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage, unsigned int* row, int lane, int cnt, unsigned int e,
+                                          uint4& pend)
 {
+    if (SPHX_BUILD_REGSTAGE && !stage) {
+        const int w = cnt & 3;
+        pend.x = w == 0 ? e : pend.x; pend.y = w == 1 ? e : pend.y; pend.z = w == 2 ? e : pend.z; pend.w = w == 3 ? e : pend.w;
+        if (w == 3 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+        return;
+    }
     if (stage && cnt < kRowStage) stage[cnt * 64 + lane] = e;
     else if (cnt < c.cap) row[row_entry_offset(cnt)] = e;
 }
-// `stage`: this wave's LDS staging area of kRowStage x 64 entries (or nullptr).  A lane appends at its own count, so
+// `stage`: this wave's LDS staging area of kRowStage x 64 entries (SPHX_BUILD_REGSTAGE = 0), or nullptr.  A lane appends at its own count, so
 // written straight to the wave-interleaved global layout the 64 lanes touch 64 different 256-byte lines at any
 // moment and every line is completed by 64 separate 4-byte stores spread over the whole walk (measured: 4.2x write
 // amplification at 10 M particles).  Staged, the rows are written once at the end, one full line per entry index.
@@ -1093,6 +1104,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     const float3 pi = v3(self.x, self.y, self.z);
     unsigned int* row = nbr + row_base_offset(i, c.cap);
     int cnt = 0;
+    uint4 pend = make_uint4(0u, 0u, 0u, 0u);          // register-staged chunk (SPHX_BUILD_REGSTAGE)
     const int3 c0 = cell_of(pi, c.g);
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
     WaveRanges w; w.start = w.len = w.off = 0; w.ok = false;
@@ -1146,7 +1158,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                             const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
                             const float r2 = dot3(d, d);
                             if (r2 > c.buildCut || j + u == i) continue;
-                            put_entry(c, stage, row, lane, cnt, (unsigned int)(j + u + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u));
+                            put_entry(c, stage, row, lane, cnt, (unsigned int)(j + u + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u), pend);
                             ++cnt;
                         }
                     }
@@ -1155,7 +1167,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                         const float r2 = dot3(d, d);
                         if (r2 > c.buildCut || j == i) continue;
-                        put_entry(c, stage, row, lane, cnt, (unsigned int)(j + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u));
+                        put_entry(c, stage, row, lane, cnt, (unsigned int)(j + fShift) | fTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u), pend);
                         ++cnt;
                     }
                     if (!noWall) {
@@ -1165,7 +1177,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
                             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
                             const float r2 = dot3(d, d);
                             if (r2 > c.buildCut) continue;
-                            put_entry(c, stage, row, lane, cnt, (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u));   // bShift: + bOff (fmt 0)
+                            put_entry(c, stage, row, lane, cnt, (unsigned int)(j + bShift) | bTag | (pair_needs_plain_ops(d, r2) ? plainBit : 0u), pend);   // bShift: + bOff (fmt 0)
                             ++cnt;
                         }
                     }
@@ -1175,6 +1187,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
         if (streamed) wave_lds_fence();
     }
     if (valid) nbrCount[i] = cnt;
+    if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
     if (stage) {                                  // one coalesced 1 KB store per chunk index (slots past a row's end hold
         wave_lds_fence();                         // stale stage contents: readers never look past nbrCount)
         int top = valid ? min(min(cnt, c.cap), kRowStage) : 0;
