@@ -137,7 +137,7 @@ def _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, li
 def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world, solver, adaptive, rebalance):
     """the RCCL transport as bench.py --gpus N drives it — one process per slab, every neighbour remote, the token
     handed over a side channel, grouped ncclSend/ncclRecv on the communication stream, ncclAllReduce of the adaptive
-    sum, cuts moving while particles migrate — with 2-4 ranks.  The box has one GPU and the real RCCL refuses two
+    sum, cuts moving while particles migrate — with 2, 3, 4 and 8 ranks.  The box has one GPU and the real RCCL refuses two
     ranks on one device, so the nine RCCL calls are served by tests/mock_rccl.cpp (same matching rules, size
     mismatches and unmatched messages are errors); everything above those calls is the shipped code."""
     import os
