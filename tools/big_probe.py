@@ -6,9 +6,11 @@ for nx in [int(a) for a in sys.argv[1].split(",")]:
     for flags in [int(a) for a in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]:
         P, fluid, boundary = sphx.scene(nx)
         P.solver = sphx.WCSPH; P.dt = 0.001; P.reserved[0] = flags
+        free0 = torch.cuda.mem_get_info()[0]
         t = time.time(); s = sphx.System(P, fluid, boundary); tc = time.time() - t
         t = time.time(); s.step(); ts = time.time() - t
         tot, mx, h = s.row_stats()
+        used = free0 - torch.cuda.mem_get_info()[0]
         d = s.get(sphx.F_DENSITY)
-        print("nx %d flags %d: n %d create %.3f s step %.1f ms rows: pairs %d longest %d density %.4f..%.4f" % (nx, flags, len(fluid), tc, ts * 1e3, tot, mx, d.min(), d.max()), flush=True)
+        print("nx %d flags %d: n %d create %.3f s step %.1f ms rows: pairs %d longest %d density %.4f..%.4f device memory %.2f GB = %.0f B/particle" % (nx, flags, len(fluid), tc, ts * 1e3, tot, mx, d.min(), d.max(), used / 1e9, used / len(fluid)), flush=True)
         s.close()

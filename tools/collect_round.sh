@@ -13,6 +13,6 @@ for s in 1 8; do python bench.py --force-slab --slabs $s --steps 20 2>/dev/null 
 python tools/settle_probe.py 190 300 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_fixed14.txt
 python tools/settle_probe.py 190 350 -1 -1 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_adaptive.txt
 python tools/settle_probe.py 88 450 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_88_fixed14.txt
-python tools/big_probe.py 190,320,400 0 2>/dev/null | grep -v amdgpu > gpurun_out/big_${TAG}.txt
+python tools/big_probe.py 190,320,400 0 2>/dev/null | grep "^nx" > gpurun_out/big_${TAG}.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -v "PBD:\|amdgpu\|Could not read\|iommu" | tail -4 > gpurun_out/pytest_gpu_tail_$TAG.txt
 cat gpurun_out/pytest_gpu_tail_$TAG.txt; cat gpurun_out/pcie_$TAG.txt; grep "ms/step" gpurun_out/probe_$TAG.txt
