@@ -64,6 +64,7 @@ def lib():
         L.oracle_scene_fill.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_eval_kernels.argtypes = [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_w_promote.argtypes = [C.c_int]
         L.oracle_run_phase.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_count.argtypes = [C.c_void_p, C.c_int]
         L.oracle_error_total_fixed.restype = C.c_longlong
@@ -71,6 +72,11 @@ def lib():
         assert L.oracle_sizeof_params() == C.sizeof(Params)
         _lib = L
     return _lib
+
+
+def set_w_promote(on):
+    """Diagnostic arithmetic of a g++ host compile of the reference text (see sph_oracle.c, g_w_promote)."""
+    lib().oracle_set_w_promote(int(bool(on)))
 
 
 def scene(nx):

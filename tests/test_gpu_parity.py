@@ -739,3 +739,62 @@ def test_generate_dots_colour_ramp(sphx):
             w = min((r * r - np.float32(1.0)) * np.float32(4.0), np.float32(1.0))
             want[i] = (np.float32(1) - w) * foam + w * dense
     assert np.allclose(col.cpu().numpy(), want, rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Through the landing of the column on the reference scene: wall clamps, boundary contributions, the divergence-error
+# clamp, adaptive DFSPH running into maxIter = 20.  (The short trajectory tests above end in free fall.)
+def _anchor_states(name):
+    import json, os
+    V = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "refsrc_anchors.json")))["variants"]["float_fabs"][name]
+    return V["dt"], {st["step"]: st for st in V["states"]}
+
+
+def _crc_in_particle_order(sphx, gs, field):
+    import zlib
+    ids = gs.get(sphx.F_ID)
+    a = gs.get(field); b = np.empty_like(a); b[ids] = a
+    return zlib.crc32(b.tobytes())
+
+
+def test_reference_source_anchor_dfsph_on_gpu(sphx):
+    """The ENGINE (no oracle in the loop) against tests/golden/refsrc_anchors.json: CRC-32 of the complete pos / vel /
+    density arrays and the iteration counts of the reference's own sources (compiled on CPU, see tests/golden/README.md) on
+    the reference scene, adaptive DFSPH, every 10 steps up to step 100 = through the landing, iterations up to (20,2)."""
+    dt, states = _anchor_states("dfsph")
+    P, fluid, boundary = sphx.scene(24)
+    P.solver = sphx.DFSPH; P.dt = dt
+    gs = sphx.System(P, fluid, boundary)
+    for step in range(0, 101):
+        if step:
+            gs.step()
+        st = states.get(step)
+        if st:
+            for f, k in ((sphx.F_POS, "crc32_pos"), (sphx.F_VEL, "crc32_vel"), (sphx.F_DENSITY, "crc32_density")):
+                assert _crc_in_particle_order(sphx, gs, f) == st[k], "step %d: %s differs from the reference-source run" % (step, k)
+            assert list(gs.iters()) == st["iters_div_den"], (step, gs.iters())
+    assert gs.iters() == (20, 2)
+
+
+@pytest.mark.parametrize("solver,dt,first,last", [(0, 0.001, 120, 200), (1, 0.002, 50, 100), (2, 0.002, 50, 80)])
+def test_trajectory_bit_exact_through_landing(sphx, oracle, solver, dt, first, last):
+    """reference scene, default solver settings (adaptive DFSPH, PBD k = 20): every field bit-identical to the oracle at
+    steps first..last (every 5th), which bracket the landing (WCSPH ~140 at dt = 0.001; DFSPH / PBD ~60 at dt = 0.002)"""
+    def tweak(P):
+        P.dt = dt
+    gs, os_, _ = make_pair(sphx, oracle, 24, solver, tweak=tweak)
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else []) + (FIELDS_PBD if solver == 2 else [])
+    its = set()
+    for s in range(1, last + 1):
+        gs.step(); os_.step()
+        if s >= first and (s % 5 == 0 or s == last):
+            compare(sphx, oracle, gs, os_, names, "landing solver %d step %d" % (solver, s))
+        if solver == 1:
+            assert gs.iters() == os_.iters(), s
+            its.add(gs.iters())
+    den = gs.get(sphx.F_DENSITY)
+    assert den.max() > 0.99, "the column must have landed (densities near rho0)"
+    if solver == 1:
+        assert (20, 2) in its and (1, 2) in its, "adaptive control must have been exercised up to maxIter"
+    if solver == 0:
+        assert gs.get(sphx.F_PRESSURE).max() > 0, "Tait pressures must be active"

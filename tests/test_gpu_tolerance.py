@@ -48,6 +48,44 @@ def test_tolerance_trajectory_within_1e5_of_oracle(sphx, oracle, solver, steps, 
     assert worst_p > 0.0 or worst_d > 0.0, "the tolerance path must actually differ from the strict one"
 
 
+def restart_pair(sphx, oracle, solver, dt, k0, fixed=True):
+    """run the strict ORACLE k0 steps on the reference scene (pre-impact), then start a tolerance-mode engine and a fresh
+    oracle from that identical state (positions, velocities, DFSPH warm-start stiffness, PBD last positions)"""
+    P, fluid, boundary = sphx.scene(24)
+    P.solver = solver; P.dt = dt; P.pbd_iters = 5
+    if fixed:
+        P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    Po = same_params(oracle.Params(), P)
+    o = oracle.System(Po, fluid, boundary)
+    for _ in range(k0):
+        o.step()
+    pos, vel = o.get(oracle.F_POS), o.get(oracle.F_VEL)
+    extra = {1: [("F_WARM", o.get(oracle.F_WARM))], 2: [("F_POS_LAST", o.get(oracle.F_POS_LAST))]}.get(solver, [])
+    o.close()
+    Q = P.copy(); Q.reserved[3] = 1
+    g = sphx.System(Q, pos, boundary, ctor_step=False)
+    o2 = oracle.System(Po, pos, boundary, ctor_step=False)
+    ids = g.get(sphx.F_ID)
+    assert np.array_equal(ids, o2.get(oracle.F_ID))
+    g.set(sphx.F_VEL, vel[ids]); o2.set(oracle.F_VEL, vel[ids])
+    for name, arr in extra:
+        g.set(getattr(sphx, name), arr[ids]); o2.set(getattr(oracle, name), arr[ids])
+    return g, o2, P
+
+
+def deviations(sphx, oracle, g, o, P):
+    """scaled: max|d| / (domain size | rho0).  elementwise: max |d| / max(|reference|, floor) with floor = 1 % of the
+    field's scale (domain size | rho0) -- the north star's "1e-5 relative", with an absolute floor for values near 0."""
+    out = {}
+    for nm, fg, fo, scale in (("pos", sphx.F_POS, oracle.F_POS, P.space[0]), ("rho", sphx.F_DENSITY, oracle.F_DENSITY, P.rho0)):
+        a = g.get(fg).astype(np.float64); b = o.get(fo).astype(np.float64)
+        d = np.abs(a - b)
+        out[nm + "_scaled"] = float(d.max() / scale)
+        out[nm + "_elem"] = float((d / np.maximum(np.abs(b), 0.01 * scale)).max())
+    out["cells_differ"] = float(np.count_nonzero(g.get(sphx.F_CELL) != o.get(oracle.F_CELL)))
+    return out
+
+
 @pytest.mark.parametrize("solver", [0, 1, 2])
 def test_tolerance_one_step_fields_close_to_strict(sphx, solver):
     """one step from an identical disordered state, strict vs tolerance engine: every per-particle output within
