@@ -4,7 +4,7 @@ itself — particle exchange, halo schedule, adaptive termination — runs under
 import numpy as np
 import torch
 
-from multi_gpu import cell_column
+from slab_protocol import cell_column
 
 
 class OracleSlabEngine:

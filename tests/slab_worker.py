@@ -40,7 +40,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    import multi_gpu as M
+    import slab_protocol as M
     from slab_cpu_engine import OracleSlabEngine
     if engine_kind == "oracle":
         from oracle import oracle as E

@@ -229,3 +229,54 @@ def test_native_slab_layer_config3_size_matches_single_system(sphx):
     assert owned == len(fluid) and held > owned
     assert np.array_equal(ids, np.arange(len(fluid), dtype=np.int32))
     assert_bit_equal(p, rp, "8 slabs pos"); assert_bit_equal(v, rv, "8 slabs vel"); assert_bit_equal(d, rd, "8 slabs density")
+
+
+def test_native_slab_layer_config5_form_matches_single_system(sphx):
+    """BASELINE config 5 in its own form: 10,288,500 particles (nx = 190), DFSPH v=1 d=4, EIGHT x-slabs (loopback: the box
+    has one GPU) with the cuts re-balanced every step -- bit-identical to the plain single-device 10 M system after 3 steps.
+    Partition rule = the engine's cell-column expression (CUDAFunctions.cuh:64-70)."""
+    P, fluid, boundary = sphx.scene(190)
+    P.solver = sphx.DFSPH; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    steps = 3
+    ref = sphx.System(P, fluid, boundary)            # constructor step = step 1
+    ref.step_n(steps - 1)
+    order = np.argsort(ref.get(sphx.F_ID))
+    rp, rv, rd = ref.get(sphx.F_POS)[order], ref.get(sphx.F_VEL)[order], ref.get(sphx.F_DENSITY)[order]
+    ref.close()
+    g = sphx.SlabGroup(P, fluid, boundary, 8)
+    g.set_rebalance(1, 0.0)
+    cuts = set()
+    for _ in range(steps):
+        g.step(1)
+        cuts.add(tuple(g.info(i)[:2] for i in range(8)))
+    ids, p, v, d = g.gather_all()
+    owned = [g.info(i)[2] for i in range(8)]; held = [g.info(i)[3] for i in range(8)]
+    g.close()
+    assert sum(owned) == len(fluid) == 10288500 and all(h > o for h, o in zip(held, owned))
+    assert max(owned) < 1.25 * min(owned), "the cuts balance the slabs: %s" % owned
+    assert np.array_equal(ids, np.arange(len(fluid), dtype=np.int32))
+    assert_bit_equal(p, rp, "config 5, 8 slabs pos"); assert_bit_equal(v, rv, "config 5, 8 slabs vel"); assert_bit_equal(d, rd, "config 5, 8 slabs density")
+
+
+def test_native_slab_layer_rccl_transport_8_ranks_1m(sphx, tmp_path):
+    """the 8-process RCCL-transport run (stand-in library, see above) at BASELINE config 3's size, nx = 88: 1,022,208
+    particles of a disordered splash, DFSPH fixed iterations, cuts moving every step; equals the single-device ENGINE
+    (itself oracle-identical) bit for bit"""
+    import os
+    library = os.path.join(slab_worker.ROOT, "tests", "libmock_rccl.so")
+    nx, steps, seed, solver = 88, 4, 53, "dfsph"
+    parts = _run_ranks(tmp_path, 8, nx, steps, seed, solver, False, True, library)
+    ids = np.concatenate([p["ids"] for p in parts])
+    assert np.array_equal(np.sort(ids), np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    order = np.argsort(ids)
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, False)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    s = sphx.System(P, pos, boundary, ctor_step=False)
+    s.set(sphx.F_VEL, vel[s.get(sphx.F_ID)])
+    for _ in range(steps):
+        s.step()
+    o = np.argsort(s.get(sphx.F_ID))
+    assert_bit_equal(np.concatenate([p["pos"] for p in parts])[order], s.get(sphx.F_POS)[o], "8 ranks 1M pos")
+    assert_bit_equal(np.concatenate([p["vel"] for p in parts])[order], s.get(sphx.F_VEL)[o], "8 ranks 1M vel")
+    assert_bit_equal(np.concatenate([p["density"] for p in parts])[order], s.get(sphx.F_DENSITY)[o], "8 ranks 1M density")

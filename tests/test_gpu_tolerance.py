@@ -48,7 +48,7 @@ def test_tolerance_trajectory_within_1e5_of_oracle(sphx, oracle, solver, steps, 
     assert worst_p > 0.0 or worst_d > 0.0, "the tolerance path must actually differ from the strict one"
 
 
-def restart_pair(sphx, oracle, solver, dt, k0, fixed=True):
+def restart_pair(sphx, oracle, solver, dt, k0, fixed=True, perturbed=False):
     """run the strict ORACLE k0 steps on the reference scene (pre-impact), then start a tolerance-mode engine and a fresh
     oracle from that identical state (positions, velocities, DFSPH warm-start stiffness, PBD last positions)"""
     P, fluid, boundary = sphx.scene(24)
@@ -70,7 +70,34 @@ def restart_pair(sphx, oracle, solver, dt, k0, fixed=True):
     g.set(sphx.F_VEL, vel[ids]); o2.set(oracle.F_VEL, vel[ids])
     for name, arr in extra:
         g.set(getattr(sphx, name), arr[ids]); o2.set(getattr(oracle, name), arr[ids])
-    return g, o2, P
+    if not perturbed:
+        return g, o2, P
+    # control: the STRICT engine from the same state with half of the position components moved by ONE ulp
+    rng = np.random.default_rng(k0)
+    pos1 = np.where(rng.random(pos.shape) < 0.5, np.nextafter(pos, np.float32(2)), pos).astype(np.float32)
+    gp = sphx.System(P, pos1, boundary, ctor_step=False)
+    assert np.array_equal(gp.get(sphx.F_ID), ids)
+    gp.set(sphx.F_VEL, vel[ids])
+    for name, arr in extra:
+        gp.set(getattr(sphx, name), arr[ids])
+    return g, o2, P, gp
+
+
+def by_particle(mod, s, field):
+    ids = s.get(mod.F_ID)
+    a = s.get(field); b = np.empty_like(a); b[ids] = a
+    return b.astype(np.float64)
+
+
+def deviations_by_particle(sphx, oracle, g, gmod, o, P):
+    """as deviations(), but matched by particle id (valid after the sort orders of the two runs part)"""
+    out = {}
+    for nm, fname, scale in (("pos", "F_POS", P.space[0]), ("rho", "F_DENSITY", P.rho0)):
+        a = by_particle(gmod, g, getattr(gmod, fname)); b = by_particle(oracle, o, getattr(oracle, fname))
+        d = np.abs(a - b)
+        out[nm + "_scaled"] = float(d.max() / scale)
+        out[nm + "_elem"] = float((d / np.maximum(np.abs(b), 0.01 * scale)).max())
+    return out
 
 
 def deviations(sphx, oracle, g, o, P):
@@ -84,6 +111,34 @@ def deviations(sphx, oracle, g, o, P):
         out[nm + "_elem"] = float((d / np.maximum(np.abs(b), 0.01 * scale)).max())
     out["cells_differ"] = float(np.count_nonzero(g.get(sphx.F_CELL) != o.get(oracle.F_CELL)))
     return out
+
+
+@pytest.mark.parametrize("solver,dt,k0,h_tol,h_env", [(0, 0.001, 125, 15, 40), (1, 0.002, 55, 10, 25), (2, 0.002, 50, 10, 25)])
+def test_tolerance_through_wall_contact(sphx, oracle, solver, dt, k0, h_tol, h_env):
+    """Started from an identical pre-impact state of the reference scene (the oracle's state after k0 steps), through the
+    landing of the column (wall clamps, boundary terms, densities reaching rho0):
+      * for the first h_tol steps every position and density is within 1e-5 of the strict ORACLE element by element
+        (relative to max(|reference value|, 1 % of the field scale)) and cell indices / sort permutations are identical;
+      * beyond that, contact dynamics amplify ANY perturbation by orders of magnitude within tens of steps, so the
+        statement that can hold is the comparative one: up to h_env steps the tolerance engine stays inside 4x the envelope
+        of the STRICT engine started with half of its position components moved by one ulp."""
+    g, o, P, gp = restart_pair(sphx, oracle, solver, dt, k0, perturbed=True)
+    env = {"pos_scaled": 0.0, "rho_scaled": 0.0}
+    landed = False
+    for s in range(1, h_env + 1):
+        g.step(); o.step(); gp.step()
+        d = deviations_by_particle(sphx, oracle, g, sphx, o, P)
+        c = deviations_by_particle(sphx, oracle, gp, sphx, o, P)
+        landed = landed or o.get(oracle.F_DENSITY).max() >= 0.999 * P.rho0
+        if s <= h_tol:
+            assert np.array_equal(g.get(sphx.F_CELL), o.get(oracle.F_CELL)) and np.array_equal(g.get(sphx.F_ID), o.get(oracle.F_ID)), s
+            assert d["pos_elem"] <= TOL and d["rho_elem"] <= TOL, (s, d)
+            assert d["pos_scaled"] <= TOL and d["rho_scaled"] <= TOL, (s, d)
+        for k in env:
+            env[k] = max(env[k], c[k])
+            assert d[k] <= max(TOL, 4.0 * env[k]), "step +%d: %s = %.2e, one-ulp envelope %.2e" % (s, k, d[k], env[k])
+    assert landed, "the horizon must include the landing"
+    assert env["rho_scaled"] > TOL, "the control run must show the amplification this test is about"
 
 
 @pytest.mark.parametrize("solver", [0, 1, 2])

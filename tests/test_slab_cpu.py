@@ -57,7 +57,7 @@ def test_slab_driver_matches_single_domain(oracle, tmp_path, world, solver, adap
 
 
 def test_cut_planes_balance_and_width():
-    import multi_gpu as M
+    import slab_protocol as M
     cols = np.repeat(np.arange(20, 60), 100)
     cuts = M.choose_cuts(cols, 100, 4)
     assert cuts[0] == 0 and cuts[-1] == 100 and all(b - a >= 2 for a, b in zip(cuts[:-1], cuts[1:]))
@@ -71,7 +71,7 @@ def test_native_layer_slab_capacity_covers_ghosts_and_moving_cuts(sphx):
     """every slab's engine is created with room for what the slab HOLDS (owned + ghost columns), for the columns a
     moving cut can hand it, and for the fluid piling up — the r02 sizing from the owned count alone failed at
     BASELINE config 3's size over 8 slabs (5.5 columns per slab: ghosts are 36 % on top)"""
-    import multi_gpu as M
+    import slab_protocol as M
     for nx, world, solver in ((88, 8, sphx.DFSPH), (88, 2, sphx.DFSPH), (40, 5, sphx.PBD), (24, 1, sphx.WCSPH)):
         P, fluid, _ = sphx.scene(nx)
         P.solver = solver
@@ -93,7 +93,7 @@ def test_native_layer_slab_capacity_covers_ghosts_and_moving_cuts(sphx):
 def test_native_layer_cut_planning_matches_protocol_driver(sphx):
     """host-side pieces of the native slab layer (csrc/slab.hip) that need no GPU: its initial cuts equal the ones the
     Python protocol driver chooses, and the re-balancing rule is consistent from both sides of a cut"""
-    import multi_gpu as M
+    import slab_protocol as M
     for nx, world, solver in ((24, 4, sphx.DFSPH), (40, 8, sphx.DFSPH), (40, 5, sphx.PBD)):
         P, fluid, _ = sphx.scene(nx)
         P.solver = solver

@@ -14,7 +14,7 @@ def worker(rank, world, prt, kind, nx, steps, outdir, seed):
     import torch, torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(prt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import multi_gpu as M
+    import slab_protocol as M
     from slab_cpu_engine import OracleSlabEngine
     import slab_worker
     if kind == "oracle":
