@@ -127,6 +127,7 @@ struct SweepCache {
     // build the neighbour rows for the current positions (no-op when valid or disabled)
     void ensureList(const DArray<int>& csF, const DArray<int>& csB);
     void rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB);
+    void buildListForRange(const DArray<int>& csF, const DArray<int>& csB);     // rows of [rangeLo, rangeHi) only, unconditionally
     void launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext);
     SweepCtx ctx(const DArray<int>& csF, const DArray<int>& csB) const;
     bool fused() const { return (flags & kFlagUnfused) == 0; }
@@ -138,6 +139,7 @@ struct SweepCache {
     const float4* boundary4() const { return fluid4() + capN; }
 };
 
+inline unsigned int sweep_grid_for(int numTiles) { return xcd_grid(numTiles * kTile, kWideBlock); }
 inline unsigned int blocks_for(int n, int block = 256) { return n > 0 ? (unsigned int)((n - 1) / block + 1) : 1u; }
 
 // optional per-kernel timing (sphx_profile_step): when enabled every launch helper brackets the

@@ -4,6 +4,7 @@
 // Jacobi iterations on a fixed cell table while positions move, velocity from displacement, XSPH,
 // surface effects, gravity, then predict.  XSPH writes to a separate buffer (Jacobi) instead of
 // the reference's racy in-place update.
+#include <algorithm>
 #include <cstdlib>
 
 #include "PBDSolver.h"
@@ -229,9 +230,19 @@ void PBDSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const
         c.packBoundary(*boundaries);
         return;
     }
+    // range-restricted launches (slab layer): element-wise passes cover [lo, hi) only, and the two stages that meet moved
+    // positions first (P_LAMBDA after a position update, P_XSPH after the last one) build the rows of their own range
+    const bool ranged = c.rangeLo >= 0;
+    const int lo = ranged ? std::min(c.rangeLo, num) : 0, hi = ranged ? std::min(std::max(c.rangeHi, lo), num) : num;
     if (phase == SPHX_PH_P_VELOCITY) {
         ScopedKernel t("pbd_velocity");
-        launch_velocity_from_displacement(fluids->getVelPtr(), c.vel4w(), fluids->getPosPtr(), fluidPosLast.addr(), dt, num);
+        launch_velocity_from_displacement(fluids->getVelPtr() + lo, c.vel4w() + lo, fluids->getPosPtr() + lo, fluidPosLast.addr() + lo, dt, hi - lo);
+        return;
+    }
+    if (phase == SPHX_PH_P_APPLY) {
+        ScopedKernel t("pbd_apply_clamp");
+        launch_apply_delta_clamp(fluids->getPosPtr() + lo, c.fluid4w() + lo, c.posfw() + lo, bufferFloat3.addr() + lo, spaceSize, hi - lo);
+        c.listValid = false;
         return;
     }
     if (phase == SPHX_PH_P_TAIL) {
@@ -244,10 +255,17 @@ void PBDSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const
     c.setup(cellSize, cellLength, radius);
     c.packFluid(*fluids);
     c.packBoundary(*boundaries);
-    c.ensureList(cellStartFluid, cellStartBoundary);   // rebuilt whenever positions moved since the last build
+    if (ranged && (phase == SPHX_PH_P_LAMBDA || phase == SPHX_PH_P_XSPH)) c.buildListForRange(cellStartFluid, cellStartBoundary);
+    else if (ranged) c.listValid = c.nbr != nullptr && !(c.flags & kFlagNoList);   // the rows this range got from its P_LAMBDA / P_XSPH
+    else c.ensureList(cellStartFluid, cellStartBoundary);   // rebuilt whenever positions moved since the last build
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     DArray<float3>& cg = colorGradientBuffer();
     switch (phase) {
+    case SPHX_PH_P_DELTA_SWEEP: {
+        ScopedKernel t("pbd_delta_pos");
+        launch_op(OpDeltaPos{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true}, num);
+        break;
+    }
     case SPHX_PH_P_LAMBDA: {
         ScopedKernel t("pbd_lambda");
         launch_op(OpLambda{ctx, fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation}, num);
@@ -269,11 +287,17 @@ void PBDSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, const
         } else {
             ScopedKernel t("xsph");
             launch_op(OpXsph<false>{ctx, fluids->getVelPtr(), bufferFloat3.addr(), nullptr, xSPH_c, rho0, 0.0f}, num);
-            launch_copy3_mirror(fluids->getVelPtr(), c.vel4w(), bufferFloat3.addr(), num);
+            // (the live velocities are read by the neighbours' XSPH sums: a ranged schedule copies them in once EVERY range
+            // has been swept -- SPHX_PH_P_SURFACE without surface effects does it)
+            if (!ranged) launch_copy3_mirror(fluids->getVelPtr(), c.vel4w(), bufferFloat3.addr(), num);
         }
         break;
     }
     case SPHX_PH_P_SURFACE: {
+        if (!surface && ranged) {
+            ScopedKernel t("xsph_commit");
+            launch_copy3_mirror(fluids->getVelPtr() + lo, c.vel4w() + lo, bufferFloat3.addr() + lo, hi - lo);
+        }
         if (surface) {
             ScopedKernel t("surface_tension");
             launch_op(OpSurface{ctx, cg.addr(), bufferFloat3.addr(), nullptr, fluids->getVelPtr(), rho0, surfaceTensionIntensity,

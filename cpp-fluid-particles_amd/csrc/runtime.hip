@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
         streamed = wave_ranges(c, i0).ok;
         if ((threadIdx.x & 63) == 0) tileFmt[i >> 6] = streamed ? 2 : 0;
     }
-    build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n,
+    build_neighbor_rows(c, STREAM ? pos[threadIdx.x >> 6] : nullptr, streamed, nbr, nbrCount, i, i < c.n && in_range(c, i),
                         (STREAM || SPHX_BUILD_REGSTAGE) ? nullptr : stage[threadIdx.x >> 6]);
     if (posBuild && i < c.n) {
         const float4 p = c.posm[i];
@@ -557,6 +557,26 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
         activeFlag = 0;
     }
     launchBuild(c, skinMode ? reinterpret_cast<float4*>(posBuild->addr()) : nullptr, nullptr, nullptr);
+    listValid = true;
+}
+
+// Rows of the particles [rangeLo, rangeHi) only, for the positions as they are NOW (slab layer, PBD: the interior of a
+// slab is rebuilt and swept while the halo of the edge layers' new positions is still in flight; the edges follow).
+// Rows are per particle, so building them range by range gives the rows one build of everything would give.
+void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& csB)
+{
+    if ((flags & kFlagNoList) || n <= 0) return;
+    const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
+    if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { flags |= kFlagNoList; ++generation; return; }
+    if (!nbr || nbr->entries < entries) { nbr.reset(); nbr.reset(new RowStore(entries)); ++generation; }
+    listValid = false;                         // ctx() must hand out the live cell tables
+    SweepCtx c = ctx(csF, csB);                // keeps the launch range
+    c.nbr = nullptr;
+    listCsF = csF.addr(); listCsB = csB.addr();
+    ScopedKernel t("build_neighbor_list");
+    if (c.numTiles > 0)
+        k_build_list<false><<<sweep_grid_for(c.numTiles), kWideBlock, 0, stream()>>>(c, nbr->rows, nbrCount.addr(), tileFmt.addr(), nullptr, nullptr,
+                                                                                      nullptr, nullptr, staleFlag.addr(2));
     listValid = true;
 }
 

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -115,7 +116,7 @@ struct RcclTransport final : Transport {
     ncclComm_t comm = nullptr;
     hipStream_t commStream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
-    bool pending = false;
+    bool pending = false, pendingAsync = false;
     long long* dScalar = nullptr;       // 2 x int64 on the device for the all-reduce
     long long* hScalar = nullptr;       // pinned
 
@@ -127,21 +128,28 @@ struct RcclTransport final : Transport {
         static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
         std::memcpy(&id, id128, 128);
         nccl_ok(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
-        hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
-        hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
-        hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
-        hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
-        hip_ok(hipHostMalloc((void**)&hScalar, 2 * sizeof(long long), hipHostMallocDefault), "pinned scalar");
+        try {       // a constructor that throws runs no destructor: give back what exists before passing the error on
+            hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+            hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
+            hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
+            hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
+            hip_ok(hipHostMalloc((void**)&hScalar, 2 * sizeof(long long), hipHostMallocDefault), "pinned scalar");
+        } catch (...) {
+            release();
+            throw;
+        }
     }
-    ~RcclTransport() override
+    ~RcclTransport() override { release(); }
+    void release()
     {
-        (void)hipStreamSynchronize(commStream);
+        if (commStream) (void)hipStreamSynchronize(commStream);
         if (comm) (void)g_rccl.CommDestroy(comm);
         if (dScalar) (void)hipFree(dScalar);
         if (hScalar) (void)hipHostFree(hScalar);
         if (ready) (void)hipEventDestroy(ready);
         if (done) (void)hipEventDestroy(done);
         if (commStream) (void)hipStreamDestroy(commStream);
+        comm = nullptr; dScalar = nullptr; hScalar = nullptr; ready = done = nullptr; commStream = nullptr;
     }
     void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) override
     {
@@ -153,14 +161,18 @@ struct RcclTransport final : Transport {
         for (const Msg& m : recvs) if (m.bytes) nccl_ok(g_rccl.Recv(m.buf, m.bytes, ncclInt8, m.from, comm, commStream), "ncclRecv");
         nccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd");
         hip_ok(hipEventRecord(done, commStream), "event record");
-        pending = true;
+        pending = true; pendingAsync = async;
         sends.clear(); recvs.clear();
         if (!async) wait();
     }
     void wait() override
     {
         if (!pending) return;
-        hip_ok(hipStreamWaitEvent(sphx::stream(), done, 0), "stream wait");
+        // fault injection for the tests ("skipwait"): the engine stream is NOT ordered after an overlapped halo transfer.
+        // With a transport that really completes late (tests/mock_rccl.cpp, deferred mode) results must then be wrong;
+        // tests/test_gpu_slab.py asserts that, which proves the several-ranks tests can see a missing wait().
+        static const bool skip = [] { const char* f = std::getenv("SPHX_SLAB_FAULT"); return f && std::strcmp(f, "skipwait") == 0; }();
+        if (!(skip && pendingAsync)) hip_ok(hipStreamWaitEvent(sphx::stream(), done, 0), "stream wait");
         pending = false;
     }
     long long allreduce_sum(long long v) override
@@ -305,6 +317,7 @@ struct sphx_slab_group {
     int lastDiv = 0, lastDen = 0;
     double waitSeconds = 0.0;
     std::vector<Msg> sends, recvs;
+    bool failed = false;        // a step threw: posted messages were dropped, slabs may be half-updated -> only destroy is allowed
 
     bool overlap() const { return (flags & SPHX_SLAB_NO_OVERLAP) == 0; }
 
@@ -385,14 +398,34 @@ struct sphx_slab_group {
             hip_ok(hipMemcpyAsync(s.hInts + 6, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
         }
         sync("particle exchange (sizes)");
+        // Rank-local failures are only known now (the violation flag, and the capacity check needs the neighbours' sizes),
+        // but the neighbours are about to post receives for THIS rank's payload: a rank that simply returned an error here
+        // would leave them waiting in ncclRecv.  So every rank contributes its failure code to one all-reduce and all of
+        // them leave the step together.  Encoding: crossed = 1, capacity = 1 << 20 per failing slab.
+        long long bad = 0;
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            if (s.hInts[6]) die("slab: a particle crossed more than one cell column in one step");
+            const long long rl = s.hasLeft ? s.hCounts[6] : 0, rr = s.hasRight ? s.hCounts[9] : 0;
+            if (s.hInts[6]) bad += 1;
+            if (s.hCounts[12] + rl + rr > s.capacity) bad += 1LL << 20;
+        }
+        if (const char* f = std::getenv("SPHX_SLAB_FAULT")) {      // fault injection for the tests: "capacity:<rank>:<step>"
+            int r = -1, st = -1;
+            if (std::sscanf(f, "capacity:%d:%d", &r, &st) == 2)
+                for (auto& sp : slabs) if (sp->rank == r && sp->stepsDone == st) bad += 1LL << 20;
+        }
+        const long long anyBad = world > (int)slabs.size() ? transport->allreduce_sum(bad) : bad;
+        if (anyBad) {
+            const char* here = bad ? "this process" : "another rank";
+            if (anyBad & ((1LL << 20) - 1)) die(std::string("slab: a particle crossed more than one cell column in one step (") + here + ")");
+            die(std::string("slab: capacity exceeded (particles piled up in one slab; ") + here + ")");
+        }
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
             const size_t rowBytes = sizeof(float) * (size_t)s.width();
             const long long sl = s.hCounts[0], sr = s.hCounts[3], rl = s.hasLeft ? s.hCounts[6] : 0, rr = s.hasRight ? s.hCounts[9] : 0;
             if (s.hasLeft) { s.ownedLeft = s.hCounts[7]; s.widthLeft = (int)s.hCounts[8]; }
             if (s.hasRight) { s.ownedRight = s.hCounts[10]; s.widthRight = (int)s.hCounts[11]; }
-            if (s.hCounts[12] + rl + rr > s.capacity) die("slab: capacity exceeded (particles piled up in one slab)");
             if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.sendL.p, (size_t)sl * rowBytes}); recvs.push_back({s.rank - 1, s.rank, s.recvL.p, (size_t)rl * rowBytes}); }
             if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.sendR.p, (size_t)sr * rowBytes}); recvs.push_back({s.rank + 1, s.rank, s.recvR.p, (size_t)rr * rowBytes}); }
         }
@@ -569,8 +602,71 @@ struct sphx_slab_group {
 
     // PBDSolver::step (PBDSolver.cu:34-79): two ghost columns, every stage on all held particles, halo after each
     // stage that writes a neighbour-read field.  The first call only sorts and records positions (PBDSolver.cu:45-49).
+    // The owned particles of a slab as three disjoint ranges: left edge layer, interior, right edge layer (a PBD slab may be
+    // narrower than its two edge layers together: the right edge then starts where the left one ends).
+    struct Parts { int eL0, eL1, in0, in1, eR0, eR1; };
+    static Parts parts(const Slab& s)
+    {
+        const int* l = s.layer;
+        Parts p;
+        p.eL0 = l[0]; p.eL1 = std::min(std::max(l[1], l[0]), l[3]);
+        p.eR0 = std::max(std::min(l[2], l[3]), p.eL1); p.eR1 = l[3];
+        p.in0 = p.eL1; p.in1 = p.eR0;
+        return p;
+    }
+    void pbdInterior(int phase) { for (auto& sp : slabs) { const Parts p = parts(*sp); sp->sys->system->phaseEx(phase, p.in0, p.in1, false, 0, 0, false); } }
+    void pbdEdges(int phase)
+    {
+        for (auto& sp : slabs) {
+            const Parts p = parts(*sp);
+            sp->sys->system->phaseEx(phase, p.eL0, p.eL1, false, 0, 0, false);
+            sp->sys->system->phaseEx(phase, p.eR0, p.eR1, false, 0, 0, false);
+        }
+    }
+
+    // PBD with halo traffic hidden behind the interior (r03).  Every stage sweeps its INTERIOR first -- interior particles
+    // read owned particles only, so the halo posted by the previous stage may still be in flight -- then waits, sweeps the two
+    // edge layers (which read ghosts) and posts the halo of its own output at once.  Jacobi semantics are kept: every delta-p
+    // is computed (interior, then edges) before any position moves (PBDSolver.cu:225-258), the rows of a range
+    // are rebuilt by the first stage that meets moved positions (P_LAMBDA, P_XSPH), ghosts are never swept.
+    void stepPbdOverlapped()
+    {
+        exchangeParticles();
+        runAll(SPHX_PH_P_SEARCH);
+        updateLayers();
+        if (slabs[0]->stepsDone == 0) return;
+        for (int it = 0; it < global.pbd_iters; ++it) {
+            pbdInterior(SPHX_PH_P_LAMBDA);               // (the position halo of the previous iteration is in flight)
+            transport->wait();
+            pbdEdges(SPHX_PH_P_LAMBDA);
+            postHalo({SPHX_F_LAMBDA, SPHX_F_POSF}, true);
+            pbdInterior(SPHX_PH_P_DELTA_SWEEP);
+            transport->wait();
+            pbdEdges(SPHX_PH_P_DELTA_SWEEP);
+            pbdEdges(SPHX_PH_P_APPLY);                   // all delta-p of this slab are computed: positions may move now
+            postHalo({SPHX_F_POS4}, true);
+            pbdInterior(SPHX_PH_P_APPLY);
+        }
+        for (auto& sp : slabs) sp->sys->system->phaseEx(SPHX_PH_P_VELOCITY, sp->o0, sp->o1, false, 0, 0, false);
+        postHalo({SPHX_F_VEL4}, true);                   // (orders the engine stream after the position halo first)
+        pbdInterior(SPHX_PH_P_XSPH);
+        transport->wait();
+        pbdEdges(SPHX_PH_P_XSPH);
+        if (surface) {
+            postHalo({SPHX_F_CG4}, true);
+            pbdInterior(SPHX_PH_P_SURFACE);
+            transport->wait();
+            pbdEdges(SPHX_PH_P_SURFACE);
+        } else {
+            // every XSPH sum has been formed: the new velocities become the live ones (owned particles)
+            for (auto& sp : slabs) sp->sys->system->phaseEx(SPHX_PH_P_SURFACE, sp->o0, sp->o1, false, 0, 0, false);
+        }
+        runAll(SPHX_PH_P_TAIL);
+    }
+
     void stepPbd()
     {
+        if (overlap()) { stepPbdOverlapped(); return; }
         exchangeParticles();
         runAll(SPHX_PH_P_SEARCH);
         updateLayers();
@@ -631,7 +727,10 @@ std::vector<int> choose_cuts(const std::vector<int>& column, int gx, int world, 
     std::vector<int> cuts{0};
     for (int r = 1; r < world; ++r) {
         const double target = (double)total * r / world;
-        int x = (int)(std::lower_bound(cdf.begin(), cdf.end(), target, [](long long a, double t) { return (double)a < t; }) - cdf.begin()) + 1;
+        // the column in which the running count crosses the target goes to whichever side leaves the smaller error
+        const int xc = (int)(std::lower_bound(cdf.begin(), cdf.end(), target, [](long long a, double t) { return (double)a < t; }) - cdf.begin());
+        const double below = xc > 0 ? (double)cdf[(size_t)xc - 1] : 0.0, above = xc < gx ? (double)cdf[(size_t)xc] : (double)total;
+        int x = (target - below < above - target) ? xc : xc + 1;
         x = std::max(x, cuts.back() + minWidth);
         x = std::min(x, gx - minWidth * (world - r));
         cuts.push_back(x);
@@ -797,12 +896,18 @@ int sphx_slab_destroy(sphx_slab_group* g)
 int sphx_slab_step(sphx_slab_group* g, int n, float* ms_total)
 {
     if (!g || n < 0) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_step: bad argument");
+    if (g->failed) return slab_fail(SPHX_ERR_STATE, "sphx_slab_step: an earlier step of this group failed; destroy it (sphx_slab_destroy) and create a new one");
     return slab_guarded("sphx_slab_step", [&] {
+        struct Guard {           // any exception leaves the group unusable: posted messages are dropped, never replayed
+            sphx_slab_group* g; bool ok = false;
+            ~Guard() { if (!ok) { g->failed = true; g->sends.clear(); g->recvs.clear(); } }
+        } guard{g};
         const auto t0 = std::chrono::steady_clock::now();
         for (int k = 0; k < n; ++k) g->step();
         g->transport->wait();
         hip_ok(hipStreamSynchronize(sphx::stream()), "step sync");
         if (ms_total) *ms_total = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+        guard.ok = true;
         return (int)SPHX_OK;
     });
 }

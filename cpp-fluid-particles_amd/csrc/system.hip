@@ -358,7 +358,7 @@ void SPHSystem::phase(int p)
                          _sc.surfaceTension, _sc.airPressure);
         return;
     }
-    if (p >= SPHX_PH_P_SEARCH && p <= SPHX_PH_P_TAIL) {
+    if ((p >= SPHX_PH_P_SEARCH && p <= SPHX_PH_P_TAIL) || p == SPHX_PH_P_DELTA_SWEEP || p == SPHX_PH_P_APPLY) {
         auto* pbd = dynamic_cast<PBDSolver*>(_solver.get());
         if (!pbd) throw "SPHSystem::phase: PBD stages need a PBDSolver";
         if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, _fluidCellStart);

@@ -21,7 +21,7 @@ WCSPH, DFSPH, PBD = 0, 1, 2
 (PH_SEARCH, PH_HEAD, PH_DIV_CORRECT, PH_DIV_ERROR, PH_FORCE, PH_VISC_COLOR, PH_SURFACE, PH_WARM_CORRECT,
  PH_DEN_ERROR_SET, PH_DEN_CORRECT, PH_DEN_ERROR_ACC, PH_ADVECT, PH_W_SEARCH, PH_W_PROPS, PH_W_SURFACE,
  PH_W_PRESSURE, PH_P_SEARCH, PH_P_LAMBDA, PH_P_DELTA, PH_P_VELOCITY, PH_P_XSPH, PH_P_SURFACE, PH_P_TAIL,
- PH_SURFACE_WARM, PH_W_SURFACE_PRESSURE) = range(25)
+ PH_SURFACE_WARM, PH_W_SURFACE_PRESSURE, PH_P_DELTA_SWEEP, PH_P_APPLY) = range(27)
 
 _INT_FIELDS = (F_CELL, F_CELLSTART_F, F_CELLSTART_B, F_ID)
 _VEC_FIELDS = (F_POS, F_VEL, F_BPOS, F_POS_LAST, F_BUF3)

@@ -165,7 +165,11 @@ typedef enum sphx_phase {
     SPHX_PH_P_TAIL,           /* gravity, remember positions, predict (advect + clamp)              */
     /* fused forms (one row walk, same bits): */
     SPHX_PH_SURFACE_WARM,     /* DFSPH: SPHX_PH_SURFACE + SPHX_PH_WARM_CORRECT (surface effects on; writes vel)     */
-    SPHX_PH_W_SURFACE_PRESSURE/* WCSPH: SPHX_PH_W_SURFACE + SPHX_PH_W_PRESSURE (surface effects on)                */
+    SPHX_PH_W_SURFACE_PRESSURE,/* WCSPH: SPHX_PH_W_SURFACE + SPHX_PH_W_PRESSURE (surface effects on)               */
+    /* PBD, split form for range-restricted launches (slab layer: interior first, edges after the halo arrived):
+     * P_DELTA = P_DELTA_SWEEP on every range, THEN P_APPLY (Jacobi: every delta-p is computed from the old positions) */
+    SPHX_PH_P_DELTA_SWEEP,    /* delta-p sweep only                              (writes the delta-p buffer)       */
+    SPHX_PH_P_APPLY           /* pos += delta-p, box clamp                       (writes pos mirror)               */
 } sphx_phase;
 int  sphx_run_phase(sphx_system *sys, int phase);
 /* adaptive DFSPH across processes: the error stages (DIV_ERROR, DEN_ERROR_ACC) accumulate the exact

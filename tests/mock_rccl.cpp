@@ -8,8 +8,16 @@
  *     count (a mismatch, which the real library answers with a hang or silent corruption, fails loudly here);
  *   - the operations of one ncclGroupStart/End make progress together (no ordering between different peers);
  *   - an operation is ordered after the work enqueued on its stream before it.
- * Mechanics: messages are staged through a POSIX shared-memory segment named by the unique id (host copies), and
- * everything is complete when ncclGroupEnd / ncclAllReduce returns.  Timing means nothing here; order and sizes do.
+ * Mechanics: messages are staged through a POSIX shared-memory segment named by the unique id (host copies).
+ * Two modes:
+ *   immediate (default)       everything is complete when ncclGroupEnd / ncclAllReduce returns.
+ *   deferred  (SPHX_MOCK_RCCL_DEFER_US=<microseconds>)   like the real library, ncclGroupEnd only ENQUEUES: on the
+ *       caller's stream go a spin kernel of that many microseconds, the device-to-host copies of the sends into pinned
+ *       staging, ONE host callback that moves all of the group's messages through the mailboxes, and the
+ *       host-to-device copies of the receives.  ncclGroupEnd returns before any byte has moved; data lands in the
+ *       receive buffers (and is read from the send buffers) late and only in stream order.  A consumer that forgets to
+ *       order its kernels after the transfer reads stale ghosts, a producer that overwrites a send buffer early
+ *       ships wrong data -- both show up as wrong results (tests/test_gpu_slab.py has the negative test).
  *
  * Loaded through SPHX_RCCL_LIBRARY=<this .so> (tests/test_gpu_slab.py); never part of the product.
  */
@@ -18,6 +26,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <fcntl.h>
@@ -54,7 +63,7 @@ struct Comm {
     char name[64];
 };
 
-struct Op { bool send; char* dev; size_t bytes, done; int peer; Comm* comm; hipStream_t stream; bool headerSeen; };
+struct Op { bool send; char* dev; size_t bytes, done; int peer; Comm* comm; hipStream_t stream; bool headerSeen; char* host; };   // host: pinned staging (deferred mode)
 
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
@@ -91,7 +100,8 @@ int progress(Op& op, std::vector<char>& stage, bool& moved)
         Box& b = c->sh->box[c->rank][op.peer];
         if (b.written.load() != b.consumed.load()) return 0;             // the consumer still holds the previous chunk
         const size_t n = op.bytes - op.done < kChunk ? op.bytes - op.done : kChunk;
-        if (hipMemcpy(b.data, op.dev + op.done, n, hipMemcpyDeviceToHost) != hipSuccess) return fail("device-to-host copy failed");
+        if (op.host) std::memcpy(b.data, op.host + op.done, n);           // deferred mode: we are inside a stream callback, no HIP calls
+        else if (hipMemcpy(b.data, op.dev + op.done, n, hipMemcpyDeviceToHost) != hipSuccess) return fail("device-to-host copy failed");
         b.messageBytes = op.bytes; b.chunkBytes = n;
         b.written.fetch_add(1);
         op.done += n; moved = true;
@@ -105,7 +115,8 @@ int progress(Op& op, std::vector<char>& stage, bool& moved)
         }
         const size_t n = b.chunkBytes;
         if (op.done + n > op.bytes) return fail("chunk overruns the receive buffer");
-        if (hipMemcpy(op.dev + op.done, b.data, n, hipMemcpyHostToDevice) != hipSuccess) return fail("host-to-device copy failed");
+        if (op.host) std::memcpy(op.host + op.done, b.data, n);
+        else if (hipMemcpy(op.dev + op.done, b.data, n, hipMemcpyHostToDevice) != hipSuccess) return fail("host-to-device copy failed");
         b.consumed.fetch_add(1);
         op.done += n; moved = true;
     }
@@ -113,11 +124,8 @@ int progress(Op& op, std::vector<char>& stage, bool& moved)
     return 0;
 }
 
-int run_group()
+int move_messages(std::vector<Op>& ops)
 {
-    std::vector<Op> ops;
-    ops.swap(t_ops);
-    for (const Op& o : ops) if (hipStreamSynchronize(o.stream) != hipSuccess) return fail("stream synchronise failed");
     std::vector<char> stage;
     double lastMove = now();
     for (;;) {
@@ -151,12 +159,77 @@ int run_group()
     }
 }
 
+// ---- deferred mode ------------------------------------------------------------------------------------------------
+__global__ void k_mock_delay(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+struct Deferred { std::vector<Op> ops; hipEvent_t done; std::vector<char*> pinned; int status; };
+std::vector<Deferred*> g_inflight;         // groups whose stream work may still be running (single host thread per process)
+std::atomic<int> g_deferredError{0};
+
+void deferred_callback(void* p)
+{
+    Deferred* d = (Deferred*)p;
+    d->status = move_messages(d->ops);
+    if (d->status) g_deferredError.store(d->status);
+}
+void reap(bool all)
+{
+    for (size_t k = 0; k < g_inflight.size();) {
+        Deferred* d = g_inflight[k];
+        if (all) (void)hipEventSynchronize(d->done);
+        if (all || hipEventQuery(d->done) == hipSuccess) {
+            for (char* h : d->pinned) (void)hipHostFree(h);
+            (void)hipEventDestroy(d->done);
+            delete d;
+            g_inflight.erase(g_inflight.begin() + (long)k);
+        } else ++k;
+    }
+}
+int defer_us()
+{
+    static const int us = [] { const char* e = std::getenv("SPHX_MOCK_RCCL_DEFER_US"); return e ? std::atoi(e) : 0; }();
+    return us;
+}
+
+int run_group()
+{
+    if (g_deferredError.load()) return fail("an earlier deferred group failed");
+    if (defer_us() <= 0) {
+        std::vector<Op> ops;
+        ops.swap(t_ops);
+        for (const Op& o : ops) if (hipStreamSynchronize(o.stream) != hipSuccess) return fail("stream synchronise failed");
+        return move_messages(ops);
+    }
+    reap(false);
+    Deferred* d = new Deferred;
+    d->ops.swap(t_ops);
+    d->status = 0;
+    if (d->ops.empty()) { delete d; return 0; }
+    hipStream_t st = d->ops[0].stream;
+    for (const Op& o : d->ops) if (o.stream != st) { delete d; return fail("deferred mode expects one stream per group"); }
+    hipLaunchKernelGGL(k_mock_delay, dim3(1), dim3(1), 0, st, (long long)defer_us() * 100);     // wall_clock64: 100 MHz
+    for (Op& o : d->ops) {
+        if (hipHostMalloc((void**)&o.host, o.bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned staging allocation failed");
+        d->pinned.push_back(o.host);
+        if (o.send && hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("async device-to-host copy failed");
+    }
+    if (hipLaunchHostFunc(st, deferred_callback, d) != hipSuccess) return fail("hipLaunchHostFunc failed");
+    for (Op& o : d->ops)
+        if (!o.send && hipMemcpyAsync(o.dev, o.host, o.bytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail("async host-to-device copy failed");
+    if (hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess || hipEventRecord(d->done, st) != hipSuccess) return fail("event failed");
+    g_inflight.push_back(d);
+    return 0;
+}
+
 int post(bool send, void* buf, size_t count, int type, int peer, Comm* c, hipStream_t stream)
 {
     if (!c || peer < 0 || peer >= c->world || peer == c->rank) return fail("bad peer");
     const size_t width = (type == 0 || type == 1) ? 1 : (type == 2 || type == 3 || type == 7) ? 4 : 8;
     if (count == 0) return fail("zero-byte message (RCCL would hang on an unmatched empty message)");
-    t_ops.push_back(Op{send, (char*)buf, count * width, 0, peer, c, stream, false});
+    t_ops.push_back(Op{send, (char*)buf, count * width, 0, peer, c, stream, false, nullptr});
     if (t_depth == 0) return run_group();
     return 0;
 }
@@ -204,6 +277,7 @@ int ncclCommInitRank(Comm** out, int world, ncclUniqueIdMock id, int rank)
 int ncclCommDestroy(Comm* c)
 {
     if (!c) return 0;
+    reap(true);
     (void)barrier(c);
     if (c->rank == 0) shm_unlink(c->name);
     munmap(c->sh, sizeof(Shared));
@@ -225,6 +299,7 @@ int ncclRecv(void* buf, size_t count, int type, int peer, Comm* c, hipStream_t s
 int ncclAllReduce(const void* in, void* out, size_t count, int type, int op, Comm* c, hipStream_t stream)
 {
     if (!c || count != 1 || type != 4 || op != 0) return fail("the mock only reduces one int64 with ncclSum");
+    if (g_deferredError.load()) return fail("an earlier deferred group failed");
     if (hipStreamSynchronize(stream) != hipSuccess) return fail("stream synchronise failed");
     long long v = 0;
     if (hipMemcpy(&v, in, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return fail("device-to-host copy failed");

@@ -76,7 +76,10 @@ def choose_cuts(columns, gx, world, min_width=2):
     cuts = [0]
     for r in range(1, world):
         target = total * r / world
-        x = int(np.searchsorted(cdf, target, side="left")) + 1
+        xc = int(np.searchsorted(cdf, target, side="left"))      # the column in which the running count crosses the target
+        below = float(cdf[xc - 1]) if xc > 0 else 0.0
+        above = float(cdf[xc]) if xc < gx else float(total)
+        x = xc if (target - below < above - target) else xc + 1   # ... goes to the side that leaves the smaller error
         x = max(x, cuts[-1] + min_width)
         x = min(x, gx - min_width * (world - r))
         cuts.append(x)
