@@ -157,8 +157,9 @@ def test_native_slab_layer_rccl_transport_several_ranks(oracle, tmp_path, world,
     assert_bit_equal(np.concatenate([p["density"] for p in parts])[order], rd, "rccl ranks density")
     if solver == "dfsph":
         assert all(tuple(p["iters"]) == rit for p in parts)
-    if rebalance and world < 8:        # (8 narrow slabs: the rule's minimum width keeps the cuts where they are)
-        assert any(int(p["distinct_cuts"]) > 1 for p in parts), "the cuts must have moved"
+    if rebalance and world < 8 and solver != "pbd":     # (8 narrow slabs, or PBD's two ghost columns on this 17-column grid: the rule's
+        assert any(int(p["distinct_cuts"]) > 1 for p in parts), "the cuts must have moved"   # minimum width keeps the cuts where they are;
+                                                                                             # test_native_slab_layer_moving_cuts[pbd] moves them)
 
 
 def test_bench_launch_line_two_ranks(tmp_path):
