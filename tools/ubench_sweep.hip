@@ -14,7 +14,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
 //         -fno-gpu-flush-denormals-to-zero -I cpp-fluid-particles_amd/csrc -I include tools/ubench_sweep.hip -o ubench_sweep
-//   ./ubench_sweep [nx=88] [reps=20]
+//   ./ubench_sweep [nx=88] [reps=20] [p = address-pattern probes | b = compact-brick LDS variants] [x: tile schedules] [x: L16]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -400,6 +400,81 @@ __global__ void __launch_bounds__(T) k_l16(Consts c, const float4* __restrict__ 
     if (tile * 64 + lane < n) out[i] = e;
 }
 
+
+// ---- BRICK: the compact-brick LDS stage SURVEY 8(a) sized ---------------------------------------------------
+// A block owns the particles of a brick of BX x BY cell columns x BZ cells along z (z is the fastest cell axis, so the brick's part
+// of every column is ONE contiguous particle run) and stages the (BX+2) x (BY+2) surrounding runs, z range [z0-1, z0+BZ], with
+// coalesced loads: position+mass (and, for the two-field sweeps, velocity) as 16-byte LDS records.  Rows hold 16-bit LDS slots,
+// 8 per 16-byte chunk; a pair costs one (two) ds_read_b128 instead of one (two) divergent global gathers.  Own particles are
+// handed to the T threads in rounds of T (a brick of the reference lattice owns ~500-700 particles).
+struct BrickDesc { int runFirst, numRuns, staged, own, ownFirst, rowBase, rounds; };   // runs / own map / rows: offsets into flat arrays
+struct BrickRun { int start, len, base; };
+
+template <int T, bool EXACT, bool TWO>
+__global__ void __launch_bounds__(T) k_brick(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                             const BrickDesc* __restrict__ bricks, const BrickRun* __restrict__ runs,
+                                             const int* __restrict__ ownIndex, const unsigned short* __restrict__ ownSlot,
+                                             const uint4* __restrict__ rows, const unsigned char* __restrict__ waveChunks,
+                                             float* __restrict__ out, int numBricks, int slots)
+{
+    extern __shared__ float4 lds[];
+    float4* lpos = lds;
+    float4* lvel = lds + slots;
+    constexpr int kWaves = T / 64;
+    const int blk = logical_block();
+    if (blk >= numBricks) return;
+    const BrickDesc B = bricks[blk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < B.numRuns; r += kWaves) {             // one wave per run: coalesced 16-byte loads
+        const BrickRun R = runs[B.runFirst + r];
+        for (int t = lane; t < R.len; t += 64) {
+            lpos[R.base + t] = posm[R.start + t];
+            if (TWO) lvel[R.base + t] = vel4[R.start + t];
+        }
+    }
+    if (threadIdx.x == 0) {                                      // the padding slot
+        lpos[B.staged] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
+        if (TWO) lvel[B.staged] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    int rowAt = B.rowBase;                                       // in chunk-rows of T lanes
+    for (int rd = 0; rd < B.rounds; ++rd) {
+        const int p = rd * T + (int)threadIdx.x;
+        const bool has = p < B.own;
+        const int i = has ? ownIndex[B.ownFirst + p] : -1;
+        const int self = has ? (int)ownSlot[B.ownFirst + p] : B.staged;
+        const float4 sp = lpos[self];
+        const float3 pi = v3(sp.x, sp.y, sp.z);
+        const float4 sv = TWO ? lvel[self] : make_float4(sp.w, 0.f, 0.f, 0.f);
+        const float3 vi = v3(sv.x, sv.y, sv.z);
+        const int chunksRound = waveChunks[(size_t)(blk * 8 + rd) * 17 + 16];      // [brick][round][wave 0..15 | 16 = max of the round]
+        const int chunks = waveChunks[(size_t)(blk * 8 + rd) * 17 + wave];
+        const uint4* row = rows + (size_t)rowAt * T + threadIdx.x;
+        float e = 0.0f;
+        uint4 nxt = chunks > 0 ? row[0] : make_uint4(0, 0, 0, 0);
+        for (int ch = 0; ch < chunks; ++ch) {
+            const uint4 cur = nxt;
+            if (ch + 1 < chunks) nxt = row[(size_t)(ch + 1) * T];
+            const unsigned int w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 pj[4], vj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned int word = w[h * 2 + (u >> 1)];
+                    const unsigned int slot = (u & 1) ? (word >> 16) : (word & 0xffffu);
+                    pj[u] = lpos[slot];
+                    vj[u] = TWO ? lvel[slot] : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e += pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+            }
+        }
+        if (has) out[i] = e;
+        rowAt += chunksRound;
+    }
+}
+
 // ---- host: scene, grid, rows ---------------------------------------------------------------------------
 static float bits_to_float(unsigned int b) { float f; memcpy(&f, &b, 4); return f; }
 
@@ -663,7 +738,7 @@ int main(int argc, char** argv)
 #undef LQ2
 #undef LQ
             }
-            for (int v = 0; v < (argc > 5 ? 2 : 0); ++v) {
+            for (int v = 0; v < ((argc > 5 && argv[3][0] != 'b') ? 2 : 0); ++v) {
                 const int T = sets[v].T, slots = sets[v].slots + 1;
                 const size_t ldsBytes = (size_t)slots * 16 * (two ? 2 : 1);
                 const unsigned grid = xcd_grid(n, T);
@@ -687,8 +762,116 @@ int main(int argc, char** argv)
         }
     }
 
+
+    // ---- BRICK variants (argv[6] present): brick shapes BXxBYxBZ, T threads ---------------------------------------------------
+    if (argc > 3 && argv[3][0] == 'b') {
+        struct Shape { int bx, by, bz, T; };
+        const Shape shapes[] = {{4, 4, 4, 256}, {4, 4, 4, 512}, {4, 4, 8, 512}, {4, 4, 8, 1024}, {2, 2, 8, 256}, {3, 3, 6, 256}, {6, 6, 4, 512}};
+        for (const Shape& S : shapes) {
+            const int nbx = (gx + S.bx - 1) / S.bx, nby = (gy + S.by - 1) / S.by, nbz = (gz + S.bz - 1) / S.bz;
+            std::vector<BrickDesc> descs; std::vector<BrickRun> bruns; std::vector<int> ownIdx; std::vector<unsigned short> ownSlot;
+            std::vector<unsigned char> wch;
+            std::vector<int> slotOf(n, -1);
+            int maxStaged = 0, maxOwn = 0; long long stagedSum = 0, ownSum = 0; long long rowChunkRows = 0;
+            struct Tmp { int first, count; };
+            std::vector<std::vector<unsigned short>> rowsPerBrick;   // flattened later
+            std::vector<uint4> rowsFlat;
+            bool ok = true;
+            for (int bxi = 0; bxi < nbx && ok; ++bxi) for (int byi = 0; byi < nby && ok; ++byi) for (int bzi = 0; bzi < nbz && ok; ++bzi) {
+                const int x0 = bxi * S.bx, y0 = byi * S.by, z0 = bzi * S.bz;
+                const int x1 = std::min(x0 + S.bx, gx), y1 = std::min(y0 + S.by, gy), z1 = std::min(z0 + S.bz, gz);   // exclusive
+                BrickDesc D; D.runFirst = (int)bruns.size(); D.numRuns = 0; D.staged = 0; D.own = 0; D.ownFirst = (int)ownIdx.size();
+                // own particles first (to skip empty bricks)
+                std::vector<int> own;
+                for (int X = x0; X < x1; ++X) for (int Y = y0; Y < y1; ++Y) {
+                    const int a = cs[(X * gy + Y) * gz + z0], b = cs[(X * gy + Y) * gz + z1 - 1 + 1];
+                    for (int j = a; j < b; ++j) own.push_back(j);
+                }
+                if (own.empty()) continue;
+                const int zlo = std::max(z0 - 1, 0), zhi = std::min(z1, gz - 1);
+                std::vector<std::pair<int, int>> touched;
+                for (int X = std::max(x0 - 1, 0); X <= std::min(x1, gx - 1); ++X) for (int Y = std::max(y0 - 1, 0); Y <= std::min(y1, gy - 1); ++Y) {
+                    const int a = cs[(X * gy + Y) * gz + zlo], b = cs[(X * gy + Y) * gz + zhi + 1];
+                    if (b == a) continue;
+                    bruns.push_back({a, b - a, D.staged});
+                    for (int j = a; j < b; ++j) slotOf[j] = D.staged + (j - a);
+                    touched.push_back({a, b});
+                    D.staged += b - a; D.numRuns++;
+                }
+                if (D.staged + 1 > 65535) { ok = false; break; }
+                D.own = (int)own.size();
+                D.rounds = (D.own + S.T - 1) / S.T;
+                if (D.rounds > 8) { ok = false; break; }
+                D.rowBase = (int)rowChunkRows;
+                for (int j : own) { ownIdx.push_back(j); ownSlot.push_back((unsigned short)slotOf[j]); }
+                const int blk = (int)descs.size();
+                wch.resize((size_t)(blk + 1) * 8 * 17, 0);
+                for (int rd = 0; rd < D.rounds; ++rd) {
+                    int roundMax = 0;
+                    for (int t = 0; t < S.T; ++t) {
+                        const int p = rd * S.T + t;
+                        const int m = p < D.own ? cnt[own[p]] : 0;
+                        const int ch = (m + kChunk - 1) / kChunk;
+                        unsigned char& wv = wch[(size_t)(blk * 8 + rd) * 17 + t / 64];
+                        wv = (unsigned char)std::max<int>(wv, ch);
+                        roundMax = std::max(roundMax, ch);
+                    }
+                    wch[(size_t)(blk * 8 + rd) * 17 + 16] = (unsigned char)roundMax;
+                    const size_t at = rowsFlat.size();
+                    rowsFlat.resize(at + (size_t)roundMax * S.T, make_uint4(0, 0, 0, 0));
+                    for (int t = 0; t < S.T; ++t) {
+                        const int p = rd * S.T + t;
+                        const int i = p < D.own ? own[p] : -1;
+                        const int m = i >= 0 ? cnt[i] : 0;
+                        for (int k = 0; k < roundMax * kChunk; ++k) {
+                            int slot = D.staged;
+                            if (k < m) { slot = slotOf[nbr[i][k]]; if (slot < 0) { printf("brick: neighbour outside the halo\n"); return 1; } }
+                            reinterpret_cast<unsigned short*>(&rowsFlat[at + (size_t)(k / kChunk) * S.T + t])[k % kChunk] = (unsigned short)slot;
+                        }
+                    }
+                    rowChunkRows += roundMax;
+                }
+                for (auto& ab : touched) for (int j = ab.first; j < ab.second; ++j) slotOf[j] = -1;
+                maxStaged = std::max(maxStaged, D.staged); maxOwn = std::max(maxOwn, D.own);
+                stagedSum += D.staged; ownSum += D.own;
+                descs.push_back(D);
+            }
+            if (!ok) { printf("BRICK %dx%dx%d T=%d: shape does not fit (slots or rounds)\n", S.bx, S.by, S.bz, S.T); continue; }
+            const int numBricks = (int)descs.size(), slots = maxStaged + 1;
+            double waveIt = 0; for (size_t k = 0; k < wch.size(); k += 17) for (int w = 0; w < 16; ++w) waveIt += wch[k + w] * 8.0 * 64.0;
+            printf("BRICK %dx%dx%d T=%d: %d bricks, own avg %.0f max %d, staged avg %.0f max %d (x%.2f of own, %.1f KB per field), row slots x%.2f of pairs\n",
+                   S.bx, S.by, S.bz, S.T, numBricks, (double)ownSum / numBricks, maxOwn, (double)stagedSum / numBricks, maxStaged,
+                   (double)stagedSum / ownSum, slots * 16.0 / 1024, waveIt / pairs);
+            BrickDesc* dDesc; BrickRun* dRuns; int* dOwnIdx; unsigned short* dOwnSlot; uint4* dRowsB; unsigned char* dWch;
+            CK(hipMalloc(&dDesc, sizeof(BrickDesc) * descs.size())); CK(hipMalloc(&dRuns, sizeof(BrickRun) * bruns.size()));
+            CK(hipMalloc(&dOwnIdx, sizeof(int) * ownIdx.size())); CK(hipMalloc(&dOwnSlot, sizeof(unsigned short) * ownSlot.size()));
+            CK(hipMalloc(&dRowsB, sizeof(uint4) * std::max<size_t>(rowsFlat.size(), 1))); CK(hipMalloc(&dWch, wch.size()));
+            CK(hipMemcpy(dDesc, descs.data(), sizeof(BrickDesc) * descs.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dRuns, bruns.data(), sizeof(BrickRun) * bruns.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dOwnIdx, ownIdx.data(), sizeof(int) * ownIdx.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dOwnSlot, ownSlot.data(), sizeof(unsigned short) * ownSlot.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dRowsB, rowsFlat.data(), sizeof(uint4) * rowsFlat.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dWch, wch.data(), wch.size(), hipMemcpyHostToDevice));
+            const unsigned grid = (unsigned)(((numBricks + 7) / 8) * 8);
+            for (int exact = 1; exact >= 0; --exact)
+                for (int two = 1; two >= 0; --two) {
+                    const size_t ldsBytes = (size_t)slots * 16 * (two ? 2 : 1);
+                    if (ldsBytes > 160 * 1024) { printf("   (%s %s: %zu KB of LDS, skipped)\n", exact ? "exact" : "tol", two ? "2f" : "1f", ldsBytes / 1024); continue; }
+                    char nm[96];
+                    snprintf(nm, sizeof(nm), "BRICK %dx%dx%d T=%d %s %s (%zu KB)", S.bx, S.by, S.bz, S.T, exact ? "exact" : "tol", two ? "2f" : "1f", ldsBytes / 1024);
+#define LB(TT, EX, TW) do { if (ldsBytes > 64 * 1024) CK(hipFuncSetAttribute((const void*)k_brick<TT, EX, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+                            hipLaunchKernelGGL((k_brick<TT, EX, TW>), dim3(grid), dim3(TT), ldsBytes, st, c, dPos, dVel, dDesc, dRuns, dOwnIdx, dOwnSlot, dRowsB, dWch, dOut, numBricks, slots); } while (0)
+#define LB2(TT) do { if (exact) { if (two) LB(TT, true, true); else LB(TT, true, false); } else { if (two) LB(TT, false, true); else LB(TT, false, false); } } while (0)
+                    run(nm, exact, two, [&] { if (S.T == 256) LB2(256); else if (S.T == 512) LB2(512); else LB2(1024); });
+#undef LB2
+#undef LB
+                }
+            CK(hipFree(dDesc)); CK(hipFree(dRuns)); CK(hipFree(dOwnIdx)); CK(hipFree(dOwnSlot)); CK(hipFree(dRowsB)); CK(hipFree(dWch));
+        }
+    }
+
     // ---- tile schedules: which tiles share a CU's L1 / an XCD's L2 at the same time ---------------------------
-    if (argc > 4) {
+    if (argc > 4 && argv[3][0] != 'b') {
         std::vector<int> order(numTiles);
         int* dOrder; CK(hipMalloc(&dOrder, sizeof(int) * numTiles));
         auto spread3 = [](unsigned long long v) { unsigned long long r = 0; for (int b = 0; b < 20; ++b) r |= ((v >> b) & 1ull) << (3 * b); return r; };
