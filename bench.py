@@ -104,10 +104,24 @@ def read_traffic(workload_key):
         with open(path) as f:
             entry = json.load(f).get(workload_key)
         if not entry or entry.get("source_hash") != engine_source_hash():
-            return None, None
-        return entry.get("hbm_bytes_per_launch"), entry.get("valu_busy_frac")
+            return None
+        return entry
     except Exception:
-        return None, None
+        return None
+
+
+def limiter_text(pmc):
+    """names both limits of the dominant kernel WITH the numbers measured on this source tree; without them it says so"""
+    if not pmc or pmc.get("valu_issue_frac") is None:
+        return "not measured for this build (profiles/traffic.json belongs to another source hash); r02 measurement: vector L1 / TA path"
+    parts = ["VALU issue %.0f %% of the calibrated slots (SQ_INSTS_VALU x 2.3 clk, profiles/r03_valu_calibration.txt)" % (100.0 * pmc["valu_issue_frac"])]
+    if pmc.get("l1_line_accesses_per_clk_per_cu") is not None:
+        parts.append("vector L1 %.2f line accesses per clock per CU (ceiling ~1)" % pmc["l1_line_accesses_per_clk_per_cu"])
+    if pmc.get("ta_busy_frac") is not None:
+        parts.append("TA busy %.0f %%" % (100.0 * pmc["ta_busy_frac"]))
+    if pmc.get("hbm_bytes_per_launch") and pmc.get("avg_launch_us_rocprof"):
+        parts.append("HBM traffic %.2f TB/s of 8" % (pmc["hbm_bytes_per_launch"] / pmc["avg_launch_us_rocprof"] / 1e6))
+    return "; ".join(parts)
 
 
 _T0 = time.time()
@@ -287,7 +301,8 @@ def main():
         tot_ms, launches = spans[span]
         avg_ms = tot_ms / launches
         achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
-        traffic, valu_busy = read_traffic("%s_nx%d" % (solver, args.nx))
+        pmc = read_traffic("%s_nx%d" % (solver, args.nx))         # None unless measured on exactly this source tree
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         flops = RATE_KERNEL_FLOP_PER_PAIR * nb_free_fall["pairs"] / (avg_ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s')" % span,
                               "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -296,10 +311,9 @@ def main():
                               "algorithmic_bytes_per_launch": RATE_KERNEL_BYTES_PER_PARTICLE * n,
                               "valu": {"pairs_per_launch": nb_free_fall["pairs"], "flop_per_pair_model": RATE_KERNEL_FLOP_PER_PAIR,
                                        "achieved_TFLOPs": flops, "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
-                                       "valu_busy_frac_pmc": valu_busy},
-                              "limiter": "VALU issue (bit-exact IEEE pair arithmetic, ~97 % of the issue slots) with the quad-per-particle "
-                                         "walk; the lane-per-particle walk it replaced was bound by the L1's line-access rate "
-                                         "(profiles/r02_ubench_sweep_structure.txt, profiles/r02_ubench_quad_walk.txt)"}
+                                       "valu_issue_frac_pmc": pmc.get("valu_issue_frac") if pmc else None,
+                                       "valu_instr_per_simd_per_clk_pmc": pmc.get("valu_instr_per_simd_per_clk_raw") if pmc else None},
+                              "limiter": limiter_text(pmc)}
     else:
         result["roofline"] = None
 

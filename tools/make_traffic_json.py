@@ -12,9 +12,11 @@ entry = {
     "hbm_bytes_per_launch": src["hbm_bytes_fetch_x2"],
     "fetch_size_raw_bytes": src["FETCH_SIZE"], "write_size_bytes": src["WRITE_SIZE"],
     "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes); separate --pmc passes",
-    "valu_busy_frac": min(1.0, src["valu_busy_frac"]) if src.get("valu_busy_frac") is not None else None,
-    "valu_busy_note": "SQ_ACTIVE_INST_VALU x4 / (kernel cycles x 1024 SIMDs), capped at 1 (raw %.3f); VALU issue slots SQ_INSTS_VALU x4 / same = %.3f"
-                      % (src.get("valu_busy_frac") or 0.0, src.get("valu_issue_frac") or (src.get("SQ_INSTS_VALU", 0.0) * 4.0 / (src.get("kernel_cycles", 1.0) * 1024.0))),
+    "valu_issue_frac": src.get("valu_issue_frac"),
+    "valu_instr_per_simd_per_clk_raw": src.get("valu_instr_per_simd_per_clk_raw"),
+    "valu_note": "SQ_INSTS_VALU x 2.3 clk / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); 2.3 clk per wave64 fp32 instruction calibrated in "
+                 "profiles/r03_valu_calibration.txt (never clipped; the raw instructions per SIMD per clock are given beside it)",
+    "sq_insts_valu_per_launch": src.get("SQ_INSTS_VALU"),
     "ta_busy_frac": src.get("ta_busy_frac"),
     "l1_hit_rate": 1.0 - src["TCP_TCC_READ_REQ_sum"] / src["TCP_TOTAL_CACHE_ACCESSES_sum"] if "TCP_TCC_READ_REQ_sum" in src else None,
     "l1_line_accesses_per_clk_per_cu": src.get("l1_line_accesses_per_clk_per_cu"),

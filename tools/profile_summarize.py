@@ -7,6 +7,7 @@ import os
 import sys
 from collections import defaultdict
 
+VALU_CLK_PER_INSTR = 2.3      # profiles/r03_valu_calibration.txt
 out, tag = sys.argv[1], sys.argv[2]
 bench_args = sys.argv[3:]
 
@@ -78,13 +79,16 @@ for sub in ("valu", "cache"):
 if traffic:
     kr = traffic["k_rate_density"]
     kr.update(extra)
-    if "SQ_ACTIVE_INST_VALU" in extra and extra.get("GRBM_GUI_ACTIVE"):
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs
+    if "SQ_INSTS_VALU" in extra and extra.get("GRBM_GUI_ACTIVE"):
+        # Calibration (profiles/r03_valu_calibration.txt, tools/valu_calib.hip): SQ_INSTS_VALU = 1 per issued wave64 VALU
+        # instruction; GRBM_GUI_ACTIVE / 8 XCDs = elapsed shader clocks; a non-packed fp32 instruction occupies its SIMD for
+        # 2.3 clocks when nothing else limits it (packed ones twice that; not distinguished by the counter);
+        # SQ_ACTIVE_INST_VALU reads like SQ_INSTS_VALU on gfx950 and is NOT a busy-cycle count (r01/r02 used it as one).
         cycles = extra["GRBM_GUI_ACTIVE"] / 8.0
         kr["kernel_cycles"] = cycles
-        kr["valu_busy_frac"] = extra["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
-        if "SQ_INSTS_VALU" in extra:       # issue slots: one wave64 VALU instruction occupies a SIMD for 4 clocks
-            kr["valu_issue_frac"] = extra["SQ_INSTS_VALU"] * 4.0 / (cycles * 1024.0)
+        kr["valu_clocks_per_instruction_calibrated"] = VALU_CLK_PER_INSTR
+        kr["valu_instr_per_simd_per_clk_raw"] = extra["SQ_INSTS_VALU"] / (cycles * 1024.0)
+        kr["valu_issue_frac"] = extra["SQ_INSTS_VALU"] * VALU_CLK_PER_INSTR / (cycles * 1024.0)
         stats = find("stats", "*kernel_stats.csv")
         us = None
         if stats:
