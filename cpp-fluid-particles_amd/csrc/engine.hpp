@@ -82,6 +82,7 @@ struct SweepCache {
     int flags = 0;
     int quadMask = 1;                        // QuadBits (sweep_ops.hpp): sweeps that run quad-per-particle when rows exist
     int duoMask = 0;                         // QuadBits: sweeps that run with two lanes per particle
+    int quadMaskTol = 511;                   // tolerance arithmetic: quad walks with per-lane partial sums + one DPP reduction pay off in every sweep
     // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
     // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
     unsigned int generation = 0;

@@ -533,6 +533,7 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
     if (const char* e = getenv("SPHX_DUO_MASK")) duoMask = atoi(e);            // ... and which with two lanes per particle
+    if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
 }
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
@@ -618,7 +619,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.nbrCount = nbrCount.addr();
     c.cap = cap;
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
-    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? quadMask : 0;
+    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? quadMaskTol : quadMask) : 0;
     c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? duoMask : 0;
     c.n = n;
     c.vel4 = vel4w();

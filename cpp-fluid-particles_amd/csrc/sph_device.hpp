@@ -799,6 +799,16 @@ __device__ __forceinline__ void quad_accumulate(Body& body, Body& term, const bo
     });
 }
 
+// tolerance walks: butterfly sum of the 4 lanes' partial sums; afterwards every lane of the quad holds the total
+template <class Body>
+__device__ __forceinline__ void quad_reduce(Body& body)
+{
+    body.each_acc(body, [](float& a, float&) {
+        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0xB1, 0xf, 0xf, true));      // quad_perm:[1,0,3,2]
+        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0x4E, 0xf, 0xf, true));      // quad_perm:[2,3,0,1]
+    });
+}
+
 // U consecutive chunks [s, s + U) of the quad's row, straight-line: all row loads, then all gathers, then the terms in
 // order.  (No early exit inside: a conditional between the chunks makes the compiler sink each chunk's loads next to
 // their use, and the walk becomes load -> wait -> compute per chunk.)
@@ -843,6 +853,23 @@ __device__ __forceinline__ void quad_chunks(const Op& op, const SweepCtx& c, con
             return;
         }
     }
+    if constexpr (TOL) {
+        // tolerance arithmetic: the order of a particle's sum is free, so every lane of the quad keeps its OWN partial sums
+        // (entries 4s + g) and the quad adds them up once at the end (quad_reduce: two DPP steps per accumulator) instead of
+        // the 4 ordered adds per entry of the strict walk.  A dropped entry enters with mass 0: every pair_tol term carries
+        // the neighbour's mass as a factor.
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool isB = (e[u] & kBoundaryBit) != 0u;
+            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+            const float r2 = dot3(d, d);
+            bool use = ok[u];
+            if (!WANT_BOUNDARY && isB) use = false;
+            if (SKIN && r2 > c.k.tCut) use = false;
+            body.pair_tol(f[u], isB, d, r2, use ? pj[u].w : 0.0f);
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool isB = (e[u] & kBoundaryBit) != 0u;
@@ -876,6 +903,7 @@ __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, c
     int s = 0;
     for (; s + U <= steps; s += U) quad_chunks<U, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowq, cnt, s, m0, allPlain, pi, body);
     for (; s < steps; ++s) quad_chunks<1, PACKED, WANT_BOUNDARY, SKIN, TOL>(op, c, rowq, cnt, s, m0, allPlain, pi, body);
+    if constexpr (TOL) quad_reduce(body);
 }
 
 // The particle of this lane's quad in a quad-per-particle launch: one block of 4 waves per tile, wave w takes the

@@ -264,14 +264,17 @@ struct OpSurface {
                             o.airPressure * m2 * tol_gradW_scale(t, o.c.k) * li * __builtin_amdgcn_rcpf(ml);
             a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
+    static constexpr int kQuadBit = kQuadSurface;
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body b{*this, sc, sc.dii, sc.li, sc.ml, v3(0, 0, 0)};
-        sweep<false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!valid) return;
+        sweep_any<QUAD, false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!stores_results<QUAD>(valid)) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
         const float3 vn = add3(v, mul3s(b.a, dt));
@@ -327,14 +330,20 @@ struct OpSurfaceThen {
             const float sb = (NEXT == 1 ? mj : -mj) * (si + f.s) * g;
             b = v3(b.x + d.x * sb, b.y + d.y * sb, b.z + d.z * sb);
         }
+        template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
+        {
+            f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); f(b.x, other.b.x); f(b.y, other.b.y); f(b.z, other.b.z);
+        }
     };
+    static constexpr int kQuadBit = kQuadSurface;
+    template <int QUAD = 0>
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body body{*this, sc, sc.dii, sc.li, sc.ml, valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
-        if (!valid) return;
+        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
+        if (!stores_results<QUAD>(valid)) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
         const float3 vs = add3(v, mul3s(body.a, dt));                 // what the surface sweep alone would have stored
