@@ -30,6 +30,7 @@ GridDesc make_grid_desc(int3 cellSize, float cellLength, int cellOffsetX = 0);
 // kFlagTiles: LDS-streamed tiles (sph_device.hpp, entry format 2)
 // kFlagLinearTiles: launch tiles in array order instead of the (y-chunk, x) schedule
 // kFlagNoQuad: lane-per-particle walks everywhere (no quad-per-particle sweep variants)
+constexpr int kQuadSurfaceBit = 256;      // = kQuadSurface (sweep_ops.hpp)
 enum EngineFlags { kFlagUnfused = 1, kFlagNoList = 2, kFlagTiles = 4, kFlagLinearTiles = 8, kFlagNoQuad = 16 };
 
 // The neighbour rows are the one array that outgrows DArray's 32-bit element count (cap = 96 entries per particle:

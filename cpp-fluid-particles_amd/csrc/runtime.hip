@@ -416,113 +416,6 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 }
 
 
-// ---- cooperative row builder (r03) ------------------------------------------------------------------------------------------
-// EIGHT lanes per particle.  The lane-per-particle builder above has every lane walk its own candidate runs: a wave's load
-// touches ~64 different cache lines and the kernel sits on the vector L1 / TA path (r02: 1.77 ms at 10 M particles, TA busy
-// 88 %).  Here the 8 lanes of a group test 8 CONSECUTIVE candidates of their particle's run -- one 128-byte line per group and
-// load, 8 lines per wave instruction -- and append the accepted ones in lane order (ballot + prefix count), which is exactly
-// the visit order of the reference walk (dx, dy, dz; per cell fluid then boundary; ascending index): the rows are bit for bit
-// the rows of the other builders.  The candidate runs of a particle (one per (dx,dy) column when the column holds no boundary
-// particles, else fluid and boundary per cell) are flattened through a small per-group segment table, rows are staged in LDS
-// and leave as whole 16-byte chunks: the 8 particles of a wave complete one 128-byte line per chunk index.
-constexpr int kCoopLanes = 8;
-constexpr int kCoopMaxSeg = 54;                 // 9 columns x 3 cells x (fluid, boundary)
-constexpr int kCoopMaxCap = 128;                // row capacities above this use the lane-per-particle builder
-struct CoopGroup { int segEnd[kCoopMaxSeg + 2]; int segBase[kCoopMaxSeg + 2]; };   // running end offset, unified index of the first candidate (bit 31: boundary)
-
-__global__ void __launch_bounds__(kWideBlock) k_build_list_coop(SweepCtx c, unsigned int* nbr, int* nbrCount, float4* posBuild, int* rowCell,
-                                                                const int* flagNow, int* flagNext, int* rebuilds)
-{
-    constexpr int kGroups = kWideBlock / kCoopLanes;        // 32 particles per block
-    __shared__ CoopGroup table[kGroups];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[kGroups][kCoopMaxCap];
-    if (flagNext && blockIdx.x == 0 && threadIdx.x == 0) {
-        *flagNext = 0;
-        if (rebuilds && *flagNow != 0) *rebuilds += 1;
-    }
-    if (flagNow && *flagNow == 0) return;      // launch-uniform
-    // block -> half a tile, in the tile schedule of the sweeps (wave_tile)
-    const int lb = logical_block();
-    const int lt = lb >> 1;
-    if (lt >= c.numTiles) return;
-    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
-    const int grp = threadIdx.x / kCoopLanes, g = threadIdx.x % kCoopLanes;
-    const int i = tile * kTile + (lb & 1) * kGroups + grp;
-    const bool valid = i < c.n && in_range(c, i);
-    const float4 self = valid ? c.posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float3 pi = v3(self.x, self.y, self.z);
-    CoopGroup& T = table[grp];
-    // ---- segment table (every lane of the group computes the same values; lane 0 writes)
-    int nseg = 0, total = 0;
-    if (valid) {
-        const int3 c0 = cell_of(pi, c.g);
-        const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int X = c0.x + dx;
-            if (X < 0 || X >= c.g.gx || zlo > zhi) continue;
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int Y = c0.y + dy;
-                if (Y < 0 || Y >= c.g.gy) continue;
-                const int base = (X * c.g.gy + Y) * c.g.gz;
-                const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
-                if (noWall) {
-                    const int a = c.csF[base + zlo], b = c.csF[base + zhi + 1];
-                    if (b > a) { total += b - a; if (g == 0) { T.segEnd[nseg] = total; T.segBase[nseg] = a; } ++nseg; }
-                } else {
-                    for (int z = zlo; z <= zhi; ++z) {
-                        const int a = c.csF[base + z], b = c.csF[base + z + 1];
-                        if (b > a) { total += b - a; if (g == 0) { T.segEnd[nseg] = total; T.segBase[nseg] = a; } ++nseg; }
-                        const int ab = c.csB[base + z], bb = c.csB[base + z + 1];
-                        if (bb > ab) { total += bb - ab; if (g == 0) { T.segEnd[nseg] = total; T.segBase[nseg] = (int)(0x80000000u | (unsigned)ab); } ++nseg; }
-                    }
-                }
-            }
-        }
-    }
-    if (g == 0) { T.segEnd[nseg] = 0x7fffffff; T.segBase[nseg] = 0; }       // sentinel: lanes past the end stay here
-    wave_lds_fence();
-    // ---- flattened walk: candidate t of the particle is tested by lane t % 8 of its group
-    int seg = 0, segStart = 0, segEnd = T.segEnd[0], segBase = T.segBase[0];
-    int cnt = 0;
-    const int cap = min(c.cap, kCoopMaxCap);
-    const unsigned int groupShift = (unsigned)((threadIdx.x & 63) & ~(kCoopLanes - 1));
-    const unsigned int below = (1u << g) - 1u;
-    for (int t0 = 0; __any(t0 < total); t0 += kCoopLanes) {
-        const int t = t0 + g;
-        while (t >= segEnd) { segStart = segEnd; ++seg; segEnd = T.segEnd[seg]; segBase = T.segBase[seg]; }
-        const bool live = t < total;
-        const bool isB = segBase < 0;
-        const int j = (segBase & 0x7fffffff) + (t - segStart);
-        const unsigned int u = (unsigned)j + (isB ? (unsigned)c.bOff : 0u);          // unified index [fluid | boundary]
-        const float4 pj = gather16(c.posm, (live ? u : 0u) << 4);
-        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
-        const float r2 = dot3(d, d);
-        const bool accept = live && !(r2 > c.buildCut) && (int)u != i;
-        const unsigned long long mask = __ballot(accept);
-        const unsigned int m8 = (unsigned int)(mask >> groupShift) & 0xffu;
-        if (accept) {
-            const int at = cnt + __popc(m8 & below);
-            if (at < cap) stage[grp][at] = u | (isB ? kBoundaryBit : 0u) | (pair_needs_plain_ops(d, r2) ? kPlainBit : 0u);
-        }
-        cnt += __popc(m8);
-    }
-    wave_lds_fence();
-    if (!valid) return;
-    if (g == 0) {
-        nbrCount[i] = cnt;
-        if (posBuild) {
-            posBuild[i] = self;
-            const int3 c0 = cell_of(pi, c.g);
-            rowCell[i] = cell_id(c0.x, c0.y, c0.z, c.g);
-        }
-    }
-    // rows leave as 16-byte chunks; for one chunk index the 8 particles of a wave fill one 128-byte line
-    unsigned int* row = nbr + row_base_offset(i, c.cap);
-    const int chunks = (min(cnt, cap) + kRowChunk - 1) / kRowChunk;
-    for (int sChunk = g; sChunk < chunks; sChunk += kCoopLanes)
-        *reinterpret_cast<uint4*>(row + (size_t)sChunk * 256u) = *reinterpret_cast<const uint4*>(&stage[grp][sChunk * kRowChunk]);
-}
-
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
@@ -619,7 +512,9 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.nbrCount = nbrCount.addr();
     c.cap = cap;
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
-    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? quadMaskTol : quadMask) : 0;
+    // (strict: the surface sweeps add TWO terms per entry to one accumulator, (a + t1) + t2, which the ordered one-term-per-lane
+    // accumulation of the quad walk cannot reproduce: they stay lane-per-particle whatever the mask says)
+    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? quadMaskTol : (quadMask & ~kQuadSurfaceBit)) : 0;
     c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? duoMask : 0;
     c.n = n;
     c.vel4 = vel4w();
@@ -690,13 +585,6 @@ void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& cs
 void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext)
 {
     unsigned int* rows = nbr->rows;
-    static const bool coop = [] { const char* e = getenv("SPHX_BUILD_COOP"); return !e || atoi(e) != 0; }();
-    if (coop && cap <= kCoopMaxCap && !(allowTiles && (flags & kFlagTiles))) {
-        // two blocks of 32 particles per tile
-        k_build_list_coop<<<xcd_grid(c.numTiles * 2 * kWideBlock, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), posBuildOut,
-                                                                                                        rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
-        return;
-    }
     if (allowTiles && (flags & kFlagTiles))
         k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
     else

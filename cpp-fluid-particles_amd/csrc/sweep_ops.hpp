@@ -33,10 +33,19 @@ template <class Op> __host__ __device__ constexpr int op_quad_bit_impl(long) { r
 template <class Op> __host__ __device__ constexpr int op_quad_bit() { return op_quad_bit_impl<Op>(0); }
 
 // MODE: 0 lane per particle, 1 quad per particle, 2 duo (two lanes per particle)
-template <class Op, bool STREAM, int MODE = 0>
+// TOLK (quad / duo launches): 0 strict arithmetic, 1 tolerance arithmetic -- the two walks live in separate kernels so that
+// neither pays for the other's registers (sharing one kernel cost the strict rate sweep 40 bytes of scratch and 50 % of its
+// speed when the tolerance walk changed, r03); -1: decided at run time from SweepCtx::k.tol (lane-per-particle launches)
+template <int TOLK> __device__ __forceinline__ void assume_arith(const SweepCtx& c)
+{
+    if constexpr (TOLK == 0) __builtin_assume(c.k.tol == 0);
+    if constexpr (TOLK == 1) __builtin_assume(c.k.tol != 0);
+}
+template <class Op, bool STREAM, int MODE = 0, int TOLK = -1>
 __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op op, int n)
 {
     (void)n;
+    assume_arith<TOLK>(op.c);
     if constexpr (MODE != 0) {
         const int i = MODE == 1 ? quad_particle(op.c) : duo_particle(op.c);
         if (i < 0) return;
@@ -74,7 +83,10 @@ inline void launch_op(const Op& op, int n)
     if (n <= 0 || op.c.numTiles <= 0) return;
     if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
     else if constexpr (op_quad_bit<Op>() != 0) {
-        if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) k_run_op<Op, false, 1><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+        if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) {
+            if (op.c.k.tol) k_run_op<Op, false, 1, 1><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+            else k_run_op<Op, false, 1, 0><<<quad_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
+        }
         else if (op.c.nbr && (op.c.duo & op_quad_bit<Op>())) k_run_op<Op, false, 2><<<duo_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
         else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
     } else k_run_op<Op, false><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
@@ -514,9 +526,10 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     }
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
-template <bool WITH_RATE, int MODE>
+template <bool WITH_RATE, int MODE, int TOLK = -1>
 __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_group(const OpDfsphHeadT<WITH_RATE> o, int n)
 {
+    assume_arith<TOLK>(o.c);
     const int i = MODE == 1 ? quad_particle(o.c) : duo_particle(o.c);
     if (i < 0) return;
     (void)n;
@@ -538,7 +551,10 @@ inline void launch_dfsph_head(const OpDfsphHeadT<WITH_RATE>& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-    else if (o.c.nbr && (o.c.quad & kQuadHead)) k_dfsph_head_group<WITH_RATE, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.quad & kQuadHead)) {
+        if (o.c.k.tol) k_dfsph_head_group<WITH_RATE, 1, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+        else k_dfsph_head_group<WITH_RATE, 1, 0><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    }
     else if (o.c.nbr && (o.c.duo & kQuadHead)) k_dfsph_head_group<WITH_RATE, 2><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_dfsph_head<WITH_RATE, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }
@@ -579,9 +595,13 @@ struct OpRate {
 #ifndef SPHX_QUAD_WAVES
 #define SPHX_QUAD_WAVES 8      // waves per SIMD the register budget is cut for (64 VGPRs, 16 bytes of scratch): measured 4 % faster than 7
 #endif
-template <bool DENSITY_MODE, int WARM>
-__global__ void __launch_bounds__(kWideBlock, SPHX_QUAD_WAVES) k_rate_quad(const OpRate o, int n)
+#ifndef SPHX_QUAD_WAVES_TOL
+#define SPHX_QUAD_WAVES_TOL 6  // the tolerance walk keeps 4 chunks of partial state live: 6 waves per SIMD (80 VGPRs) avoid its scratch
+#endif
+template <bool DENSITY_MODE, int WARM, int TOLK>
+__global__ void __launch_bounds__(kWideBlock, TOLK == 1 ? SPHX_QUAD_WAVES_TOL : SPHX_QUAD_WAVES) k_rate_quad(const OpRate o, int n)
 {
+    assume_arith<TOLK>(o.c);
     const int i = quad_particle(o.c);
     if (i < 0) return;
     (void)n;
@@ -629,7 +649,10 @@ inline void launch_rate_kernel(const OpRate& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-    else if (o.c.nbr && (o.c.quad & kQuadRate)) k_rate_quad<DENSITY_MODE, WARM><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.quad & kQuadRate)) {
+        if (o.c.k.tol) k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+        else k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    }
     else if (o.c.nbr && (o.c.duo & kQuadRate)) k_rate_duo<DENSITY_MODE, WARM><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
 }

@@ -134,7 +134,7 @@ def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
     (SPHX_QUAD_MASK; the default switches it on for the DFSPH rate sweeps only) and two-lanes-per-particle walks
     (SPHX_DUO_MASK; off by default) all produce the oracle's bits."""
     if cap and cap.startswith("quad-all"):
-        monkeypatch.setenv("SPHX_QUAD_MASK", "511")
+        monkeypatch.setenv("SPHX_QUAD_MASK", "255")
         cap = cap[9:] or None
     if cap and cap.startswith("duo-all"):        # two lanes per particle in every sweep that has the variant
         monkeypatch.setenv("SPHX_QUAD_MASK", "0")

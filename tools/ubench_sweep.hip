@@ -272,6 +272,47 @@ __global__ void __launch_bounds__(256) k_qg(Consts c, const float4* __restrict__
     if (ip < n && (lane % G) == 0) out[i] = e;
 }
 
+
+// ---- QGI: the quad walk (G = 4, E = 1) on 32-byte interleaved (position | velocity) records: the two gathers of a pair fall
+// into the same 128-byte line, and the 4 consecutive records of a quad are ONE line instead of two half lines
+template <int U, bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_qgi(Consts c, const float4* __restrict__ pv, const unsigned int* __restrict__ rows,
+                                             const int* __restrict__ tileSteps, float* __restrict__ out, int n, int numTilesQ, int capSteps)
+{
+    constexpr int G = 4, PPW = 16;
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTilesQ) return;
+    const int lane = threadIdx.x & 63;
+    const int ip = tile * PPW + lane / G;
+    const int i = min(ip, n - 1);
+    const float4 self = pv[2 * i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = pv[2 * i + 1];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const unsigned int* row = rows + ((size_t)tile * capSteps) * 64u + (unsigned)lane;
+    const int steps = tileSteps[tile];
+    float e = 0.0f;
+    for (int s = 0; s < steps; s += U) {
+        unsigned int idx[U];
+        float4 pj[U], vj[U];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = (s + u < steps) ? row[(size_t)(s + u) * 64u] : (unsigned)n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = gather16(pv, idx[u] << 5);
+            vj[u] = TWO ? gather16(pv, (idx[u] << 5) + 16u) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) e += group_term<G>(t[u], g, lane);
+    }
+    if (ip < n && (lane % G) == 0) out[i] = e;
+}
+
 // ---- CQ: lane-per-particle arithmetic and accumulation (as G32c), but the gathers are issued quad-cooperatively: in
 // gather k the 4 lanes of a quad fetch the 4 entries of particle k of the quad (adjacent records), park them in LDS and
 // every lane then reads its own 4 records back.  Rows in the engine's chunk layout: [tile][chunk][lane][4].
@@ -737,6 +778,17 @@ int main(int argc, char** argv)
                 });
 #undef LQ2
 #undef LQ
+            }
+            {   // the quad walk on interleaved records (rows of the Q4x1 u4 set)
+                const QSet& Q = qsets[1];
+                const unsigned gridQ = xcd_grid(Q.numTiles * 64, 256);
+                snprintf(nm, sizeof(nm), "Q4x1 u4 interleaved %s %s", exact ? "exact" : "tol", two ? "2f" : "1f");
+                run(nm, exact, two, [&] {
+                    if (exact) { if (two) hipLaunchKernelGGL((k_qgi<4, true, true>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
+                                 else hipLaunchKernelGGL((k_qgi<4, true, false>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
+                    else { if (two) hipLaunchKernelGGL((k_qgi<4, false, true>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
+                           else hipLaunchKernelGGL((k_qgi<4, false, false>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
+                });
             }
             for (int v = 0; v < ((argc > 5 && argv[3][0] != 'b') ? 2 : 0); ++v) {
                 const int T = sets[v].T, slots = sets[v].slots + 1;
