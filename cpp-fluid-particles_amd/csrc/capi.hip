@@ -286,6 +286,13 @@ int sphx_row_stats(const sphx_system* h, long long* total, int* longest, int* hi
     return SPHX_OK;
 }
 
+int sphx_row_capacity(const sphx_system* h, int* capacity)
+{
+    if (!h || !h->wcsph || !capacity) return fail(SPHX_ERR_INVALID, "sphx_row_capacity: bad argument");
+    *capacity = h->wcsph->engineRowCapacity();
+    return SPHX_OK;
+}
+
 int sphx_rows_stale(const sphx_system* h, int* stale)
 {
     if (!h || !h->wcsph || !stale) return fail(SPHX_ERR_INVALID, "sphx_rows_stale: bad argument");

@@ -79,11 +79,21 @@ struct SweepCache {
     int nbCap = 0;                           // boundary slots currently reserved
     int nb = 0;
     int cap = 96;
+    // Row capacity.  Fixed (SPHX_NBR_CAP, slabs: 96) or adaptive: rows start at 48 entries per particle -- the lattice needs 32,
+    // the settled dam-break 42-46 -- the builder records the longest row that did not fit (such a particle walks the
+    // cells directly meanwhile: same bits, slower), and between steps the host enlarges the rows to that length + 8.  Halves
+    // the row slab (192 instead of 384 bytes per particle).
+    bool capAuto = false;
+    DArray<int> rowOverflow;                 // [0]: longest row beyond `cap` since the last check
+    int capCheckSteps = 0;
+    void tuneRowCapacity(int stepsSinceLastCall);
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)
     int flags = 0;
     int quadMask = 1;                        // QuadBits (sweep_ops.hpp): sweeps that run quad-per-particle when rows exist
     int duoMask = 0;                         // QuadBits: sweeps that run with two lanes per particle
-    int quadMaskTol = 511;                   // tolerance arithmetic: quad walks with per-lane partial sums + one DPP reduction pay off in every sweep
+    int quadMaskTol = 15;                    // tolerance arithmetic, quad walks with per-lane partial sums + one DPP reduction (r03, 10.3 M particles):
+                                             // head -11 %, viscosity+colour -26 %, corrections -2..4 %; the surface sweeps (3 gathers, ~100 VGPRs)
+                                             // lose 5x and stay lane-per-particle.  Below 4 M particles the corrections stay lane-per-particle too (mask & 7)
     // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
     // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
     unsigned int generation = 0;

@@ -51,6 +51,7 @@ void PBDSolver::configureSkin(float radius)
 
 void PBDSolver::tune(int stepsSinceLastCall)
 {
+    BasicSPHSolver::tune(stepsSinceLastCall);
     SweepCache& c = cache();
     if (c.isSlab || getenv("SPHX_PBD_SKIN_FIXED")) return;
     tuneSteps += stepsSinceLastCall;

@@ -420,9 +420,10 @@ SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
-      staleFlag(3u)
+      staleFlag(3u), rowOverflow(2u)
 {
-    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; }   // rows are stored in chunks of 4
+    capAuto = true; cap = 48;
+    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
     if (const char* e = getenv("SPHX_DUO_MASK")) duoMask = atoi(e);            // ... and which with two lanes per particle
@@ -514,7 +515,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
     // (strict: the surface sweeps add TWO terms per entry to one accumulator, (a + t1) + t2, which the ordered one-term-per-lane
     // accumulation of the quad walk cannot reproduce: they stay lane-per-particle whatever the mask says)
-    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? quadMaskTol : (quadMask & ~kQuadSurfaceBit)) : 0;
+    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? (n >= 4000000 ? quadMaskTol : (quadMaskTol & 7)) : (quadMask & ~kQuadSurfaceBit)) : 0;
     c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? duoMask : 0;
     c.n = n;
     c.vel4 = vel4w();
@@ -535,7 +536,26 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.buildCut = k.tCut;
     if (skinRows && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
+    c.overflowMax = nullptr;
     return c;
+}
+
+// Adaptive row capacity: called between steps (never inside a captured graph).  One 4-byte read every 8+ steps.
+void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
+{
+    if (!capAuto || !nbr) return;
+    capCheckSteps += stepsSinceLastCall;
+    if (capCheckSteps < 8) return;
+    capCheckSteps = 0;
+    int longest = 0;
+    HIP_CALL(hipMemcpyAsync(&longest, rowOverflow.addr(), sizeof(int), hipMemcpyDeviceToHost, stream()));
+    HIP_CALL(hipStreamSynchronize(stream()));
+    if (longest <= cap) return;
+    cap = std::min(1024, (longest + 8 + kRowChunk - 1) / kRowChunk * kRowChunk);
+    HIP_CALL(hipMemsetAsync(rowOverflow.addr(), 0, sizeof(int), stream()));
+    nbr.reset();                               // reallocated by the next ensureList
+    listValid = false;
+    ++generation;
 }
 
 void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
@@ -551,7 +571,7 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     rangeLo = rangeHi = -1;                    // rows are always built for every particle
     SweepCtx c = ctx(csF, csB);
     rangeLo = keepLo; rangeHi = keepHi;
-    c.nbr = nullptr;
+    c.nbr = nullptr; c.overflowMax = rowOverflow.addr();
     listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");
     const bool skinMode = skinRows && skin > 0.0f;
@@ -575,7 +595,7 @@ void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& cs
     if (!nbr || nbr->entries < entries) { nbr.reset(); nbr.reset(new RowStore(entries)); ++generation; }
     listValid = false;                         // ctx() must hand out the live cell tables
     SweepCtx c = ctx(csF, csB);                // keeps the launch range
-    c.nbr = nullptr;
+    c.nbr = nullptr; c.overflowMax = rowOverflow.addr();
     listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");
     if (c.numTiles > 0) launchBuild(c, nullptr, nullptr, nullptr);
@@ -599,7 +619,7 @@ void SweepCache::rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB)
     rangeLo = rangeHi = -1;
     SweepCtx c = ctx(csF, csB);
     rangeLo = keepLo; rangeHi = keepHi;
-    c.nbr = nullptr; c.stale = nullptr;
+    c.nbr = nullptr; c.stale = nullptr; c.overflowMax = rowOverflow.addr();
     ScopedKernel t("rebuild_rows_if_stale");
     launchBuild(c, reinterpret_cast<float4*>(posBuild->addr()), staleFlag.addr(activeFlag), staleFlag.addr(activeFlag ^ 1));
     activeFlag ^= 1;

@@ -473,6 +473,7 @@ struct SweepCtx {
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
     int n;
+    int* overflowMax;                       // row builder only: longest row that did not fit `cap` (atomicMax; nullptr otherwise)
 };
 
 // The tile (64 consecutive particles) this wave works on.  Launch order is a free choice — results
@@ -1215,6 +1216,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
         if (streamed) wave_lds_fence();
     }
     if (valid) nbrCount[i] = cnt;
+    if (valid && cnt > c.cap && c.overflowMax) atomicMax(c.overflowMax, cnt);     // (rare: the host enlarges the rows, SweepCache::tuneRowCapacity)
     if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
     if (stage) {                                  // one coalesced 1 KB store per chunk index (slots past a row's end hold
         wave_lds_fence();                         // stale stage contents: readers never look past nbrCount)

@@ -27,6 +27,7 @@ void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; _cache->listValid = false; ++_cache->generation; }
 unsigned int BasicSPHSolver::graphGeneration() const { return _cache->generation; }
 void BasicSPHSolver::prepareForCapture() { _cache->orderAge = 1 << 20; _cache->orderValid = false; }
+void BasicSPHSolver::tune(int stepsSinceLastCall) { _cache->tuneRowCapacity(stepsSinceLastCall); }
 void BasicSPHSolver::setToleranceArithmetic(bool on) { _cache->tolerance = on; ++_cache->generation; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }
 void* BasicSPHSolver::engineCg4() const { return _cache->cg4.addr(); }
@@ -34,11 +35,16 @@ void* BasicSPHSolver::enginePterm() const { return _cache->pterm.addr(); }
 void* BasicSPHSolver::enginePos4() const { return _cache->posm.addr(); }
 void* BasicSPHSolver::enginePosf() const { return _cache->posf.addr(); }
 const int* BasicSPHSolver::engineRowCounts() const { return _cache->nbrCount.addr(); }
+int BasicSPHSolver::engineRowCapacity() const { return _cache->cap; }
 const int* BasicSPHSolver::engineStaleFlag() const { return (_cache->skinRows && _cache->skin > 0.0f) ? _cache->staleFlag.addr(2) : nullptr; }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
 void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }
-void BasicSPHSolver::setCellOffsetX(int cellOffsetX) { _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true; }
+void BasicSPHSolver::setCellOffsetX(int cellOffsetX)
+{
+    _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true;
+    if (_cache->capAuto) { _cache->capAuto = false; _cache->cap = 96; }      // slabs are stepped stage by stage (no tune() calls): fixed rows
+}
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G
 void BasicSPHSolver::force(std::shared_ptr<SPHParticles>& fluids, float dt, float3 G)

@@ -33,7 +33,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
-    "sphx_get_params", "sphx_row_stats", "sphx_rows_stale", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
+    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -109,6 +109,7 @@ def lib():
         L.sphx_snapshot_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.sphx_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.sphx_row_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p]
+        L.sphx_row_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
         L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.sphx_sizeof_params() != C.sizeof(Params):
@@ -378,6 +379,12 @@ class SlabGroup:
             self.close()
         except Exception:
             pass
+
+
+def row_capacity(system):
+    cap = C.c_int()
+    _check(lib().sphx_row_capacity(system._h, C.byref(cap)))
+    return cap.value
 
 
 def use_stream(hip_stream_handle):

@@ -30,6 +30,7 @@ public:
     bool graphSafe() const override { return true; }
     unsigned int graphGeneration() const override;
     void prepareForCapture() override;
+    void tune(int stepsSinceLastCall) override;      // engine: adaptive neighbour-row capacity
     // engine extensions: the colour gradient left by handleSurface(), and engine switches used by
     // the tests (bit 0: run the reference-structure, unfused sequence of building blocks;
     // bit 1: walk the 27 cells directly instead of the per-step neighbour list;
@@ -49,6 +50,7 @@ public:
     void* enginePosf() const;
     // per-particle neighbour-row lengths of the most recent row build (bench statistics)
     const int* engineRowCounts() const;
+    int engineRowCapacity() const;
     const int* engineStaleFlag() const;     // device counter of conditional skin-row rebuilds (nullptr when not in use)
     // reserve the boundary part of the engine's unified neighbour arrays (called once by SPHSystem
     // before any engine pointer is handed out; otherwise done lazily by the first step)

@@ -195,6 +195,8 @@ int  sphx_get_params(const sphx_system *sys, sphx_params *out);
 /* neighbour statistics of the most recent row build (bench.py reports them beside the timings): total
  * accepted pairs, longest row, histogram of row lengths (bin 127 = 127 and more; may be NULL)   */
 int  sphx_row_stats(const sphx_system *sys, long long *total_pairs, int *longest_row, int *hist128);
+/* current capacity (entries per particle) of the neighbour rows: 96 fixed for slabs / SPHX_NBR_CAP, else adaptive from 48 */
+int  sphx_row_capacity(const sphx_system *sys, int *capacity);
 /* PBD diagnostics: how many times since creation the once-per-step neighbour rows had to be rebuilt inside a step because
  * a particle moved farther than their skin allows (decided and done on the device; always 0 for other solvers)      */
 int  sphx_rows_stale(const sphx_system *sys, int *rebuilds);

@@ -550,10 +550,12 @@ def test_10m_path_smoke(sphx):
     s.close()
 
 
-def test_rows_beyond_32bit_entry_count(sphx):
-    """49,152,000 particles (nx = 320): cap x particles = 4.7e9 row entries, past a 32-bit element count (the row
-    store has a 64-bit length; round 1 fell back to direct walks beyond 44.7 M particles).  Two WCSPH steps through
-    the rows equal two steps of direct 27-cell walks (engine flag 2, oracle-checked at small sizes) bit for bit."""
+def test_rows_beyond_32bit_entry_count(sphx, monkeypatch):
+    """49,152,000 particles (nx = 320) with the row capacity pinned at 96: cap x particles = 4.7e9 row entries, past a
+    32-bit element count (the row store has a 64-bit length; round 1 fell back to direct walks beyond 44.7 M particles).
+    Two WCSPH steps through the rows equal two steps of direct 27-cell walks (engine flag 2, oracle-checked at small
+    sizes) bit for bit."""
+    monkeypatch.setenv("SPHX_NBR_CAP", "96")
     P, fluid, boundary = sphx.scene(320)
     n = 320 * 480 * 320
     assert len(fluid) == n and ((n + 63) // 64) * 64 * 96 > 2 ** 32
@@ -798,3 +800,27 @@ def test_trajectory_bit_exact_through_landing(sphx, oracle, solver, dt, first, l
         assert (20, 2) in its and (1, 2) in its, "adaptive control must have been exercised up to maxIter"
     if solver == 0:
         assert gs.get(sphx.F_PRESSURE).max() > 0, "Tait pressures must be active"
+
+
+def test_adaptive_row_capacity_grows_and_stays_exact(sphx, oracle):
+    """rows start at 48 entries per particle; a state denser than the lattice (two interleaved jittered lattices, ~60 neighbours)
+    overflows them: the overflowing particles walk the cells directly (same bits), the builder reports the longest row, the
+    host enlarges the rows between steps -- the trajectory equals the oracle bit for bit before, while and after that"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.DFSPH; P.dt = 0.0005
+    rng = np.random.default_rng(3)
+    a = fluid + rng.uniform(-0.002, 0.002, fluid.shape).astype(np.float32)
+    b = fluid[: len(fluid) // 2] + np.float32(0.01) + rng.uniform(-0.002, 0.002, (len(fluid) // 2, 3)).astype(np.float32)
+    pos = np.concatenate([a, b]).astype(np.float32)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    longest = []
+    for s in range(20):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, ["POS", "VEL", "DENSITY", "KAPPA"], "dense state step %d" % (s + 1))
+        assert gs.iters() == os_.iters()
+        longest.append(gs.row_stats()[1])
+    assert max(longest) > 48, "the state must overflow the initial rows (longest row %d)" % max(longest)
+    grown = sphx.row_capacity(gs)
+    assert grown >= max(longest[:8]) and grown > 48, "the rows must have been enlarged (capacity %d)" % grown
