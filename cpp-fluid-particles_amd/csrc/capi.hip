@@ -149,7 +149,9 @@ int sphx_scene_fill(int nx, float* fluid, float* boundary)
 int sphx_create(const sphx_params* P, const float* fluid, int n, const float* boundary, int nb, int run_ctor_step,
                 sphx_system** out)
 {
-    return guarded("sphx_create", [&] { return sphx_create_impl(P, fluid, n, boundary, nb, run_ctor_step, out); });
+    // (the internal mode 2 = "restored: no constructor step, no initial sort" belongs to sphx_snapshot_load alone: a caller
+    // that passes 2 as "true" gets the ordinary constructor step)
+    return guarded("sphx_create", [&] { return sphx_create_impl(P, fluid, n, boundary, nb, run_ctor_step ? 1 : 0, out); });
 }
 
 }  // extern "C"
@@ -637,7 +639,7 @@ int sphx_generate_dots(const sphx_system* h, float* device_dot, float* device_co
 // set (sorted positions + masses) and the solver's persistent array (DFSPH warm stiffness / PBD last
 // positions).  The reference has no checkpoint facility; this is §8(f)-2.
 namespace {
-constexpr unsigned int kSnapVersion = 1;
+constexpr unsigned int kSnapVersion = 2;       // 2: + active fluid count, + "PBD last positions initialised" (r03); version-1 files still load
 struct FileCloser { void operator()(FILE* f) const { if (f) fclose(f); } };
 
 std::vector<int> snapshot_fields(const sphx_system* h)
@@ -660,9 +662,12 @@ int sphx_snapshot_save(const sphx_system* h, const char* path)
         const std::vector<int> fields = snapshot_fields(h);
         const unsigned int head[3] = {kSnapVersion, (unsigned int)sizeof(sphx_params), (unsigned int)fields.size()};
         const int counts[2] = {h->n, h->nb};
+        // state that is not a field: the ACTIVE fluid count (sphx_set_count may have lowered it below the capacity h->n)
+        // and whether the PBD solver has recorded last positions yet (its first step only does that, PBDSolver.cu:45-49)
+        const int extra[2] = {(int)h->system->getFluids()->size(), (h->pbd && h->pbd->graphSafe()) ? 1 : 0};
         bool ok = fwrite("SPHXSNAP", 1, 8, fp.get()) == 8 && fwrite(head, 4, 2, fp.get()) == 2 &&
                   fwrite(counts, 4, 2, fp.get()) == 2 && fwrite(head + 2, 4, 1, fp.get()) == 1 &&
-                  fwrite(&h->params, sizeof(sphx_params), 1, fp.get()) == 1;
+                  fwrite(extra, 4, 2, fp.get()) == 2 && fwrite(&h->params, sizeof(sphx_params), 1, fp.get()) == 1;
         std::vector<char> buf;
         for (int f : fields) {
             void* p; size_t sz;
@@ -688,11 +693,12 @@ int sphx_snapshot_load(const char* path, sphx_system** out)
         if (!fp) return fail(SPHX_ERR_INVALID, std::string("sphx_snapshot_load: cannot open ") + path);
         char magic[8]; unsigned int head[2]; int counts[2]; unsigned int nfields = 0;
         sphx_params P;
+        int extra[2] = {-1, -1};      // version 1: every slot active, last positions initialised iff the field is there
         if (fread(magic, 1, 8, fp.get()) != 8 || std::memcmp(magic, "SPHXSNAP", 8) != 0 || fread(head, 4, 2, fp.get()) != 2 ||
-            head[0] != kSnapVersion || head[1] != sizeof(sphx_params) || fread(counts, 4, 2, fp.get()) != 2 ||
-            fread(&nfields, 4, 1, fp.get()) != 1 || fread(&P, sizeof(P), 1, fp.get()) != 1 || counts[0] < 0 || counts[1] < 0 ||
-            nfields > 64)
-            return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: not a version-1 sphx snapshot");
+            (head[0] != 1u && head[0] != kSnapVersion) || head[1] != sizeof(sphx_params) || fread(counts, 4, 2, fp.get()) != 2 ||
+            fread(&nfields, 4, 1, fp.get()) != 1 || (head[0] >= 2u && fread(extra, 4, 2, fp.get()) != 2) ||
+            fread(&P, sizeof(P), 1, fp.get()) != 1 || counts[0] < 0 || counts[1] < 0 || nfields > 64 || extra[0] > counts[0])
+            return fail(SPHX_ERR_INVALID, "sphx_snapshot_load: not a version-1/2 sphx snapshot");
         std::vector<std::pair<int, std::vector<char>>> blobs(nfields);
         for (auto& b : blobs) {
             unsigned long long bytes = 0;
@@ -722,8 +728,9 @@ int sphx_snapshot_load(const char* path, sphx_system** out)
             if (hipMemcpyAsync(p, b.second.data(), sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
                 hipStreamSynchronize(sphx::stream()) != hipSuccess) { sphx_destroy(h); return fail(SPHX_ERR_HIP, "sphx_snapshot_load: upload failed"); }
             if (b.first == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
-            if (b.first == SPHX_F_POS_LAST && h->pbd) h->pbd->markPosLastInitialized();
+            if (b.first == SPHX_F_POS_LAST && h->pbd && extra[1] != 0) h->pbd->markPosLastInitialized();
         }
+        if (extra[0] >= 0 && extra[0] < counts[0]) h->system->getFluids()->setActiveCount((unsigned)extra[0]);
         *out = h;
         return (int)SPHX_OK;
     });

@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
-#include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 #include "capi_internal.hpp"
@@ -25,7 +25,9 @@ struct Emitter {
 };
 
 // number of intervals so that the step along an edge of length L is <= spacing (at least one)
-int intervals(float length, float spacing) { return std::max(1, (int)std::ceil(length / spacing - 1e-4f)); }
+// (bounded before the int cast: a tiny spacing must not overflow; kMaxIntervals^2 points per face is far beyond any capacity)
+constexpr float kMaxIntervals = 1.0e6f;
+int intervals(float length, float spacing) { return std::max(1, (int)std::min(kMaxIntervals, std::ceil(length / spacing - 1e-4f))); }
 
 int finish(const Emitter& e, int* count, const char* who)
 {
@@ -44,15 +46,21 @@ int sphx_sample_box(const float lo[3], const float hi[3], float spacing, float* 
 {
     if (!lo || !hi || !count || !(spacing > 0.0f) || hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2])
         return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_box: bad argument");
-    const int nx = intervals(hi[0] - lo[0], spacing), ny = intervals(hi[1] - lo[1], spacing), nz = intervals(hi[2] - lo[2], spacing);
-    auto at = [&](int axis, int k, int n) { return lo[axis] + (hi[axis] - lo[axis]) * ((float)k / (float)n); };
+    // a box that is flat along an axis (lo == hi) has ONE face there and no intervals along it: a second face or a second
+    // lattice line would put coincident particles
+    const bool flatX = !(hi[0] > lo[0]), flatY = !(hi[1] > lo[1]), flatZ = !(hi[2] > lo[2]);
+    const int nx = flatX ? 0 : intervals(hi[0] - lo[0], spacing), ny = flatY ? 0 : intervals(hi[1] - lo[1], spacing),
+              nz = flatZ ? 0 : intervals(hi[2] - lo[2], spacing);
+    auto at = [&](int axis, int k, int n) { return n > 0 ? lo[axis] + (hi[axis] - lo[axis]) * ((float)k / (float)n) : lo[axis]; };
+    if (((double)nx + 1.0) * ((double)ny + 1.0) + ((double)nx + 1.0) * ((double)nz + 1.0) + ((double)ny + 1.0) * ((double)nz + 1.0) > 5.0e8)
+        return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_box: spacing too small for this box (more than 1e9 points)");
     Emitter e{out_xyz, capacity};
     for (int a = 0; a <= nx; ++a)                       // the two z faces
-        for (int b = 0; b <= ny; ++b) { e.put(at(0, a, nx), at(1, b, ny), lo[2]); e.put(at(0, a, nx), at(1, b, ny), hi[2]); }
+        for (int b = 0; b <= ny; ++b) { e.put(at(0, a, nx), at(1, b, ny), lo[2]); if (!flatZ) e.put(at(0, a, nx), at(1, b, ny), hi[2]); }
     for (int a = 0; a <= nx; ++a)                       // the two y faces without their z edges
-        for (int c = 1; c < nz; ++c) { e.put(at(0, a, nx), lo[1], at(2, c, nz)); e.put(at(0, a, nx), hi[1], at(2, c, nz)); }
+        for (int c = 1; c < nz; ++c) { e.put(at(0, a, nx), lo[1], at(2, c, nz)); if (!flatY) e.put(at(0, a, nx), hi[1], at(2, c, nz)); }
     for (int b = 1; b < ny; ++b)                        // the two x faces without y and z edges
-        for (int c = 1; c < nz; ++c) { e.put(lo[0], at(1, b, ny), at(2, c, nz)); e.put(hi[0], at(1, b, ny), at(2, c, nz)); }
+        for (int c = 1; c < nz; ++c) { e.put(lo[0], at(1, b, ny), at(2, c, nz)); if (!flatX) e.put(hi[0], at(1, b, ny), at(2, c, nz)); }
     return finish(e, count, "sphx_sample_box");
 }
 
@@ -63,6 +71,7 @@ int sphx_sample_sphere(const float center[3], float radius, float spacing, float
     if (!center || !count || !(spacing > 0.0f) || !(radius > 0.0f)) return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_sphere: bad argument");
     const float pi = 3.14159265358979323846f;
     const int rings = intervals(pi * radius, spacing);
+    if ((double)rings * (double)rings > 5.0e8) return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_sphere: spacing too small for this sphere (more than 1e9 points)");
     Emitter e{out_xyz, capacity};
     for (int k = 0; k <= rings; ++k) {
         const float theta = pi * (float)k / (float)rings;
@@ -83,21 +92,39 @@ int sphx_sample_triangles(const float* tri_xyz, int n_triangles, float spacing, 
 {
     if (!count || n_triangles < 0 || (n_triangles && !tri_xyz) || !(spacing > 0.0f)) return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_triangles: bad argument");
     Emitter e{out_xyz, capacity};
+    // Points already emitted, binned on a lattice of step q = spacing / 8 with the FULL three 64-bit cell coordinates as key
+    // (no masking: far-away coordinates cannot alias).  A new point is a duplicate when an emitted point lies within q of it,
+    // which may sit in any of the 27 lattice cells around its own: all of them are looked at.
     const float q = spacing * 0.125f;
-    std::unordered_set<uint64_t> seen;
-    auto key = [&](float x, float y, float z) {
-        const int64_t a = (int64_t)std::llround(x / q), b = (int64_t)std::llround(y / q), c = (int64_t)std::llround(z / q);
-        return (uint64_t)((a & 0x1fffff) | ((b & 0x1fffff) << 21) | ((c & 0x1fffff) << 42));
+    struct Cell { int64_t a, b, c; bool operator==(const Cell& o) const { return a == o.a && b == o.b && c == o.c; } };
+    struct CellHash { size_t operator()(const Cell& k) const { uint64_t h = (uint64_t)k.a * 0x9E3779B97F4A7C15ull; h ^= (uint64_t)k.b + 0x7F4A7C15u + (h << 6) + (h >> 2); h ^= (uint64_t)k.c * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2); return (size_t)h; } };
+    std::unordered_multimap<Cell, int, CellHash> seen;      // lattice cell -> index of an emitted point
+    std::vector<float> kept;                                // emitted points (kept even when out_xyz is null / too small)
+    auto cell_of = [&](float x, float y, float z) { return Cell{(int64_t)std::floor(x / q), (int64_t)std::floor(y / q), (int64_t)std::floor(z / q)}; };
+    auto is_new = [&](float x, float y, float z) {
+        const Cell c0 = cell_of(x, y, z);
+        for (int64_t da = -1; da <= 1; ++da) for (int64_t db = -1; db <= 1; ++db) for (int64_t dc = -1; dc <= 1; ++dc) {
+            const auto range = seen.equal_range(Cell{c0.a + da, c0.b + db, c0.c + dc});
+            for (auto it = range.first; it != range.second; ++it) {
+                const float* p = &kept[3 * (size_t)it->second];
+                const float dx = p[0] - x, dy = p[1] - y, dz = p[2] - z;
+                if (dx * dx + dy * dy + dz * dz <= q * q) return false;
+            }
+        }
+        seen.emplace(c0, (int)(kept.size() / 3));
+        kept.push_back(x); kept.push_back(y); kept.push_back(z);
+        return true;
     };
     for (int t = 0; t < n_triangles; ++t) {
         const float* A = tri_xyz + 9 * (size_t)t; const float* B = A + 3; const float* C = A + 6;
         auto len = [](const float* p, const float* r) { return std::sqrt((p[0] - r[0]) * (p[0] - r[0]) + (p[1] - r[1]) * (p[1] - r[1]) + (p[2] - r[2]) * (p[2] - r[2])); };
         const int n = intervals(std::max(len(A, B), std::max(len(B, C), len(C, A))), spacing);
+        if (n > 30000) return sphx_fail(SPHX_ERR_INVALID, "sphx_sample_triangles: spacing too small for a triangle (more than 4.5e8 points)");
         for (int i = 0; i <= n; ++i)
             for (int j = 0; i + j <= n; ++j) {
                 const float u = (float)i / (float)n, v = (float)j / (float)n, w = 1.0f - u - v;
                 const float x = w * A[0] + u * B[0] + v * C[0], y = w * A[1] + u * B[1] + v * C[1], z = w * A[2] + u * B[2] + v * C[2];
-                if (seen.insert(key(x, y, z)).second) e.put(x, y, z);
+                if (is_new(x, y, z)) e.put(x, y, z);
             }
     }
     return finish(e, count, "sphx_sample_triangles");

@@ -132,6 +132,18 @@ def test_obstacle_samplers(sphx):
     assert d.min() > 0.02 / 8 and d.min(axis=1).max() <= 0.0205
     with pytest.raises(sphx.SphxError):
         sphx.sample_sphere(c, -1.0, 0.01)
+    # far from the origin the dedupe must neither alias distinct points (no coordinate masking) nor miss the shared
+    # edge because two copies straddle a lattice-cell border; a box that is flat along an axis has one face, not two coincident ones
+    far = tri.copy(); far[:, 0::3] += np.float32(3000.0); far[:, 2::3] -= np.float32(2500.0)
+    tf = sphx.sample_triangles(far, 0.02)
+    assert len(tf) == len(t), "the same two triangles, translated by (3000, 0, -2500): %d vs %d points" % (len(tf), len(t))
+    plate = sphx.sample_box(np.float32([0.1, 0.2, 0.1]), np.float32([0.3, 0.2, 0.3]), 0.02)
+    assert len(np.unique(plate, axis=0)) == len(plate) and len(plate) == 11 * 11, "a flat box is ONE layer of points"
+    tiny = sphx.lib().sphx_sample_box          # a spacing that would overflow the interval count is bounded, not UB: only counted
+    import ctypes as C
+    cnt = C.c_int()
+    rc = tiny((C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1), C.c_float(1e-30), None, 0, C.byref(cnt))
+    assert rc == -1, "a spacing that asks for more than 1e9 points is refused at once"
 
 
 def test_bench_refuses_cpu_and_checks_traffic_provenance(tmp_path, monkeypatch):
@@ -152,10 +164,13 @@ def test_bench_refuses_cpu_and_checks_traffic_provenance(tmp_path, monkeypatch):
     h = engine_source_hash()
     assert len(h) == 16 and h == engine_source_hash()
     entry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["dfsph_nx190"]
-    got, valu = bench.read_traffic("dfsph_nx190")
+    got = bench.read_traffic("dfsph_nx190")
     if entry["source_hash"] == h:
-        assert got == entry["hbm_bytes_per_launch"] and got > 4.5e8       # more than the algorithmic 0.45 GB
+        assert got["hbm_bytes_per_launch"] == entry["hbm_bytes_per_launch"] and got["hbm_bytes_per_launch"] > 4.5e8   # more than the algorithmic 0.45 GB
+        assert "valu_issue_frac" in got and (got["valu_issue_frac"] is None or 0.0 < got["valu_issue_frac"] <= 1.05), "calibrated, never clipped"
+        assert "VALU issue" in bench.limiter_text(got)
     else:
-        assert got is None and valu is None                               # stale evidence is not reported
-    assert bench.read_traffic("no_such_workload") == (None, None)
+        assert got is None                                                # stale evidence is not reported
+        assert "not measured for this build" in bench.limiter_text(got)   # ... and no limiter is asserted for it
+    assert bench.read_traffic("no_such_workload") is None
     assert bench.step_bytes_per_particle("dfsph", 1, 4, 0) == 1000 and bench.step_bytes_per_particle("pbd", 0, 0, 4) == 788

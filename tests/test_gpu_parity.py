@@ -824,3 +824,39 @@ def test_adaptive_row_capacity_grows_and_stays_exact(sphx, oracle):
     assert max(longest) > 48, "the state must overflow the initial rows (longest row %d)" % max(longest)
     grown = sphx.row_capacity(gs)
     assert grown >= max(longest[:8]) and grown > 48, "the rows must have been enlarged (capacity %d)" % grown
+
+
+def test_snapshot_keeps_the_active_count_and_the_pbd_first_step_state(sphx, oracle, tmp_path):
+    """snapshot container version 2: (a) a system whose active count was lowered with sphx_set_count continues
+    with that count, not with the capacity; (b) a PBD system saved BEFORE its first step still spends that step recording
+    positions (PBDSolver.cu:45-49) -- both equal the oracle's uninterrupted run bit for bit"""
+    # (a)
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.WCSPH; P.dt = 0.001
+    pos, vel = _splash_state(len(fluid), P, 201)
+    Po = same_params(oracle.Params(), P)
+    a = sphx.System(P, pos, boundary, ctor_step=False)
+    o = oracle.System(Po, pos, boundary, ctor_step=False)
+    m = len(fluid) - 777
+    a.set_count(m); o.set_count(m)
+    for _ in range(2):
+        a.step(); o.step()
+    path = str(tmp_path / "count.bin")
+    sphx.save_snapshot(a, path); a.close()
+    b = sphx.load_snapshot(path)
+    for s_ in range(2):
+        b.step(); o.step()
+        for nm in ("POS", "VEL", "DENSITY", "ID"):
+            assert_bit_equal(b.get(getattr(sphx, "F_" + nm))[:m], o.get(getattr(oracle, "F_" + nm))[:m], "lowered count, resumed step %d %s" % (s_ + 1, nm))
+    b.close(); o.close()
+    # (b)
+    P.solver = sphx.PBD; P.pbd_iters = 3
+    Po = same_params(oracle.Params(), P)
+    a = sphx.System(P, pos, boundary, ctor_step=False)
+    o = oracle.System(Po, pos, boundary, ctor_step=False)
+    path = str(tmp_path / "pbd0.bin")
+    sphx.save_snapshot(a, path); a.close()
+    b = sphx.load_snapshot(path)
+    for s_ in range(3):
+        b.step(); o.step()
+        compare(sphx, oracle, b, o, ["POS", "VEL", "DENSITY", "POS_LAST"], "PBD saved before its first step, step %d" % (s_ + 1))
