@@ -1135,17 +1135,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     int cnt = 0;
     uint4 pend = make_uint4(0u, 0u, 0u, 0u);          // register-staged chunk (SPHX_BUILD_REGSTAGE)
     const int3 c0 = cell_of(pi, c.g);
-    const int zlo0 = max(c0.z - 1, 0), zhi0 = min(c0.z + 1, c.g.gz - 1);
-    // Cell culling (r03).  A neighbour cell whose box is farther from the particle than the support holds no neighbour:
-    // skipping it leaves the row as it is (its candidates would all have been rejected) and saves their loads -- 49 % of the
-    // corner cells and 23 % of the edge cells of a uniformly placed particle, a quarter of all candidates.  Distances to the
-    // cell's faces from the particle's own cell: ax/ay/az toward the lower (L) and upper (H) neighbour.  The margin (1e-3 of the
-    // radius, ~40 ulps of a coordinate at 8 m) absorbs the rounding of pos / cellLength against idx * cellLength.
-    const float cullR = sqrtf(c.buildCut) * 1.001f, cullR2 = cullR * cullR;
-    const float faceX = (float)(c0.x + c.g.xOff) * c.g.cellLength, faceY = (float)c0.y * c.g.cellLength, faceZ = (float)c0.z * c.g.cellLength;
-    const float axL = fmaxf(pi.x - faceX, 0.0f), axH = fmaxf(faceX + c.g.cellLength - pi.x, 0.0f);
-    const float ayL = fmaxf(pi.y - faceY, 0.0f), ayH = fmaxf(faceY + c.g.cellLength - pi.y, 0.0f);
-    const float azL = fmaxf(pi.z - faceZ, 0.0f), azH = fmaxf(faceZ + c.g.cellLength - pi.z, 0.0f);
+    const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
     WaveRanges w; w.start = w.len = w.off = 0; w.ok = false;
     if (streamed) w = wave_ranges(c, (i >> 6) << 6);
 #pragma unroll 1
@@ -1171,16 +1161,10 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
             }
         }
         const int X = c0.x + dx;
-        const float ax = dx < 0 ? axL : (dx > 0 ? axH : 0.0f);
-        if (valid && X >= 0 && X < c.g.gx && zlo0 <= zhi0) {
+        if (valid && X >= 0 && X < c.g.gx && zlo <= zhi) {
             for (int dy = -1; dy <= 1; ++dy) {
                 const int Y = c0.y + dy;
                 if (Y < 0 || Y >= c.g.gy) continue;
-                const float ay = dy < 0 ? ayL : (dy > 0 ? ayH : 0.0f);
-                const float dxy2 = ax * ax + ay * ay;
-                if (dxy2 > cullR2) continue;                                   // the whole column is out of reach
-                const int zlo = (dxy2 + azL * azL > cullR2) ? max(c0.z, zlo0) : zlo0;      // trim the run's end cells
-                const int zhi = (dxy2 + azH * azH > cullR2) ? min(c0.z, zhi0) : zhi0;
                 const int base = (X * c.g.gy + Y) * c.g.gz;
                 const int fShift = dy < 0 ? fSh[0] : (dy == 0 ? fSh[1] : fSh[2]);
                 const int bShift = streamed ? (dy < 0 ? bSh[0] : (dy == 0 ? bSh[1] : bSh[2])) : c.bOff;
