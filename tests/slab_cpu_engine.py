@@ -1,5 +1,5 @@
 """CPU stand-in for the HIP slab engine, used ONLY by the tests: the oracle behind the engine interface
-of cpp-fluid-particles_amd/multi_gpu.py (copies instead of zero-copy views), so that the slab driver
+of tests/slab_protocol.py (copies instead of zero-copy views), so that the slab driver
 itself — particle exchange, halo schedule, adaptive termination — runs under gloo without a GPU."""
 import numpy as np
 import torch

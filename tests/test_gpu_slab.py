@@ -1,6 +1,6 @@
 """GPU tests of the x-slab decomposition with the HIP engine; the result must equal the single-domain ORACLE
 result bit for bit.  Two host drivers: the native layer csrc/slab.hip (loopback transport: all slabs on the test
-box's one GPU; its RCCL transport needs a multi-GPU node) and the Python protocol driver multi_gpu.py (ranks are
+box's one GPU; its RCCL transport needs a multi-GPU node) and the Python protocol driver tests/slab_protocol.py (ranks are
 processes sharing the GPU, talking over gloo)."""
 import numpy as np
 import pytest

@@ -1,4 +1,4 @@
-"""CPU (gloo, world_size 2 and 3) tests of the x-slab driver cpp-fluid-particles_amd/multi_gpu.py with
+"""CPU (gloo, world_size 2 and 3) tests of the x-slab protocol driver tests/slab_protocol.py with
 the oracle plugged in as the engine: the distributed result must equal the single-domain oracle
 result bit for bit, including particles that migrate across the cut planes."""
 import os
