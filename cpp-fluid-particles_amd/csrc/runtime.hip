@@ -416,107 +416,6 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 }
 
 
-
-// ---- row-of-16 tiled row builder (r03) ------------------------------------------------------------------------------------------
-// The lane-per-particle builder above issues one 16-byte load per lane and candidate: ~190 load instructions per wave and row
-// build, and the kernel sits on the texture-address path (TA busy 88 %, r02).  Here the 16 lanes of a DPP row (16 consecutive
-// cell-sorted particles) share their candidates: for one (dx,dy) offset the candidate cells of the whole row are ONE contiguous
-// particle range (cell ids run z fastest: [first + off - 1, last + off + 1], off = (dx gy + dy) gz); the row loads it 16 records
-// at a time, one per lane, and every lane tests all 16 through DPP row rotations (the rotated operand feeds the subtraction
-// directly).  ~7x fewer load instructions for ~1.7x the distance tests.  A candidate outside a lane's own 27 cells is farther
-// than the support (cells are at least one support radius wide) and fails the test like any other rejected candidate, so the
-// accepted set and its order (ascending index inside a (dx,dy) run) are exactly those of the lane-per-particle walk.
-// Preconditions, checked per wave (else the wave takes the lane-per-particle walk): positions are the binned ones (not PBD),
-// every particle of the wave is inside the grid, and none of its 9 columns holds boundary particles (their per-cell
-// interleaving with the fluid candidates is not a contiguous run).
-template <int K> __device__ __forceinline__ float row_ror_f(float v)
-{
-    if constexpr (K == 0) return v;
-    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + K, 0xf, 0xf, false));
-}
-template <int K> __device__ __forceinline__ int row_ror_i(int v)
-{
-    if constexpr (K == 0) return v;
-    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + K, 0xf, 0xf, false);
-}
-template <int K>
-__device__ __forceinline__ void tiled_test(const float3 pi, const float4 pj, const int l16, const float cut, unsigned int& mask)
-{
-    const float3 d = v3(pi.x - row_ror_f<K>(pj.x), pi.y - row_ror_f<K>(pj.y), pi.z - row_ror_f<K>(pj.z));
-    const float r2 = dot3(d, d);
-    const int src = row_ror_i<K>(l16);                    // the lane (= candidate of the batch) this rotation shows me
-    mask |= (r2 > cut ? 0u : 1u) << src;
-    if constexpr (K < 15) tiled_test<K + 1>(pi, pj, l16, cut, mask);
-}
-
-__global__ void __launch_bounds__(kWideBlock) k_build_list_tiled(SweepCtx c, unsigned int* nbr, int* nbrCount)
-{
-    const int tile = wave_tile(c);
-    if (tile < 0) return;
-    const int lane = threadIdx.x & 63, l16 = lane & 15;
-    const int i = tile * kTile + lane;
-    const bool valid = i < c.n && in_range(c, i);
-    const float4 self = valid ? c.posm[i] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.0f);       // (lanes without a particle reject everything)
-    const float3 pi = v3(self.x, self.y, self.z);
-    const int3 c0 = cell_of(pi, c.g);
-    const int myCell = valid ? cell_id(c0.x, c0.y, c0.z, c.g) : -1;
-    // ---- can this wave take the tiled walk?
-    bool plainWalk = valid && myCell >= c.g.C;
-    if (valid && !plainWalk) {
-        const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
-        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) {
-            const int X = c0.x + dx, Y = c0.y + dy;
-            if (X < 0 || X >= c.g.gx || Y < 0 || Y >= c.g.gy) continue;
-            const int base = (X * c.g.gy + Y) * c.g.gz;
-            plainWalk = plainWalk || c.csB[base + zlo] != c.csB[base + zhi + 1];
-        }
-    }
-    if (__any(plainWalk)) {
-        build_neighbor_rows(c, nullptr, false, nbr, nbrCount, i, valid, nullptr);
-        return;
-    }
-    // ---- the row's cell span
-    int cmin = valid ? myCell : 0x7fffffff, cmax = valid ? myCell : -1;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { cmin = min(cmin, __shfl_xor(cmin, off, 16)); cmax = max(cmax, __shfl_xor(cmax, off, 16)); }
-    unsigned int* row = nbr + row_base_offset(i, c.cap);
-    int cnt = 0;
-    uint4 pend = make_uint4(0u, 0u, 0u, 0u);
-    if (cmax >= 0) {
-#pragma unroll 1
-        for (int m = 0; m < 9; ++m) {
-            const int off = ((m / 3 - 1) * c.g.gy + (m % 3 - 1)) * c.g.gz;
-            const int lo = max(cmin + off - 1, 0), hi = min(cmax + off + 1, c.g.C - 1);
-            if (lo > hi) continue;                                  // (row-uniform)
-            const int s = c.csF[lo], e = c.csF[hi + 1];
-#pragma unroll 1
-            for (int b = s; b < e; b += 16) {
-                const int j = b + l16;
-                const float4 pj = j < e ? c.posm[j] : make_float4(-1.0e18f, -1.0e18f, -1.0e18f, 0.0f);
-                unsigned int mask = 0u;
-                tiled_test<0>(pi, pj, l16, c.buildCut, mask);
-                // (my own record, should it be in this batch)
-                const int selfBit = i - b;
-                if (selfBit >= 0 && selfBit < 16) mask &= ~(1u << selfBit);
-                while (mask) {                                      // accepted candidates of the batch, ascending index
-                    const int cBit = __ffs(mask) - 1;
-                    mask &= mask - 1u;
-                    const unsigned int idx = (unsigned int)(b + cBit);
-                    const float4 q = gather16(c.posm, idx << 4);    // (a hit: the row loaded it a moment ago)
-                    const float3 d = sub3(pi, v3(q.x, q.y, q.z));
-                    put_entry(c, nullptr, row, lane, cnt, idx | (pair_needs_plain_ops(d, dot3(d, d)) ? kPlainBit : 0u), pend);
-                    ++cnt;
-                }
-            }
-        }
-    }
-    if (valid) {
-        nbrCount[i] = cnt;
-        if (cnt > c.cap && c.overflowMax) atomicMax(c.overflowMax, cnt);
-        if ((cnt & 3) != 0 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
-    }
-}
-
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
@@ -706,12 +605,6 @@ void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& cs
 void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext)
 {
     unsigned int* rows = nbr->rows;
-    static const bool tiled = [] { const char* e = getenv("SPHX_BUILD_TILED"); return !e || atoi(e) != 0; }();
-    // binned positions (allowTiles is false for PBD, whose sweeps run on moved positions), plain rows, no conditional rebuild
-    if (tiled && SPHX_BUILD_REGSTAGE && allowTiles && !(flags & kFlagTiles) && !posBuildOut && !flagNow && c.numTiles > 0) {
-        k_build_list_tiled<<<sweep_grid_for(c.numTiles), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr());
-        return;
-    }
     if (allowTiles && (flags & kFlagTiles))
         k_build_list<true><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
     else
