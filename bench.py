@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--slabs", type=int, default=1, help="with --force-slab: number of loopback slabs")
     ap.add_argument("--no-overlap", action="store_true", help="slab layer: stage-then-exchange instead of edge-first stages")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
