@@ -21,12 +21,17 @@ def test_sweep_kernels_have_no_spills_and_uniform_base_gathers():
             continue
         name, vgpr, occ, scratch, lds = m.group(1), int(m.group(2)), int(m.group(4)), int(m.group(5)), int(m.group(6))
         if "k_rate_quad<" in name:
-            # deliberately compiled for 8 waves/SIMD (64 VGPRs): a handful of spilled dwords buys the extra wave
-            # (measured 4 % faster than the spill-free 7-wave build)
-            assert scratch <= 32 and occ >= 8 and lds == 0, l
+            strict = bool(re.search(r"k_rate_quad<(true|false), \d, 0>", name))
+            if strict:
+                # deliberately compiled for 8 waves/SIMD (64 VGPRs): a handful of spilled dwords buys the extra wave
+                # (measured 4 % faster than the spill-free 7-wave build).  r03: the tolerance walk lives in
+                # its own kernel, which brought the strict one from 20 to 8 bytes of scratch
+                assert scratch <= 16 and occ >= 8 and lds == 0, l
+            else:
+                assert scratch == 0 and occ >= 6 and lds == 0, l      # the tolerance walk: spill-free at 6 waves/SIMD
         else:
             assert scratch == 0, "scratch spill in " + name
-        if "k_rate_quad<true, 2>" in name:            # the dominant kernel (quad-per-particle walk)
+        if "k_rate_quad<true, 2, 0>" in name:         # the dominant kernel (quad-per-particle walk, strict arithmetic)
             seen_rate = True
             mix = out[i + 1]
             assert "main loop" in mix
