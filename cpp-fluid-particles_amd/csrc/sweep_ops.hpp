@@ -278,15 +278,15 @@ struct OpSurface {
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
-    static constexpr int kQuadBit = kQuadSurface;
-    template <int QUAD = 0>
+    // (no quad variant: strict arithmetic adds two terms per entry to one accumulator, which the ordered one-term-per-lane
+    // accumulation cannot reproduce; under the tolerance arithmetic the quad kernel needs ~100 VGPRs + scratch and measured 5x slower)
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body b{*this, sc, sc.dii, sc.li, sc.ml, v3(0, 0, 0)};
-        sweep_any<QUAD, false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
-        if (!stores_results<QUAD>(valid)) return;
+        sweep<false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        if (!valid) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
         const float3 vn = add3(v, mul3s(b.a, dt));
@@ -347,15 +347,13 @@ struct OpSurfaceThen {
             f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); f(b.x, other.b.x); f(b.y, other.b.y); f(b.z, other.b.z);
         }
     };
-    static constexpr int kQuadBit = kQuadSurface;
-    template <int QUAD = 0>
-    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const      // (lane-per-particle only, see OpSurface)
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body body{*this, sc, sc.dii, sc.li, sc.ml, valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
-        sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
-        if (!stores_results<QUAD>(valid)) return;
+        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
+        if (!valid) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
         const float3 vs = add3(v, mul3s(body.a, dt));                 // what the surface sweep alone would have stored
