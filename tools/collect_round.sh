@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): everything profiles/rNN_* is made from, in one call.
 #   tools/collect_round.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 mkdir -p gpurun_out
 bash tools/profile_gpu.sh $TAG > gpurun_out/profile_$TAG.log 2>&1

@@ -2,7 +2,7 @@
 # Copies what tools/collect_round.sh <tag> left in gpurun_out/ into profiles/ under the names the docs cite.
 #   tools/publish_round.sh r02
 set -eu
-T=${1:-r02}
+T=${1:-r03}
 cp gpurun_out/profile_summary_$T.txt          profiles/${T}_rocprofv3_dfsph10m_summary.txt
 # gpurun_out/ accumulates over calls: take the csv the summary itself names
 CSV=$(grep -o "[0-9]*_kernel_stats.csv" gpurun_out/profile_summary_$T.txt | head -1)
