@@ -553,7 +553,10 @@ void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
     if (longest <= cap) return;
     cap = std::min(1024, (longest + 8 + kRowChunk - 1) / kRowChunk * kRowChunk);
     HIP_CALL(hipMemsetAsync(rowOverflow.addr(), 0, sizeof(int), stream()));
-    nbr.reset();                               // reallocated by the next ensureList
+    // reallocate HERE, between steps: the next step may be captured into a hipGraph, and a capture must not allocate
+    const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
+    nbr.reset();
+    nbr.reset(new RowStore(entries));
     listValid = false;
     ++generation;
 }

@@ -860,3 +860,24 @@ def test_snapshot_keeps_the_active_count_and_the_pbd_first_step_state(sphx, orac
     for s_ in range(3):
         b.step(); o.step()
         compare(sphx, oracle, b, o, ["POS", "VEL", "DENSITY", "POS_LAST"], "PBD saved before its first step, step %d" % (s_ + 1))
+
+
+def test_row_capacity_growth_between_graph_replays(sphx, oracle):
+    """the rows are enlarged between two step_n batches, i.e. between hipGraph replays: the reallocation happens in the tuning
+    hook (a capture must not allocate) and the next batch re-captures -- results stay oracle-identical (found by bench.py's
+    post-impact leg in r03: the first version reallocated lazily, inside the next capture)"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.DFSPH; P.dt = 0.0005; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 2
+    rng = np.random.default_rng(5)
+    a = fluid + rng.uniform(-0.002, 0.002, fluid.shape).astype(np.float32)
+    b = fluid[: len(fluid) // 2] + np.float32(0.01) + rng.uniform(-0.002, 0.002, (len(fluid) // 2, 3)).astype(np.float32)
+    pos = np.concatenate([a, b]).astype(np.float32)
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    for batch in range(3):
+        gs.step_n(10)
+        for _ in range(10):
+            os_.step()
+        compare(sphx, oracle, gs, os_, ["POS", "VEL", "DENSITY"], "batch %d" % batch)
+    assert sphx.row_capacity(gs) > 48
