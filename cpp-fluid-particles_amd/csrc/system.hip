@@ -513,11 +513,12 @@ float SPHSystem::stepN(int n)
     while (n > 0 && (_graph->stepsRun == 0 || (_solver->graphSafe() && _graph->warmSteps == 0))) { extra += step(); --n; }
     if (n == 0) return extra;
     const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
-    // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
-    // ... and so do host-side invalidations (boundary masses rewritten, arrays regrown, engine switches)
-    if (_graph->tried && (_graph->capturedCount != _fluids->size() || _graph->capturedGeneration != _solver->graphGeneration()))
-        _graph->drop();
-    if (wantGraph && !_graph->exec && !_graph->tried) {
+    auto ensureGraph = [&] {
+        // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
+        // ... and so do host-side invalidations (boundary masses rewritten, arrays regrown, engine switches)
+        if (_graph->tried && (_graph->capturedCount != _fluids->size() || _graph->capturedGeneration != _solver->graphGeneration()))
+            _graph->drop();
+        if (!(wantGraph && !_graph->exec && !_graph->tried)) return;
         _graph->tried = true;
         _graph->capturedCount = _fluids->size();
         _graph->capturedGeneration = _solver->graphGeneration();
@@ -535,17 +536,28 @@ float SPHSystem::stepN(int n)
                 (void)hipGetLastError();
             }
         }
-    }
+    };
     hipEvent_t start, stop;
     HIP_CALL(hipEventCreate(&start));
     HIP_CALL(hipEventCreate(&stop));
     HIP_CALL(hipEventRecord(start, st));
-    for (int s = 0; s < n; ++s) {
-        if (wantGraph && _graph->exec) {
-            HIP_CALL(hipGraphLaunch(_graph->exec, st));
-        } else {
-            try { enqueueStep(); } catch (const char* msg) { std::cout << msg << "\n"; }
+    // The batch runs in chunks of 16 steps with the solver's host-side tuning hook between them (one 4-byte read-back: row
+    // capacity, PBD skin controller): a long batch that runs into denser states must not wait for its end to get longer rows.
+    // The hook may invalidate the capture (regrown rows); the next chunk then re-captures.
+    constexpr int kChunk = 16;
+    for (int done = 0; done < n;) {
+        ensureGraph();
+        const int chunk = std::min(n - done, kChunk);
+        for (int s = 0; s < chunk; ++s) {
+            if (wantGraph && _graph->exec) {
+                HIP_CALL(hipGraphLaunch(_graph->exec, st));
+            } else {
+                try { enqueueStep(); } catch (const char* msg) { std::cout << msg << "\n"; }
+            }
         }
+        done += chunk;
+        _graph->stepsRun += chunk;
+        if (done < n) _solver->tune(chunk);
     }
     HIP_CALL(hipEventRecord(stop, st));
     HIP_CALL(hipEventSynchronize(stop));
@@ -554,7 +566,6 @@ float SPHSystem::stepN(int n)
     HIP_CALL(hipEventElapsedTime(&milliseconds, start, stop));
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
-    _graph->stepsRun += n;
-    _solver->tune(n);
+    _solver->tune(n % kChunk == 0 ? kChunk : n % kChunk);
     return milliseconds + extra;
 }
