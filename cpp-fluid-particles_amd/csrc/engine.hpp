@@ -84,7 +84,11 @@ struct SweepCache {
     // cells directly meanwhile: same bits, slower), and between steps the host enlarges the rows to that length + 8.  Halves
     // the row slab (192 instead of 384 bytes per particle).
     bool capAuto = false;
-    DArray<int> rowOverflow;                 // [0]: longest row beyond `cap` since the last check
+    // compact-brick LDS stage (tolerance arithmetic): rows hold 16-bit LDS slots, every sweep runs one block per brick
+    bool brickWanted = true, brickFailed = false, listIsBrick = false;
+    int brickMin = 2000000;
+    bool brickMode() const;
+    DArray<int> rowOverflow;                 // [0]: longest row beyond `cap` since the last check; [1]: brick stage fault flag
     int capCheckSteps = 0;
     void tuneRowCapacity(int stepsSinceLastCall);
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)

@@ -416,6 +416,33 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 }
 
 
+
+// Row builder of the compact-brick path: one block per brick, candidates read from the staged positions, rows of 16-bit slots.
+__global__ void __launch_bounds__(kBrickThreads, 4) k_build_brick(SweepCtx c, unsigned int* nbr, int* nbrCount)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char brickLds[];
+    __shared__ BrickTables T;
+    float4* lp = reinterpret_cast<float4*>(brickLds);
+    const BrickGeom G = brick_geom(c, logical_block());
+    if (!G.any) return;
+    brick_slice_tables(c, T, G.x0, G.y0, G.z0, G.z0 + kBrickEdge);
+    if (T.own == 0) return;
+    int parts = 1;
+    if (T.staged > kBrickSlots) {
+        __syncthreads();
+        parts = brick_parts(c, T, G);
+        if (parts == 0) { if (threadIdx.x == 0 && c.brickFault) *c.brickFault = 1; return; }
+    }
+    const int h = kBrickEdge / parts;
+#pragma unroll 1
+    for (int sl = 0; sl < parts; ++sl) {
+        if (parts > 1) brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
+        brick_stage(c, T, lp, (float*)nullptr, [](bool, int) { return 0.0f; });
+        brick_build_rows(c, T, lp, G.x0, G.y0, nbr, nbrCount);
+        __syncthreads();
+    }
+}
+
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
@@ -428,6 +455,8 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
     if (const char* e = getenv("SPHX_DUO_MASK")) duoMask = atoi(e);            // ... and which with two lanes per particle
     if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
+    if (const char* e = getenv("SPHX_BRICK")) brickWanted = atoi(e) != 0;      // compact-brick LDS stage under the tolerance arithmetic
+    if (const char* e = getenv("SPHX_BRICK_MIN")) brickMin = atoi(e);
 }
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
@@ -537,20 +566,36 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     if (skinRows && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
     c.overflowMax = nullptr;
+    c.brick = (use && listIsBrick) ? 1 : 0;
+    c.brickFault = rowOverflow.addr(1);
     return c;
+}
+
+// The compact-brick stage serves whole-domain systems under the tolerance arithmetic whose sweeps run on the binned positions
+// (not PBD), from `brickMin` particles on (below, the quad walks are as fast: profiles/r03_ubench_brick.txt).
+bool SweepCache::brickMode() const
+{
+    return brickWanted && !brickFailed && tolerance && !isSlab && allowTiles && !(flags & (kFlagTiles | kFlagNoList)) && rangeLo < 0 &&
+           !(skinRows && skin > 0.0f) && n >= brickMin;
 }
 
 // Adaptive row capacity: called between steps (never inside a captured graph).  One 4-byte read every 8+ steps.
 void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
 {
-    if (!capAuto || !nbr) return;
+    if ((!capAuto && !listIsBrick) || !nbr) return;
     capCheckSteps += stepsSinceLastCall;
     if (capCheckSteps < 8) return;
     capCheckSteps = 0;
-    int longest = 0;
-    HIP_CALL(hipMemcpyAsync(&longest, rowOverflow.addr(), sizeof(int), hipMemcpyDeviceToHost, stream()));
+    int words[2] = {0, 0};
+    HIP_CALL(hipMemcpyAsync(words, rowOverflow.addr(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
     HIP_CALL(hipStreamSynchronize(stream()));
-    if (longest <= cap) return;
+    if (words[1] != 0 && !brickFailed) {       // a single cell's neighbourhood outgrew the brick stage: back to the global rows for good
+        fprintf(stderr, "sphx: a brick's one-cell slice exceeded the LDS stage (density far beyond rest): the compact-brick path is switched off; "
+                        "the particles of that brick kept their previous values in the sweeps since the last check\n");
+        brickFailed = true; listValid = false; ++generation;
+    }
+    const int longest = words[0];
+    if (!capAuto || longest <= cap) return;
     cap = std::min(1024, (longest + 8 + kRowChunk - 1) / kRowChunk * kRowChunk);
     HIP_CALL(hipMemsetAsync(rowOverflow.addr(), 0, sizeof(int), stream()));
     // reallocate HERE, between steps: the next step may be captured into a hipGraph, and a capture must not allocate
@@ -583,7 +628,11 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
         HIP_CALL(hipMemsetAsync(staleFlag.addr(), 0, 2 * sizeof(int), stream()));
         activeFlag = 0;
     }
-    launchBuild(c, skinMode ? reinterpret_cast<float4*>(posBuild->addr()) : nullptr, nullptr, nullptr);
+    listIsBrick = brickMode();
+    if (listIsBrick) {
+        const size_t lds = (size_t)(kBrickSlots + 1) * sizeof(float4);
+        k_build_brick<<<xcd_grid(brick_count(g) * kBrickThreads, kBrickThreads), kBrickThreads, lds, stream()>>>(c, nbr->rows, nbrCount.addr());
+    } else launchBuild(c, skinMode ? reinterpret_cast<float4*>(posBuild->addr()) : nullptr, nullptr, nullptr);
     listValid = true;
 }
 
@@ -601,6 +650,7 @@ void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& cs
     c.nbr = nullptr; c.overflowMax = rowOverflow.addr();
     listCsF = csF.addr(); listCsB = csB.addr();
     ScopedKernel t("build_neighbor_list");
+    listIsBrick = false;
     if (c.numTiles > 0) launchBuild(c, nullptr, nullptr, nullptr);
     listValid = true;
 }

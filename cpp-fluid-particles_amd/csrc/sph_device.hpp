@@ -12,6 +12,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace sphx {
 
 constexpr float kEps = 1e-6f;                    // global.h:21
@@ -474,6 +476,8 @@ struct SweepCtx {
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
     int n;
     int* overflowMax;                       // row builder only: longest row that did not fit `cap` (atomicMax; nullptr otherwise)
+    int brick;                              // 1: rows hold 16-bit slots of the compact-brick LDS stage (tolerance arithmetic, see "brick" below)
+    int* brickFault;                        // device flag: a one-cell slice of some brick exceeded the stage (the host leaves brick mode)
 };
 
 // The tile (64 consecutive particles) this wave works on.  Launch order is a free choice — results
@@ -1228,6 +1232,242 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
             if (k < own)
                 *reinterpret_cast<uint4*>(row + (size_t)(k >> 2) * 256u) =
                     make_uint4(stage[k * 64 + lane], stage[(k + 1) * 64 + lane], stage[(k + 2) * 64 + lane], stage[(k + 3) * 64 + lane]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Compact-brick LDS stage (r03; tolerance arithmetic only; the north star's "LDS-staged neighbour cells").
+// A block of kBrickThreads owns the particles of a brick of 4 x 4 cell columns x 4 cells along z.  z is the fastest cell axis, so
+// the brick's part of a column is ONE contiguous particle run and the neighbourhood of the brick is 6 x 6 runs covering
+// [z0 - 1, z0 + 4]: they are staged with coalesced loads as 16-byte LDS records -- position+mass, and the one per-neighbour field
+// of the sweep -- fluid runs first, then the boundary runs.  Rows hold 16-bit LDS slots (bit 15: boundary), 8 per 16-byte chunk,
+// in the ordinary row storage; a pair costs two ds_read_b128 instead of two divergent global gathers (measured -15..-21 % per
+// sweep against the quad walk at 10 M particles, profiles/r03_ubench_brick.txt; nothing under strict arithmetic, whose exact
+// chains bind first, so the strict path never uses it).  A brick whose stage would not fit kBrickSlots is processed in 2 or 4
+// slices along z (same rule in the builder and in every sweep: it depends on the cell tables only).
+constexpr int kBrickEdge = 4;
+constexpr int kBrickThreads = 512;
+constexpr int kBrickSlots = 2304;           // staged records per slice: 36 KB per 16-byte field
+constexpr int kBrickRuns = 36;              // (kBrickEdge + 2)^2 halo columns
+struct BrickTables {
+    int runStart[2 * kBrickRuns];           // [0,36): fluid runs, [36,72): boundary runs (index into the fluid / boundary array)
+    int runLen[2 * kBrickRuns];
+    int runBase[2 * kBrickRuns];            // LDS slot of the run's first record
+    int ownStart[16], ownLen[16], ownEnd[16];   // the brick's own z-runs (fluid), inclusive prefix of their lengths
+    int staged, stagedFluid, own;
+};
+struct BrickGeom { int x0, y0, z0; bool any; };
+
+__device__ __forceinline__ BrickGeom brick_geom(const SweepCtx& c, int b)
+{
+    const int nbz = (c.g.gz + kBrickEdge - 1) / kBrickEdge, nby = (c.g.gy + kBrickEdge - 1) / kBrickEdge, nbx = (c.g.gx + kBrickEdge - 1) / kBrickEdge;
+    BrickGeom G;
+    G.any = b < nbx * nby * nbz;
+    G.z0 = (b % nbz) * kBrickEdge; G.y0 = ((b / nbz) % nby) * kBrickEdge; G.x0 = (b / (nbz * nby)) * kBrickEdge;
+    return G;
+}
+inline int brick_count(const GridDesc& g)
+{
+    return ((g.gx + kBrickEdge - 1) / kBrickEdge) * ((g.gy + kBrickEdge - 1) / kBrickEdge) * ((g.gz + kBrickEdge - 1) / kBrickEdge);
+}
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
+}
+// Tables of one slice [zs0, zs1) of the brick at (x0, y0): waves 0 and 1 of the block fill the fluid / boundary halo runs, wave 2
+// the own runs.  Ends with a block barrier.  (Every thread of the block must call it.)
+__device__ __forceinline__ void brick_slice_tables(const SweepCtx& c, BrickTables& T, int x0, int y0, int zs0, int zs1)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2) {
+        int start = 0, len = 0;
+        if (lane < kBrickRuns) {
+            const int X = x0 - 1 + lane / 6, Y = y0 - 1 + lane % 6;
+            const int zlo = max(zs0 - 1, 0), zhi = min(zs1, c.g.gz - 1);
+            if (X >= 0 && X < c.g.gx && Y >= 0 && Y < c.g.gy && zlo <= zhi) {
+                const int* cs = wave == 0 ? c.csF : c.csB;
+                const int base = (X * c.g.gy + Y) * c.g.gz;
+                start = cs[base + zlo]; len = cs[base + zhi + 1] - start;
+            }
+        }
+        const int end = wave_inclusive_scan(len);
+        if (lane < kBrickRuns) { T.runStart[wave * kBrickRuns + lane] = start; T.runLen[wave * kBrickRuns + lane] = len; T.runBase[wave * kBrickRuns + lane] = end - len; }
+        if (lane == 63) { if (wave == 0) T.stagedFluid = end; else T.staged = end; }      // (boundary total for now)
+    } else if (wave == 2) {
+        int start = 0, len = 0;
+        if (lane < 16) {
+            const int X = x0 + lane / 4, Y = y0 + lane % 4;
+            const int z1 = min(zs1, c.g.gz);
+            if (X < c.g.gx && Y < c.g.gy && zs0 < z1) {
+                const int base = (X * c.g.gy + Y) * c.g.gz;
+                start = c.csF[base + zs0]; len = c.csF[base + z1] - start;
+            }
+        }
+        const int end = wave_inclusive_scan(len);
+        if (lane < 16) { T.ownStart[lane] = start; T.ownLen[lane] = len; T.ownEnd[lane] = end; }
+        if (lane == 63) T.own = end;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBrickRuns) T.runBase[kBrickRuns + threadIdx.x] += T.stagedFluid;     // boundary records follow the fluid ones
+    if (threadIdx.x == 64) T.staged += T.stagedFluid;
+    __syncthreads();
+}
+// number of z slices the brick is processed in: the smallest of 1, 2, 4 whose slices all fit the stage (0: not even single cells do)
+__device__ __forceinline__ int brick_parts(const SweepCtx& c, BrickTables& T, const BrickGeom& G)
+{
+#pragma unroll 1
+    for (int parts = 1; parts <= kBrickEdge; parts *= 2) {
+        const int h = kBrickEdge / parts;
+        bool fits = true;
+#pragma unroll 1
+        for (int sl = 0; sl < parts; ++sl) {
+            brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
+            fits = fits && T.staged <= kBrickSlots;            // (block-uniform: read after the barrier)
+            __syncthreads();
+        }
+        if (fits) return parts;
+    }
+    return 0;
+}
+// own particle `p` of the current slice -> global index (p < T.own)
+__device__ __forceinline__ int brick_own_index(const BrickTables& T, int p)
+{
+    int col = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) col += (p >= T.ownEnd[k]) ? 1 : 0;
+    return T.ownStart[col] + (p - (T.ownEnd[col] - T.ownLen[col]));
+}
+// stage the halo runs: positions (+mass) always, and the sweep's per-neighbour field when `lf` is given
+template <class Field, class Stage>
+__device__ __forceinline__ void brick_stage(const SweepCtx& c, const BrickTables& T, float4* lp, Field* lf, Stage&& stage)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < 2 * kBrickRuns; r += kBrickThreads / 64) {
+        const int len = T.runLen[r];
+        if (len <= 0) continue;
+        const bool isB = r >= kBrickRuns;
+        const int u0 = T.runStart[r] + (isB ? c.bOff : 0), b0 = T.runBase[r];
+        for (int t = lane; t < len; t += 64) {
+            lp[b0 + t] = c.posm[u0 + t];
+            if (lf) lf[b0 + t] = stage(isB, u0 + t);
+        }
+    }
+    __syncthreads();
+}
+constexpr unsigned int kBrickBoundaryBit = 0x8000u;
+// The record an op stages per neighbour is its Field, unless the op names a more compact BrickField (with brick_pack /
+// brick_unpack): the stage must stay at 16 bytes per record for two blocks to share a CU.
+template <class Op, class = void> struct BrickFieldOf { using type = typename Op::Field; };
+template <class Op> struct BrickFieldOf<Op, std::void_t<typename Op::BrickField>> { using type = typename Op::BrickField; };
+template <class Op> using brick_field_t = typename BrickFieldOf<Op>::type;
+template <class Op> __device__ __forceinline__ auto brick_pack_impl(const Op& op, const typename Op::Field& f, int) -> decltype(op.brick_pack(f)) { return op.brick_pack(f); }
+template <class Op> __device__ __forceinline__ typename Op::Field brick_pack_impl(const Op&, const typename Op::Field& f, long) { return f; }
+template <class Op> __device__ __forceinline__ brick_field_t<Op> brick_pack(const Op& op, const typename Op::Field& f) { return brick_pack_impl(op, f, 0); }
+template <class Op> __device__ __forceinline__ auto brick_unpack_impl(const Op& op, const brick_field_t<Op>& t, int) -> decltype(op.brick_unpack(t)) { return op.brick_unpack(t); }
+template <class Op> __device__ __forceinline__ typename Op::Field brick_unpack_impl(const Op&, const typename Op::Field& t, long) { return t; }
+template <class Op> __device__ __forceinline__ typename Op::Field brick_unpack(const Op& op, const brick_field_t<Op>& t) { return brick_unpack_impl(op, t, 0); }
+
+// the row walk of one own particle from the stage (tolerance arithmetic; lane-per-particle)
+template <bool WANT_BOUNDARY, class Op, class Body>
+__device__ __forceinline__ void sweep_brick(const Op& op, const SweepCtx& c, const float4* lp, const typename Op::Field* lfRaw, const int i,
+                                            const bool valid, const float3 pi, Body& body)
+{
+    if (!valid) return;
+    const int cnt = c.nbrCount[i];
+    if (cnt > 2 * c.cap) {                 // row overflow: this particle walks the cells over global memory (the host enlarges the rows)
+        walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+            body.pair_tol(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj);
+        });
+        return;
+    }
+    // (the stage holds brick_field_t<Op> records; the Op's operator() hands the pointer through typed as its Field)
+    const brick_field_t<Op>* lf = reinterpret_cast<const brick_field_t<Op>*>(lfRaw);
+    const uint4* row = reinterpret_cast<const uint4*>(c.nbr + row_base_offset(i, c.cap));
+    const int chunks = (cnt + 7) >> 3;
+    uint4 nxt = chunks > 0 ? row[0] : make_uint4(0u, 0u, 0u, 0u);
+    for (int k = 0; k < chunks; ++k) {
+        const uint4 cur = nxt;
+        if (k + 1 < chunks) nxt = row[(size_t)(k + 1) * 64u];
+        const unsigned int w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 pj[4]; typename Op::Field f[4]; bool isB[4], use[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int word = w[h * 2 + (u >> 1)];
+                const unsigned int e = (u & 1) ? (word >> 16) : (word & 0xffffu);
+                use[u] = k * 8 + h * 4 + u < cnt;
+                const unsigned int slot = use[u] ? (e & 0x7fffu) : 0u;          // (slots past the row's end hold stale bits)
+                isB[u] = (e & kBrickBoundaryBit) != 0u;
+                pj[u] = lp[slot]; f[u] = brick_unpack(op, lf[slot]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+                const float r2 = dot3(d, d);
+                const bool on = use[u] && (WANT_BOUNDARY || !isB[u]);
+                body.pair_tol(f[u], isB[u], d, r2, on ? pj[u].w : 0.0f);       // a dropped entry enters with mass 0
+            }
+        }
+    }
+}
+
+// 16-bit row entries are collected 8 at a time and leave as 16-byte chunks
+__device__ __forceinline__ void brick_put_entry(unsigned int* row, int cnt, unsigned int e, uint4& pend, int capEntries)
+{
+    const int w = cnt & 7;
+    const unsigned int sh = (w & 1) ? 16u : 0u, keep = (w & 1) ? 0x0000ffffu : 0xffff0000u;
+    unsigned int* word = (w >> 1) == 0 ? &pend.x : ((w >> 1) == 1 ? &pend.y : ((w >> 1) == 2 ? &pend.z : &pend.w));
+    *word = (*word & keep) | (e << sh);
+    if (w == 7 && cnt < capEntries) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 3) * 256u) = pend;
+}
+// rows of the current slice's own particles: candidates are read from the stage (fluid of the 9 columns, then boundary: the order
+// of a particle's sum is free under the tolerance contract).  Every thread of the block calls it (after brick_stage).
+__device__ __forceinline__ void brick_build_rows(const SweepCtx& c, const BrickTables& T, const float4* lp, int x0, int y0,
+                                                 unsigned int* nbr, int* nbrCount)
+{
+    const int capEntries = 2 * c.cap;
+    for (int p = threadIdx.x; p < T.own; p += kBrickThreads) {
+        const int i = brick_own_index(T, p);
+        const float4 self = c.posm[i];
+        const float3 pi = v3(self.x, self.y, self.z);
+        const int3 c0 = cell_of(pi, c.g);
+        unsigned int* row = nbr + row_base_offset(i, c.cap);
+        const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
+        int cnt = 0; uint4 pend = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+        for (int kind = 0; kind < 2; ++kind) {
+            const int* cs = kind == 0 ? c.csF : c.csB;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int X = c0.x + dx;
+                if (X < 0 || X >= c.g.gx) continue;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int Y = c0.y + dy;
+                    if (Y < 0 || Y >= c.g.gy) continue;
+                    const int base = (X * c.g.gy + Y) * c.g.gz;
+                    const int e = cs[base + zhi + 1];
+                    int j = cs[base + zlo];
+                    const int r = kind * kBrickRuns + (X - (x0 - 1)) * 6 + (Y - (y0 - 1));
+                    const int shift = T.runBase[r] - T.runStart[r];
+                    for (; j < e; ++j) {
+                        const float4 pj = lp[j + shift];
+                        const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                        const float r2 = dot3(d, d);
+                        if (r2 > c.buildCut || (kind == 0 && j == i)) continue;
+                        brick_put_entry(row, cnt, (unsigned int)(j + shift) | (kind ? kBrickBoundaryBit : 0u), pend, capEntries);
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        nbrCount[i] = cnt;
+        if (cnt > capEntries && c.overflowMax) atomicMax(c.overflowMax, (cnt + 1) / 2);
+        if ((cnt & 7) != 0 && cnt < capEntries) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 3) * 256u) = pend;
     }
 }
 

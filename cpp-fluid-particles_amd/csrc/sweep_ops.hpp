@@ -66,21 +66,84 @@ __device__ __forceinline__ void sweep_any(const Op& op, const SweepCtx& c, float
 {
     if constexpr (MODE == 1) sweep_quad<WANT_BOUNDARY>(op, c, i, valid, pi, body);
     else if constexpr (MODE == 2) sweep_duo<WANT_BOUNDARY>(op, c, i, valid, pi, body);
+    else if constexpr (MODE == 3) sweep_brick<WANT_BOUNDARY>(op, c, lp, lf, i, valid, pi, body);      // rows of LDS slots (compact brick)
     else sweep<WANT_BOUNDARY>(op, c, lp, lf, i, valid, pi, body);
 }
 // quad: every lane holds the sums, lane 0 stores; duo: the sums end in lane 1 of the pair
 template <int MODE> __device__ __forceinline__ bool stores_results(bool valid)
 {
-    return valid && (MODE == 0 || (MODE == 1 && (threadIdx.x & 3) == 0) || (MODE == 2 && (threadIdx.x & 1) == 1));
+    return valid && (MODE == 0 || MODE == 3 || (MODE == 1 && (threadIdx.x & 3) == 0) || (MODE == 2 && (threadIdx.x & 1) == 1));
 }
 // grid of a sweep launch: one wave per tile of the launch's range, padded to a multiple of 8 blocks
 inline unsigned int sweep_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kTile, kWideBlock); }
 inline unsigned int quad_grid(const SweepCtx& c) { return xcd_grid(c.numTiles * kWideBlock, kWideBlock); }   // one block per tile
 inline unsigned int duo_grid(const SweepCtx& c) { return xcd_grid(((c.numTiles + 1) / 2) * kWideBlock, kWideBlock); }   // one block per two tiles
+// ---- compact-brick launches (sph_device.hpp "Compact-brick LDS stage"): one block per brick, all sweeps of the tolerance path ----
+// The block's dynamic LDS: [kBrickSlots + 1 positions | kBrickSlots + 1 field records].
+template <class Field> inline size_t brick_lds_bytes() { return (size_t)(kBrickSlots + 1) * (sizeof(float4) + sizeof(Field)); }
+// Runs `each(i, valid, lp, lf)` for every own particle of this block's brick, slice by slice; all threads of the block take part in
+// every round (valid = false past the end), so `each` may use wave-wide operations.  Returns false when the brick cannot be staged.
+template <class Field, class Stage, class Each>
+__device__ __forceinline__ void brick_run(const SweepCtx& c, Stage&& stage, Each&& each)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char brickLds[];
+    __shared__ BrickTables T;
+    float4* lp = reinterpret_cast<float4*>(brickLds);
+    Field* lf = reinterpret_cast<Field*>(lp + kBrickSlots + 1);
+    const BrickGeom G = brick_geom(c, logical_block());
+    if (!G.any) return;
+    brick_slice_tables(c, T, G.x0, G.y0, G.z0, G.z0 + kBrickEdge);
+    if (T.own == 0) return;                                             // (block-uniform) nothing lives here
+    int parts = 1;
+    if (T.staged > kBrickSlots) {
+        __syncthreads();
+        parts = brick_parts(c, T, G);
+        if (parts == 0) { if (threadIdx.x == 0 && c.brickFault) *c.brickFault = 1; return; }
+    }
+    const int h = kBrickEdge / parts;
+#pragma unroll 1
+    for (int sl = 0; sl < parts; ++sl) {
+        if (parts > 1) brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
+        brick_stage(c, T, lp, lf, stage);
+        for (int p0 = 0; p0 < T.own; p0 += kBrickThreads) {
+            const int p = p0 + (int)threadIdx.x;
+            const bool valid = p < T.own;
+            each(valid ? brick_own_index(T, p) : 0, valid, lp, lf);
+        }
+        __syncthreads();                                                // the stage is reused by the next slice
+    }
+}
+template <class Op>
+__global__ void __launch_bounds__(kBrickThreads, 4) k_brick_op(const Op op, int n)
+{
+    (void)n;
+    assume_arith<1>(op.c);
+    using BF = brick_field_t<Op>;
+    brick_run<BF>(op.c, [&](bool isB, int u) { return brick_pack(op, op.stage(isB, u)); },
+                  [&](int i, bool valid, float4* lp, BF* lf) { op.template operator()<3>(i, valid, lp, reinterpret_cast<typename Op::Field*>(lf)); });
+}
+template <class Kernel>
+inline void brick_launch_prepare(Kernel kernel, size_t ldsBytes)
+{
+    // more than 64 KB of dynamic LDS must be asked for once per kernel
+    static thread_local const void* seen[64]; static thread_local int nSeen = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (int k = 0; k < nSeen; ++k) if (seen[k] == fn) return;
+    HIP_CALL(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    if (nSeen < 64) seen[nSeen++] = fn;
+}
+inline unsigned int brick_grid(const SweepCtx& c) { return xcd_grid(brick_count(c.g) * kBrickThreads, kBrickThreads); }
+
 template <class Op>
 inline void launch_op(const Op& op, int n)
 {
     if (n <= 0 || op.c.numTiles <= 0) return;
+    if (op.c.brick) {
+        const size_t lds = brick_lds_bytes<brick_field_t<Op>>();
+        brick_launch_prepare(k_brick_op<Op>, lds);
+        k_brick_op<Op><<<brick_grid(op.c), kBrickThreads, lds, stream()>>>(op, n);
+        return;
+    }
     if (op.c.nbr && op.c.tileFmt) k_run_op<Op, true><<<sweep_grid(op.c), kWideBlock, 0, stream()>>>(op, n);
     else if constexpr (op_quad_bit<Op>() != 0) {
         if (op.c.nbr && (op.c.quad & op_quad_bit<Op>())) {
@@ -280,12 +343,13 @@ struct OpSurface {
     };
     // (no quad variant: strict arithmetic adds two terms per entry to one accumulator, which the ordered one-term-per-lane
     // accumulation cannot reproduce; under the tolerance arithmetic the quad kernel needs ~100 VGPRs + scratch and measured 5x slower)
+    template <int MODE = 0>         // 0 lane-per-particle over global rows, 3 compact brick
     __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body b{*this, sc, sc.dii, sc.li, sc.ml, v3(0, 0, 0)};
-        sweep<false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
+        sweep_any<MODE, false>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!valid) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
@@ -347,12 +411,17 @@ struct OpSurfaceThen {
             f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); f(b.x, other.b.x); f(b.y, other.b.y); f(b.z, other.b.z);
         }
     };
-    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const      // (lane-per-particle only, see OpSurface)
+    // the brick stage keeps (colour gradient, scalar) in ONE 16-byte record
+    using BrickField = float4;
+    __device__ __forceinline__ BrickField brick_pack(const Field& f) const { return make_float4(f.cg.x, f.cg.y, f.cg.z, f.s); }
+    __device__ __forceinline__ Field brick_unpack(const BrickField& t) const { return Field{make_float4(t.x, t.y, t.z, 0.0f), t.w}; }
+    template <int MODE = 0>         // 0 lane-per-particle over global rows (no quad variant, see OpSurface), 3 compact brick
+    __device__ void operator()(int i, bool valid, float4* lp, Field* lf) const
     {
         const float3 cgi = valid ? colorGrad[i] : v3(0, 0, 0);
         const SurfaceConsts sc = surface_consts(cgi, valid ? c.posm[i].w : 0.0f, rho0, tension, airPressure);
         Body body{*this, sc, sc.dii, sc.li, sc.ml, valid ? scalar[i] : 0.0f, v3(0, 0, 0), v3(0, 0, 0)};
-        sweep<true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
+        sweep_any<MODE, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), body);
         if (!valid) return;
         float3 v = velIn[i];
         if (addend) v = add3(v, addend[i]);
@@ -545,9 +614,36 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_group(
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool WITH_RATE>
+__global__ void __launch_bounds__(kBrickThreads, 4) k_dfsph_head_brick(const OpDfsphHeadT<WITH_RATE> o, int n)
+{
+    (void)n;
+    assume_arith<1>(o.c);
+    using Op = OpDfsphHeadT<WITH_RATE>;
+    brick_run<typename Op::Field>(o.c, [&](bool isB, int u) { return o.stage(isB, u); },
+        [&](int i, bool valid, float4* lp, typename Op::Field* lf) {
+            long long fixed = 0;
+            const float3 own = (WITH_RATE && valid) ? o.vel[i] : v3(0, 0, 0);
+            typename Op::Body b{o, own.x, own.y, own.z, 0.0f, 0.0f, 0.0f, v3(0, 0, 0)};
+            sweep_brick<true>(o, o.c, lp, lf, i, valid, own_pos(o.c, i, valid), b);
+            if (valid) {
+                const float al = -1.0f / max_eps(dot3(b.gs, b.gs) + b.sl);
+                o.density[i] = b.den;
+                o.alpha[i] = al;
+                if (WITH_RATE) fixed = finish_rate<false, 0>(o.out, i, b.e, b.den, al);
+            }
+            if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
+        });
+}
+template <bool WITH_RATE>
 inline void launch_dfsph_head(const OpDfsphHeadT<WITH_RATE>& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
+    if (o.c.brick) {
+        const size_t lds = brick_lds_bytes<typename OpDfsphHeadT<WITH_RATE>::Field>();
+        brick_launch_prepare(k_dfsph_head_brick<WITH_RATE>, lds);
+        k_dfsph_head_brick<WITH_RATE><<<brick_grid(o.c), kBrickThreads, lds, stream()>>>(o, n);
+        return;
+    }
     if (o.c.nbr && o.c.tileFmt) k_dfsph_head<WITH_RATE, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else if (o.c.nbr && (o.c.quad & kQuadHead)) {
         if (o.c.k.tol) k_dfsph_head_group<WITH_RATE, 1, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
@@ -643,9 +739,30 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_rate(const OpRate
     if (o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool DENSITY_MODE, int WARM>
+__global__ void __launch_bounds__(kBrickThreads, 4) k_rate_brick(const OpRate o, int n)
+{
+    (void)n;
+    assume_arith<1>(o.c);
+    brick_run<OpRate::Field>(o.c, [&](bool isB, int u) { return o.stage(isB, u); },
+        [&](int i, bool valid, float4* lp, OpRate::Field* lf) {
+            long long fixed = 0;
+            const float3 own = valid ? o.vel[i] : v3(0, 0, 0);
+            OpRate::Body b{o, own.x, own.y, own.z, 0.0f};
+            sweep_brick<true>(o, o.c, lp, lf, i, valid, own_pos(o.c, i, valid), b);
+            if (valid) fixed = finish_rate<DENSITY_MODE, WARM>(o.out, i, b.e, o.density[i], o.alpha[i]);
+            if (o.out.accum) accumulate_error(fixed, o.out.accum);
+        });
+}
+template <bool DENSITY_MODE, int WARM>
 inline void launch_rate_kernel(const OpRate& o, int n)
 {
     if (n <= 0 || o.c.numTiles <= 0) return;
+    if (o.c.brick) {
+        const size_t lds = brick_lds_bytes<OpRate::Field>();
+        brick_launch_prepare(k_rate_brick<DENSITY_MODE, WARM>, lds);
+        k_rate_brick<DENSITY_MODE, WARM><<<brick_grid(o.c), kBrickThreads, lds, stream()>>>(o, n);
+        return;
+    }
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else if (o.c.nbr && (o.c.quad & kQuadRate)) {
         if (o.c.k.tol) k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
