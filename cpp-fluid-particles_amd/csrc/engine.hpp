@@ -87,8 +87,10 @@ struct SweepCache {
     // compact-brick LDS stage (tolerance arithmetic): rows hold 16-bit LDS slots, every sweep runs one block per brick
     bool brickWanted = true, brickFailed = false, listIsBrick = false;
     int brickMin = 2000000;
+    int brickBlocks = 0;                     // blocks per brick launch (about the number of non-empty bricks)
+    std::unique_ptr<DArray<int>> brickTab;   // BrickTables of the non-empty bricks of this step
     bool brickMode() const;
-    DArray<int> rowOverflow;                 // [0]: longest row beyond `cap` since the last check; [1]: brick stage fault flag
+    DArray<int> rowOverflow;                 // [0]: longest row beyond `cap` since the last check; [1]: brick stage fault flag; [2]: non-empty bricks of this step
     int capCheckSteps = 0;
     void tuneRowCapacity(int stepsSinceLastCall);
     int cellOffsetX = 0;                     // sub-grid offset of slab decompositions (GridDesc::xOff)

@@ -417,37 +417,38 @@ __global__ void __launch_bounds__(kWideBlock) k_build_list(SweepCtx c, unsigned 
 
 
 
-// Row builder of the compact-brick path: one block per brick, candidates read from the staged positions, rows of 16-bit slots.
-__global__ void __launch_bounds__(kBrickThreads, 4) k_build_brick(SweepCtx c, unsigned int* nbr, int* nbrCount)
+// The non-empty bricks of this step and their whole-brick tables (one block per brick of the grid; once per step).
+__global__ void __launch_bounds__(256) k_brick_list(SweepCtx c, BrickTables* tab, int* count, int capacity, int* fault)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char brickLds[];
-    __shared__ BrickTables T;
-    float4* lp = reinterpret_cast<float4*>(brickLds);
-    const BrickGeom G = brick_geom(c, logical_block());
+    __shared__ __attribute__((aligned(16))) BrickTables T;
+    __shared__ int slot;
+    const BrickGeom G = brick_geom(c, (int)blockIdx.x);
     if (!G.any) return;
     brick_slice_tables(c, T, G.x0, G.y0, G.z0, G.z0 + kBrickEdge);
     if (T.own == 0) return;
-    int parts = 1;
-    if (T.staged > kBrickSlots) {
+    if (threadIdx.x == 0) { T.x0 = G.x0; T.y0 = G.y0; T.z0 = G.z0; slot = atomicAdd(count, 1); }
+    __syncthreads();
+    if (slot >= capacity) { if (threadIdx.x == 0) { *fault = 1; atomicSub(count, 1); } return; }      // (the host leaves brick mode)
+    if (threadIdx.x < sizeof(BrickTables) / 16) reinterpret_cast<uint4*>(tab + slot)[threadIdx.x] = reinterpret_cast<const uint4*>(&T)[threadIdx.x];
+}
+// Row builder of the compact-brick path: candidates read from the staged positions, rows of 16-bit slots.
+__global__ void __launch_bounds__(kBrickThreads, 4) k_build_brick(SweepCtx c, unsigned int* nbr, int* nbrCount)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char brickLds[];
+    __shared__ __attribute__((aligned(16))) BrickTables T;
+    float4* lp = reinterpret_cast<float4*>(brickLds);
+    brick_for_each_slice(c, T, [&](BrickTables& tab) {
+        brick_stage(c, tab, lp, (float*)nullptr, [](bool, int) { return 0.0f; });
+        brick_build_rows(c, tab, lp, tab.x0, tab.y0, nbr, nbrCount);
         __syncthreads();
-        parts = brick_parts(c, T, G);
-        if (parts == 0) { if (threadIdx.x == 0 && c.brickFault) *c.brickFault = 1; return; }
-    }
-    const int h = kBrickEdge / parts;
-#pragma unroll 1
-    for (int sl = 0; sl < parts; ++sl) {
-        if (parts > 1) brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
-        brick_stage(c, T, lp, (float*)nullptr, [](bool, int) { return 0.0f; });
-        brick_build_rows(c, T, lp, G.x0, G.y0, nbr, nbrCount);
-        __syncthreads();
-    }
+    });
 }
 
 SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
-      staleFlag(3u), rowOverflow(2u)
+      staleFlag(3u), rowOverflow(4u)
 {
     capAuto = true; cap = 48;
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
@@ -568,6 +569,9 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.overflowMax = nullptr;
     c.brick = (use && listIsBrick) ? 1 : 0;
     c.brickFault = rowOverflow.addr(1);
+    c.brickTab = brickTab ? reinterpret_cast<const BrickTables*>(brickTab->addr()) : nullptr;
+    c.brickCount = rowOverflow.addr(2);
+    c.brickBlocks = brickBlocks;
     return c;
 }
 
@@ -586,9 +590,13 @@ void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
     capCheckSteps += stepsSinceLastCall;
     if (capCheckSteps < 8) return;
     capCheckSteps = 0;
-    int words[2] = {0, 0};
-    HIP_CALL(hipMemcpyAsync(words, rowOverflow.addr(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+    int words[3] = {0, 0, 0};
+    HIP_CALL(hipMemcpyAsync(words, rowOverflow.addr(), 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
     HIP_CALL(hipStreamSynchronize(stream()));
+    if (listIsBrick && words[2] > 0) {         // launch about as many blocks as there are bricks (they stride over the list anyway)
+        const int want = std::min(brick_count(g), words[2] + words[2] / 8 + 8);
+        if (want > brickBlocks || want < brickBlocks - brickBlocks / 4) { brickBlocks = want; ++generation; }
+    }
     if (words[1] != 0 && !brickFailed) {       // a single cell's neighbourhood outgrew the brick stage: back to the global rows for good
         fprintf(stderr, "sphx: a brick's one-cell slice exceeded the LDS stage (density far beyond rest): the compact-brick path is switched off; "
                         "the particles of that brick kept their previous values in the sweeps since the last check\n");
@@ -630,8 +638,21 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     }
     listIsBrick = brickMode();
     if (listIsBrick) {
+        // the bricks of this step: list + tables, then the rows.  Launches use `brickBlocks` blocks that stride over the list
+        // (refined from the list length between steps); the table store holds min(all bricks, n / 32 + 4096) entries
+        const int total = brick_count(g);
+        const int capacity = std::min(total, n / 32 + 4096);
+        if (!brickTab || (long long)brickTab->length() < (long long)capacity * (long long)(sizeof(BrickTables) / 4)) {
+            brickTab.reset(new DArray<int>((unsigned)((long long)capacity * (long long)(sizeof(BrickTables) / 4))));
+            ++generation;
+        }
+        if (brickBlocks <= 0) brickBlocks = std::min(total, 8192);
+        HIP_CALL(hipMemsetAsync(rowOverflow.addr(2), 0, sizeof(int), stream()));
+        k_brick_list<<<total, 256, 0, stream()>>>(c, reinterpret_cast<BrickTables*>(brickTab->addr()), rowOverflow.addr(2), capacity, rowOverflow.addr(1));
+        c = ctx(csF, csB); c.nbr = nullptr; c.overflowMax = rowOverflow.addr();      // (now with the table pointers)
+        c.brickTab = reinterpret_cast<const BrickTables*>(brickTab->addr()); c.brickCount = rowOverflow.addr(2); c.brickBlocks = brickBlocks;
         const size_t lds = (size_t)(kBrickSlots + 1) * sizeof(float4);
-        k_build_brick<<<xcd_grid(brick_count(g) * kBrickThreads, kBrickThreads), kBrickThreads, lds, stream()>>>(c, nbr->rows, nbrCount.addr());
+        k_build_brick<<<xcd_grid(brickBlocks * kBrickThreads, kBrickThreads), kBrickThreads, lds, stream()>>>(c, nbr->rows, nbrCount.addr());
     } else launchBuild(c, skinMode ? reinterpret_cast<float4*>(posBuild->addr()) : nullptr, nullptr, nullptr);
     listValid = true;
 }

@@ -478,6 +478,9 @@ struct SweepCtx {
     int* overflowMax;                       // row builder only: longest row that did not fit `cap` (atomicMax; nullptr otherwise)
     int brick;                              // 1: rows hold 16-bit slots of the compact-brick LDS stage (tolerance arithmetic, see "brick" below)
     int* brickFault;                        // device flag: a one-cell slice of some brick exceeded the stage (the host leaves brick mode)
+    const struct BrickTables* brickTab;     // tables of the non-empty bricks (whole-brick slice), built once per step by k_brick_list
+    const int* brickCount;                  // ... and how many there are (device word)
+    int brickBlocks;                        // blocks a brick launch uses (they stride over the list)
 };
 
 // The tile (64 consecutive particles) this wave works on.  Launch order is a free choice — results
@@ -1256,7 +1259,10 @@ struct BrickTables {
     int runBase[2 * kBrickRuns];            // LDS slot of the run's first record
     int ownStart[16], ownLen[16], ownEnd[16];   // the brick's own z-runs (fluid), inclusive prefix of their lengths
     int staged, stagedFluid, own;
+    int x0, y0, z0;                             // first cell of the brick
+    int pad[2];
 };
+static_assert(sizeof(BrickTables) % 16 == 0, "tables are copied as 16-byte words");
 struct BrickGeom { int x0, y0, z0; bool any; };
 
 __device__ __forceinline__ BrickGeom brick_geom(const SweepCtx& c, int b)
@@ -1358,6 +1364,36 @@ __device__ __forceinline__ void brick_stage(const SweepCtx& c, const BrickTables
         }
     }
     __syncthreads();
+}
+// copies the tables k_brick_list left for brick `b` of the list into this block's LDS (ends with a block barrier)
+__device__ __forceinline__ void brick_load_tables(const SweepCtx& c, BrickTables& T, int b)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(c.brickTab + b);
+    uint4* dst = reinterpret_cast<uint4*>(&T);
+    if (threadIdx.x < sizeof(BrickTables) / 16) dst[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+}
+// The slices of brick `b` of the list, one after the other: `perSlice(T)` runs with the slice's tables in LDS (every thread of the
+// block calls it; it must end with a block barrier).  Blocks stride over the list, so any launch size covers it.
+template <class PerSlice>
+__device__ __forceinline__ void brick_for_each_slice(const SweepCtx& c, BrickTables& T, PerSlice&& perSlice)
+{
+    const int count = *c.brickCount;
+#pragma unroll 1
+    for (int b = logical_block(); b < count; b += (int)gridDim.x) {
+        brick_load_tables(c, T, b);
+        if (T.staged <= kBrickSlots) { perSlice(T); continue; }
+        BrickGeom G; G.x0 = T.x0; G.y0 = T.y0; G.z0 = T.z0; G.any = true;
+        __syncthreads();
+        const int parts = brick_parts(c, T, G);
+        if (parts == 0) { if (threadIdx.x == 0 && c.brickFault) *c.brickFault = 1; continue; }
+        const int h = kBrickEdge / parts;
+#pragma unroll 1
+        for (int sl = 0; sl < parts; ++sl) {
+            brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
+            perSlice(T);
+        }
+    }
 }
 constexpr unsigned int kBrickBoundaryBit = 0x8000u;
 // The record an op stages per neighbour is its Field, unless the op names a more compact BrickField (with brick_pack /

@@ -87,31 +87,18 @@ template <class Field, class Stage, class Each>
 __device__ __forceinline__ void brick_run(const SweepCtx& c, Stage&& stage, Each&& each)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char brickLds[];
-    __shared__ BrickTables T;
+    __shared__ __attribute__((aligned(16))) BrickTables T;
     float4* lp = reinterpret_cast<float4*>(brickLds);
     Field* lf = reinterpret_cast<Field*>(lp + kBrickSlots + 1);
-    const BrickGeom G = brick_geom(c, logical_block());
-    if (!G.any) return;
-    brick_slice_tables(c, T, G.x0, G.y0, G.z0, G.z0 + kBrickEdge);
-    if (T.own == 0) return;                                             // (block-uniform) nothing lives here
-    int parts = 1;
-    if (T.staged > kBrickSlots) {
-        __syncthreads();
-        parts = brick_parts(c, T, G);
-        if (parts == 0) { if (threadIdx.x == 0 && c.brickFault) *c.brickFault = 1; return; }
-    }
-    const int h = kBrickEdge / parts;
-#pragma unroll 1
-    for (int sl = 0; sl < parts; ++sl) {
-        if (parts > 1) brick_slice_tables(c, T, G.x0, G.y0, G.z0 + sl * h, G.z0 + (sl + 1) * h);
-        brick_stage(c, T, lp, lf, stage);
-        for (int p0 = 0; p0 < T.own; p0 += kBrickThreads) {
+    brick_for_each_slice(c, T, [&](BrickTables& tab) {
+        brick_stage(c, tab, lp, lf, stage);
+        for (int p0 = 0; p0 < tab.own; p0 += kBrickThreads) {
             const int p = p0 + (int)threadIdx.x;
-            const bool valid = p < T.own;
-            each(valid ? brick_own_index(T, p) : 0, valid, lp, lf);
+            const bool valid = p < tab.own;
+            each(valid ? brick_own_index(tab, p) : 0, valid, lp, lf);
         }
-        __syncthreads();                                                // the stage is reused by the next slice
-    }
+        __syncthreads();                                                // the stage and the tables are reused
+    });
 }
 template <class Op>
 __global__ void __launch_bounds__(kBrickThreads, 4) k_brick_op(const Op op, int n)
@@ -132,7 +119,7 @@ inline void brick_launch_prepare(Kernel kernel, size_t ldsBytes)
     HIP_CALL(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     if (nSeen < 64) seen[nSeen++] = fn;
 }
-inline unsigned int brick_grid(const SweepCtx& c) { return xcd_grid(brick_count(c.g) * kBrickThreads, kBrickThreads); }
+inline unsigned int brick_grid(const SweepCtx& c) { return xcd_grid(c.brickBlocks * kBrickThreads, kBrickThreads); }
 
 template <class Op>
 inline void launch_op(const Op& op, int n)
