@@ -85,7 +85,7 @@ struct SweepCache {
     // the row slab (192 instead of 384 bytes per particle).
     bool capAuto = false;
     // compact-brick LDS stage (tolerance arithmetic): rows hold 16-bit LDS slots, every sweep runs one block per brick
-    bool brickWanted = true, brickFailed = false, listIsBrick = false;
+    bool brickWanted = false, brickFailed = false, listIsBrick = false;      // opt-in (SPHX_BRICK=1): measured 18 % slower than the quad walks
     int brickMin = 2000000;
     int brickBlocks = 0;                     // blocks per brick launch (about the number of non-empty bricks)
     std::unique_ptr<DArray<int>> brickTab;   // BrickTables of the non-empty bricks of this step

@@ -1430,24 +1430,24 @@ __device__ __forceinline__ void sweep_brick(const Op& op, const SweepCtx& c, con
         const uint4 cur = nxt;
         if (k + 1 < chunks) nxt = row[(size_t)(k + 1) * 64u];
         const unsigned int w[4] = {cur.x, cur.y, cur.z, cur.w};
+        {
+            constexpr int E = 8;                                               // the whole chunk in flight: 16 LDS reads, then 8 pair terms
+            float4 pj[E]; brick_field_t<Op> fr[E]; bool isB[E], use[E];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 pj[4]; typename Op::Field f[4]; bool isB[4], use[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned int word = w[h * 2 + (u >> 1)];
+            for (int u = 0; u < E; ++u) {
+                const unsigned int word = w[u >> 1];
                 const unsigned int e = (u & 1) ? (word >> 16) : (word & 0xffffu);
-                use[u] = k * 8 + h * 4 + u < cnt;
+                use[u] = k * 8 + u < cnt;
                 const unsigned int slot = use[u] ? (e & 0x7fffu) : 0u;          // (slots past the row's end hold stale bits)
                 isB[u] = (e & kBrickBoundaryBit) != 0u;
-                pj[u] = lp[slot]; f[u] = brick_unpack(op, lf[slot]);
+                pj[u] = lp[slot]; fr[u] = lf[slot];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < E; ++u) {
                 const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
                 const float r2 = dot3(d, d);
                 const bool on = use[u] && (WANT_BOUNDARY || !isB[u]);
-                body.pair_tol(f[u], isB[u], d, r2, on ? pj[u].w : 0.0f);       // a dropped entry enters with mass 0
+                body.pair_tol(brick_unpack(op, fr[u]), isB[u], d, r2, on ? pj[u].w : 0.0f);       // a dropped entry enters with mass 0
             }
         }
     }
@@ -1490,6 +1490,19 @@ __device__ __forceinline__ void brick_build_rows(const SweepCtx& c, const BrickT
                     int j = cs[base + zlo];
                     const int r = kind * kBrickRuns + (X - (x0 - 1)) * 6 + (Y - (y0 - 1));
                     const int shift = T.runBase[r] - T.runStart[r];
+                    for (; j + 4 <= e; j += 4) {                      // 4 candidates in flight: one LDS round trip per 4 tests
+                        float4 pj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pj[u] = lp[j + u + shift];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+                            const float r2 = dot3(d, d);
+                            if (r2 > c.buildCut || (kind == 0 && j + u == i)) continue;
+                            brick_put_entry(row, cnt, (unsigned int)(j + u + shift) | (kind ? kBrickBoundaryBit : 0u), pend, capEntries);
+                            ++cnt;
+                        }
+                    }
                     for (; j < e; ++j) {
                         const float4 pj = lp[j + shift];
                         const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));

@@ -177,3 +177,33 @@ def test_tolerance_mode_is_opt_in_and_validated(sphx):
     P.reserved[3] = 7
     h = C.c_void_p()
     assert sphx.lib().sphx_create(C.byref(P), fluid.ctypes.data, len(fluid), boundary.ctypes.data, len(boundary), 1, C.byref(h)) == -1
+
+
+@pytest.mark.parametrize("solver,dt", [(0, 0.001), (1, 0.002)])
+def test_compact_brick_schedule_meets_the_tolerance_contract(sphx, oracle, solver, dt, monkeypatch):
+    """the opt-in LDS-staged schedule (SPHX_BRICK=1: one block per 4x4x4-cell brick, neighbour records staged in LDS, rows of
+    16-bit slots) under the same contract as the default tolerance path: 40 steps of the reference scene
+    within 1e-5 of the oracle with identical cell indices, and through the landing inside the one-ulp envelope.  Forced onto
+    this small scene with SPHX_BRICK_MIN=1; a second run with a tiny row capacity exercises the row-overflow fallback."""
+    monkeypatch.setenv("SPHX_BRICK", "1"); monkeypatch.setenv("SPHX_BRICK_MIN", "1")
+    def tweak(P):
+        P.dt = dt
+        P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    for cap in (None, "12"):
+        if cap:
+            monkeypatch.setenv("SPHX_NBR_CAP", cap)
+        gs, os_, P = _pair(sphx, oracle, 24, solver, tweak)
+        worst = 0.0
+        for s in range(40 if cap is None else 6):
+            gs.step(); os_.step()
+            assert np.array_equal(gs.get(sphx.F_ID), os_.get(oracle.F_ID)) and np.array_equal(gs.get(sphx.F_CELL), os_.get(oracle.F_CELL)), s
+            worst = max(worst, _rel(gs.get(sphx.F_POS), os_.get(oracle.F_POS), P.space[0]), _rel(gs.get(sphx.F_DENSITY), os_.get(oracle.F_DENSITY), P.rho0))
+        assert 0.0 < worst <= TOL, "cap %s: %.2e" % (cap, worst)
+        gs.close(); os_.close()
+    monkeypatch.delenv("SPHX_NBR_CAP")
+    k0, h_tol = (125, 15) if solver == 0 else (55, 10)
+    g, o, P, gp = restart_pair(sphx, oracle, solver, dt, k0, perturbed=True)
+    for s in range(1, h_tol + 1):
+        g.step(); o.step()
+        d = deviations_by_particle(sphx, oracle, g, sphx, o, P)
+        assert d["pos_elem"] <= TOL and d["rho_elem"] <= TOL, (s, d)
