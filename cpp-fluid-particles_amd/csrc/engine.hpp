@@ -97,6 +97,7 @@ struct SweepCache {
     int flags = 0;
     int quadMask = 1;                        // QuadBits (sweep_ops.hpp): sweeps that run quad-per-particle when rows exist
     int duoMask = 0;                         // QuadBits: sweeps that run with two lanes per particle
+    int duoMaskLarge = 6;                    // ... additionally from 4 M particles on: head (2) and viscosity+colour (4)
     int quadMaskTol = 15;                    // tolerance arithmetic, quad walks with per-lane partial sums + one DPP reduction (r03, 10.3 M particles):
                                              // head -11 %, viscosity+colour -26 %, corrections -2..4 %; the surface sweeps (3 gathers, ~100 VGPRs)
                                              // lose 5x and stay lane-per-particle.  Below 4 M particles the corrections stay lane-per-particle too (mask & 7)

@@ -454,7 +454,7 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
-    if (const char* e = getenv("SPHX_DUO_MASK")) duoMask = atoi(e);            // ... and which with two lanes per particle
+    if (const char* e = getenv("SPHX_DUO_MASK")) { duoMask = atoi(e); duoMaskLarge = 0; }   // ... and which with two lanes per particle
     if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
     if (const char* e = getenv("SPHX_BRICK")) brickWanted = atoi(e) != 0;      // compact-brick LDS stage under the tolerance arithmetic
     if (const char* e = getenv("SPHX_BRICK_MIN")) brickMin = atoi(e);
@@ -546,7 +546,9 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     // (strict: the surface sweeps add TWO terms per entry to one accumulator, (a + t1) + t2, which the ordered one-term-per-lane
     // accumulation of the quad walk cannot reproduce: they stay lane-per-particle whatever the mask says)
     c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? (n >= 4000000 ? quadMaskTol : (quadMaskTol & 7)) : (quadMask & ~kQuadSurfaceBit)) : 0;
-    c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? duoMask : 0;
+    // two lanes per particle: from 4 M particles on the head and the viscosity+colour sweep gain 7-8 % (r03: 1.10 -> 1.02 ms and
+    // 1.18 -> 1.09 ms at 10.3 M; below, where they are not bound by the L1, they lose 10-25 %: r02)
+    c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (n >= 4000000 ? (duoMask | duoMaskLarge) : duoMask) : 0;
     c.n = n;
     c.vel4 = vel4w();
     c.cg4 = cg4w();
