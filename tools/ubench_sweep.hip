@@ -313,6 +313,56 @@ __global__ void __launch_bounds__(256) k_qgi(Consts c, const float4* __restrict_
     if (ip < n && (lane % G) == 0) out[i] = e;
 }
 
+
+// ---- QG16: the quad walk (G = 4, E = 1, 4 steps in flight) on 16-bit tile-relative row entries: entry = column (4 bits) | offset
+// (12 bits) inside the tile's candidate window of that (dx,dy) column; 9 window bases per 16-particle tile.  Halves the row stream.
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_qg16(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                              const unsigned short* __restrict__ rows, const int* __restrict__ tileSteps,
+                                              const int* __restrict__ tileBases, float* __restrict__ out, int n, int numTilesQ, int capSteps)
+{
+    constexpr int G = 4, PPW = 16, U = 4;
+    __shared__ int bases[4][16];
+    const int wave = threadIdx.x >> 6;
+    const int tile = logical_block() * 4 + wave;
+    if (tile >= numTilesQ) return;
+    const int lane = threadIdx.x & 63;
+    if (lane < 16) bases[wave][lane] = lane < 10 ? tileBases[tile * 10 + lane] : n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ip = tile * PPW + lane / G;
+    const int i = min(ip, n - 1);
+    const float4 self = posm[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = vel4[i];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const unsigned short* row = rows + ((size_t)tile * capSteps) * 64u + (unsigned)lane;
+    const int steps = tileSteps[tile];
+    float e = 0.0f;
+    for (int s = 0; s < steps; s += U) {
+        unsigned int idx[U];
+        float4 pj[U], vj[U];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned int raw = (s + u < steps) ? row[(size_t)(s + u) * 64u] : 0x9000u;        // column 9 = the dummy record
+            idx[u] = (unsigned int)bases[wave][raw >> 12] + (raw & 0xfffu);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = pair_term<EXACT>(c, pi, vi, pj[u], vj[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) e += group_term<G>(t[u], g, lane);
+    }
+    if (ip < n && (lane % G) == 0) out[i] = e;
+}
+
 // ---- CQ: lane-per-particle arithmetic and accumulation (as G32c), but the gathers are issued quad-cooperatively: in
 // gather k the 4 lanes of a quad fetch the 4 entries of particle k of the quad (adjacent records), park them in LDS and
 // every lane then reads its own 4 records back.  Rows in the engine's chunk layout: [tile][chunk][lane][4].
@@ -982,6 +1032,50 @@ int main(int argc, char** argv)
                 });
 #undef LQ2
 #undef LQ
+            }
+            {   // the quad walk on 16-bit tile-relative rows
+                static unsigned short* dRows16 = nullptr; static int* dBases = nullptr;
+                const QSet& Q = qsets[1];
+                if (!dRows16) {
+                    std::vector<unsigned short> r16((size_t)Q.numTiles * Q.capSteps * 64, (unsigned short)0x9000u);
+                    std::vector<int> bases((size_t)Q.numTiles * 10, n);
+                    bool fits = true;
+                    for (int tile = 0; tile < Q.numTiles; ++tile) {
+                        const int i0 = tile * 16, i1 = std::min(n, i0 + 16) - 1;
+                        if (i0 >= n) break;
+                        const int cmin = scell[i0], cmax = scell[i1];
+                        int lo9[9], hi9[9];
+                        for (int m = 0; m < 9; ++m) {
+                            const int off = ((m / 3 - 1) * gy + (m % 3 - 1)) * gz;
+                            const int lo = std::min(std::max(cmin + off - 1, 0), C), hi = std::min(std::max(cmax + off + 1, 0), C - 1);
+                            lo9[m] = cs[lo]; hi9[m] = hi >= lo ? cs[hi + 1] : cs[lo];
+                            bases[(size_t)tile * 10 + m] = lo9[m];
+                        }
+                        bases[(size_t)tile * 10 + 9] = n;
+                        for (int p = 0; p < 16 && i0 + p < n; ++p) {
+                            const int i = i0 + p, m_ = cnt[i];
+                            for (int t = 0; t < m_; ++t) {
+                                const int j = nbr[i][t];
+                                int col = -1;
+                                for (int m = 0; m < 9; ++m) if (j >= lo9[m] && j < hi9[m]) { col = m; break; }
+                                if (col < 0 || j - lo9[col] > 4095) { fits = false; continue; }
+                                r16[((size_t)tile * Q.capSteps + t / 4) * 64 + p * 4 + (t % 4)] = (unsigned short)((col << 12) | (j - lo9[col]));
+                            }
+                        }
+                    }
+                    printf("Q4x1 r16 rows: %s\n", fits ? "every entry fits 4+12 bits" : "SOME ENTRIES DO NOT FIT");
+                    CK(hipMalloc(&dRows16, 2 * r16.size())); CK(hipMalloc(&dBases, 4 * bases.size()));
+                    CK(hipMemcpy(dRows16, r16.data(), 2 * r16.size(), hipMemcpyHostToDevice));
+                    CK(hipMemcpy(dBases, bases.data(), 4 * bases.size(), hipMemcpyHostToDevice));
+                }
+                const unsigned gridQ = xcd_grid(Q.numTiles * 64, 256);
+                snprintf(nm, sizeof(nm), "Q4x1 u4 rows16 %s %s", exact ? "exact" : "tol", two ? "2f" : "1f");
+                run(nm, exact, two, [&] {
+                    if (exact) { if (two) hipLaunchKernelGGL((k_qg16<true, true>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRows16, Q.dSteps, dBases, dOut, n, Q.numTiles, Q.capSteps);
+                                 else hipLaunchKernelGGL((k_qg16<true, false>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRows16, Q.dSteps, dBases, dOut, n, Q.numTiles, Q.capSteps); }
+                    else { if (two) hipLaunchKernelGGL((k_qg16<false, true>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRows16, Q.dSteps, dBases, dOut, n, Q.numTiles, Q.capSteps);
+                           else hipLaunchKernelGGL((k_qg16<false, false>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRows16, Q.dSteps, dBases, dOut, n, Q.numTiles, Q.capSteps); }
+                });
             }
             {   // the quad walk on interleaved records (rows of the Q4x1 u4 set)
                 const QSet& Q = qsets[1];
