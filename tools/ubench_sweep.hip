@@ -363,6 +363,52 @@ __global__ void __launch_bounds__(256) k_qg16(Consts c, const float4* __restrict
     if (ip < n && (lane % G) == 0) out[i] = e;
 }
 
+
+// ---- QG3: the quad walk gathering 12-byte records (float3 arrays, global_load_dwordx3) instead of 16-byte ones: if the gather
+// path is bound by bytes per lane, 24 instead of 32 bytes per pair should show
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+template <bool EXACT, bool TWO>
+__global__ void __launch_bounds__(256) k_qg3(Consts c, const F3* __restrict__ pos3, const F3* __restrict__ vel3, float m0,
+                                             const unsigned int* __restrict__ rows, const int* __restrict__ tileSteps,
+                                             float* __restrict__ out, int n, int numTilesQ, int capSteps)
+{
+    constexpr int G = 4, PPW = 16, U = 4;
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTilesQ) return;
+    const int lane = threadIdx.x & 63;
+    const int ip = tile * PPW + lane / G;
+    const int i = min(ip, n - 1);
+    const F3 sp = pos3[i], sv = vel3[i];
+    const float3 pi = v3(sp.x, sp.y, sp.z), vi = v3(sv.x, sv.y, sv.z);
+    const unsigned int* row = rows + ((size_t)tile * capSteps) * 64u + (unsigned)lane;
+    const int steps = tileSteps[tile];
+    float e = 0.0f;
+    for (int s = 0; s < steps; s += U) {
+        unsigned int idx[U];
+        F3 pj[U], vj[U];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = (s + u < steps) ? row[(size_t)(s + u) * 64u] : (unsigned)n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = *reinterpret_cast<const F3*>(reinterpret_cast<const char*>(pos3) + idx[u] * 12u);
+            if (TWO) vj[u] = *reinterpret_cast<const F3*>(reinterpret_cast<const char*>(vel3) + idx[u] * 12u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mj = idx[u] == (unsigned)n ? 0.0f : m0;
+            const float4 p4 = make_float4(pj[u].x, pj[u].y, pj[u].z, mj);
+            const float4 v4 = TWO ? make_float4(vj[u].x, vj[u].y, vj[u].z, 0.f) : make_float4(mj, 0.f, 0.f, 0.f);
+            t[u] = pair_term<EXACT>(c, pi, vi, p4, v4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) e += group_term<G>(t[u], g, lane);
+    }
+    if (ip < n && (lane % G) == 0) out[i] = e;
+}
+
 // ---- CQ: lane-per-particle arithmetic and accumulation (as G32c), but the gathers are issued quad-cooperatively: in
 // gather k the 4 lanes of a quad fetch the 4 entries of particle k of the quad (adjacent records), park them in LDS and
 // every lane then reads its own 4 records back.  Rows in the engine's chunk layout: [tile][chunk][lane][4].
@@ -1032,6 +1078,26 @@ int main(int argc, char** argv)
                 });
 #undef LQ2
 #undef LQ
+            }
+            {   // the quad walk gathering 12-byte records
+                static F3 *dPos3 = nullptr, *dVel3 = nullptr;
+                const QSet& Q = qsets[1];
+                if (!dPos3) {
+                    std::vector<F3> p3(n + 1), v3h(n + 1);
+                    for (int q = 0; q <= n; ++q) { p3[q] = F3{posm[q].x, posm[q].y, posm[q].z}; v3h[q] = F3{vel4[q].x, vel4[q].y, vel4[q].z}; }
+                    CK(hipMalloc(&dPos3, 12 * (size_t)(n + 1))); CK(hipMalloc(&dVel3, 12 * (size_t)(n + 1)));
+                    CK(hipMemcpy(dPos3, p3.data(), 12 * (size_t)(n + 1), hipMemcpyHostToDevice));
+                    CK(hipMemcpy(dVel3, v3h.data(), 12 * (size_t)(n + 1), hipMemcpyHostToDevice));
+                }
+                const unsigned gridQ = xcd_grid(Q.numTiles * 64, 256);
+                const float m0 = posm[0].w;
+                snprintf(nm, sizeof(nm), "Q4x1 u4 float3 gathers %s %s", exact ? "exact" : "tol", two ? "2f" : "1f");
+                run(nm, exact, two, [&] {
+                    if (exact) { if (two) hipLaunchKernelGGL((k_qg3<true, true>), dim3(gridQ), dim3(256), 0, st, c, dPos3, dVel3, m0, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
+                                 else hipLaunchKernelGGL((k_qg3<true, false>), dim3(gridQ), dim3(256), 0, st, c, dPos3, dVel3, m0, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
+                    else { if (two) hipLaunchKernelGGL((k_qg3<false, true>), dim3(gridQ), dim3(256), 0, st, c, dPos3, dVel3, m0, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
+                           else hipLaunchKernelGGL((k_qg3<false, false>), dim3(gridQ), dim3(256), 0, st, c, dPos3, dVel3, m0, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
+                });
             }
             {   // the quad walk on 16-bit tile-relative rows
                 static unsigned short* dRows16 = nullptr; static int* dBases = nullptr;
