@@ -10,8 +10,13 @@
  * the un-vendored CUDA-Samples helper_math.h; shimming those is not allowed).  The oracle is
  * therefore "parity unpinned" by reference-owned vectors.  It is anchored instead on (1) a
  * line-by-line restatement of the reference arithmetic, each function citing the file:line it
- * follows, and (2) the known-answer digits SURVEY.md §8(c) recorded from the survey's own CPU run
- * of the reference sources (tests/test_oracle_known_answers.py).
+ * follows, (2) the known-answer digits SURVEY.md 8(c) recorded from the survey's own CPU run
+ * of the reference sources (tests/test_cpu_oracle.py), and (3) since r03, CRC-32 anchors of the
+ * complete pos / vel / density arrays of a diagnostic CPU build of the reference's own sources
+ * (stand-in CUDA headers, done once in a scratch directory, nothing of it committed) at every
+ * 10th..50th step through the landing of the column, for all three solvers: this file was
+ * bit-identical to that build on every value (tests/golden/refsrc_anchors.json, README.md there).
+ * That build is evidence, not a sanctioned reference build: the status stays "parity unpinned".
  *
  * Arithmetic contract: IEEE-754 binary32 add/mul/div/sqrt, no FMA contraction
  * (build with -ffp-contract=off), summation in the reference's loop order.  Deliberate, documented
