@@ -227,3 +227,35 @@ def test_reference_source_anchors_wcsph_through_landing(oracle):
 def test_reference_source_anchors_pbd_through_landing(oracle):
     """PBD(k = 20), dt = 0.002, steps 0..80 (landing at step ~60), XSPH in the serial in-place order of the host build."""
     _run_anchor(oracle, "float_fabs", "pbd", oracle.PBD, 80, xsph_mode=1)
+
+
+def _splash_state(n, P, seed):
+    rng = np.random.default_rng(seed)
+    lo = 0.02 * P.space[0]
+    pos = rng.uniform(lo, 0.5 * P.space[0], (n, 3)).astype(np.float32)
+    pos[:, 1] = rng.uniform(lo, 0.35 * P.space[1], n).astype(np.float32)
+    vel = rng.normal(0, 0.8, (n, 3)).astype(np.float32)
+    return pos, vel
+
+
+@pytest.mark.parametrize("name,solver,knobs", [("wcsph", 0, {"pow7_mode": 1}), ("dfsph", 1, {}), ("pbd", 2, {"xsph_mode": 1})])
+def test_reference_source_anchors_disordered_splash(oracle, name, solver, knobs):
+    """ragged cells, particles at the walls from the first step, random velocities, adaptive DFSPH with (9,7) .. (4,2)
+    iterations: the oracle equals the reference sources bit for bit on a disordered state too (30 steps, CRCs every 10)"""
+    V = _anchors()["float_fabs"]["splash_nx12"][name]
+    P, fluid, boundary = oracle.scene(12)
+    P.solver = solver; P.dt = V["dt"]; P.pbd_iters = 20
+    for k, v in knobs.items():
+        setattr(P, k, v)
+    pos, vel = _splash_state(len(fluid), P, V["seed"])
+    s = oracle.System(P, pos, boundary, ctor_step=False)
+    s.set(oracle.F_VEL, vel[s.get(oracle.F_ID)])
+    s.step()                                            # = the constructor's step of the reference flow
+    states = {st["step"]: st for st in V["states"]}
+    for step in range(0, 31):
+        if step:
+            s.step()
+        if step in states:
+            _check_state(s, oracle, states[step], "splash/" + name)
+            if "iters_div_den" in states[step]:
+                assert list(s.iters()) == states[step]["iters_div_den"]

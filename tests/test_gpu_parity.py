@@ -881,3 +881,25 @@ def test_row_capacity_growth_between_graph_replays(sphx, oracle):
             os_.step()
         compare(sphx, oracle, gs, os_, ["POS", "VEL", "DENSITY"], "batch %d" % batch)
     assert sphx.row_capacity(gs) > 48
+
+
+def test_reference_source_anchor_disordered_dfsph_on_gpu(sphx):
+    """the ENGINE against the reference-source CRCs of a disordered splash (tests/golden/refsrc_anchors.json, splash_nx12):
+    adaptive DFSPH, ragged cells and wall contact from the first step, iteration counts (9,7) .. (4,2)"""
+    import json, os
+    V = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "refsrc_anchors.json")))["variants"]["float_fabs"]["splash_nx12"]["dfsph"]
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = sphx.DFSPH; P.dt = V["dt"]
+    pos, vel = _splash_state(len(fluid), P, V["seed"])
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    gs.set(sphx.F_VEL, vel[gs.get(sphx.F_ID)])
+    gs.step()
+    states = {st["step"]: st for st in V["states"]}
+    for step in range(0, 31):
+        if step:
+            gs.step()
+        st = states.get(step)
+        if st:
+            for f, k in ((sphx.F_POS, "crc32_pos"), (sphx.F_VEL, "crc32_vel"), (sphx.F_DENSITY, "crc32_density")):
+                assert _crc_in_particle_order(sphx, gs, f) == st[k], "step %d: %s differs from the reference-source run" % (step, k)
+            assert list(gs.iters()) == st["iters_div_den"], (step, gs.iters())
