@@ -259,3 +259,38 @@ def test_reference_source_anchors_disordered_splash(oracle, name, solver, knobs)
             _check_state(s, oracle, states[step], "splash/" + name)
             if "iters_div_den" in states[step]:
                 assert list(s.iters()) == states[step]["iters_div_den"]
+
+
+def _obstacle_scene(sphx, oracle):
+    P, fluid, shell = oracle.scene(12)
+    box = sphx.sample_box((0.40, 0.0, 0.10), (0.46, 0.15, 0.40), 0.02)
+    ball = sphx.sample_sphere((0.25, 0.02, 0.25), 0.018, 0.01)
+    ramp = sphx.sample_triangles(np.float32([[0.05, 0.0, 0.05, 0.13, 0.0, 0.05, 0.05, 0.06, 0.45],
+                                             [0.13, 0.0, 0.05, 0.13, 0.06, 0.45, 0.05, 0.06, 0.45]]), 0.02)
+    boundary = np.concatenate([shell, box, ball, ramp]).astype(np.float32)
+    vel = np.zeros_like(fluid); vel[:, 1] = -1.5; vel[:, 0] = 0.8
+    return P, fluid, boundary, vel
+
+
+@pytest.mark.parametrize("name,solver,knobs", [("dfsph", 1, {}), ("wcsph", 0, {"pow7_mode": 1})])
+def test_reference_source_anchors_obstacles(sphx, oracle, name, solver, knobs):
+    """computeBoundaryMass_CUDA on a NON-shell boundary set (shell + box + sphere + triangle ramp from the host-side samplers) and
+    the block driven into it: boundary masses and 20 steps of trajectory equal the reference sources bit for bit"""
+    A = _anchors()["float_fabs"]["obstacles_nx12"]
+    P, fluid, boundary, vel = _obstacle_scene(sphx, oracle)
+    assert len(boundary) == A["boundary_count"]
+    P.solver = solver; P.dt = A[name]["dt"]
+    for k, v in knobs.items():
+        setattr(P, k, v)
+    s = oracle.System(P, fluid, boundary, ctor_step=False)
+    assert zlib.crc32(s.get(oracle.F_BMASS).tobytes()) == A["crc32_boundary_mass_sorted"]
+    s.set(oracle.F_VEL, vel[s.get(oracle.F_ID)])
+    s.step()
+    states = {st["step"]: st for st in A[name]["states"]}
+    for step in range(0, 21):
+        if step:
+            s.step()
+        if step in states:
+            _check_state(s, oracle, states[step], "obstacles/" + name)
+            if "iters_div_den" in states[step]:
+                assert list(s.iters()) == states[step]["iters_div_den"]

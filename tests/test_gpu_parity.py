@@ -903,3 +903,26 @@ def test_reference_source_anchor_disordered_dfsph_on_gpu(sphx):
             for f, k in ((sphx.F_POS, "crc32_pos"), (sphx.F_VEL, "crc32_vel"), (sphx.F_DENSITY, "crc32_density")):
                 assert _crc_in_particle_order(sphx, gs, f) == st[k], "step %d: %s differs from the reference-source run" % (step, k)
             assert list(gs.iters()) == st["iters_div_den"], (step, gs.iters())
+
+
+def test_reference_source_anchor_obstacles_dfsph_on_gpu(sphx, oracle):
+    """the ENGINE against the reference-source CRCs of the obstacle scene (refsrc_anchors.json, obstacles_nx12): boundary masses of a
+    non-shell boundary set, then adaptive DFSPH driven into the obstacles, iterations (1,2) -> (7,2) -> (20,2)"""
+    import json, os, zlib
+    from test_cpu_oracle import _obstacle_scene
+    A = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "refsrc_anchors.json")))["variants"]["float_fabs"]["obstacles_nx12"]
+    P, fluid, boundary, vel = _obstacle_scene(sphx, sphx)
+    P.solver = sphx.DFSPH; P.dt = A["dfsph"]["dt"]
+    gs = sphx.System(P, fluid, boundary, ctor_step=False)
+    assert zlib.crc32(gs.get(sphx.F_BMASS).tobytes()) == A["crc32_boundary_mass_sorted"], "boundary masses differ from the reference-source run"
+    gs.set(sphx.F_VEL, vel[gs.get(sphx.F_ID)])
+    gs.step()
+    states = {st["step"]: st for st in A["dfsph"]["states"]}
+    for step in range(0, 21):
+        if step:
+            gs.step()
+        st = states.get(step)
+        if st:
+            for f, k in ((sphx.F_POS, "crc32_pos"), (sphx.F_VEL, "crc32_vel"), (sphx.F_DENSITY, "crc32_density")):
+                assert _crc_in_particle_order(sphx, gs, f) == st[k], "step %d: %s differs from the reference-source run" % (step, k)
+            assert list(gs.iters()) == st["iters_div_den"], (step, gs.iters())
