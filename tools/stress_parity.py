@@ -1,0 +1,113 @@
+"""Randomised parity stress (GPU box): many small random scenes, states, constants and engine schedules; every fp32 and integer field
+of the engine must equal the CPU oracle bit for bit after every step.  python tools/stress_parity.py [cases=150] [first_seed=0]
+Prints one line per failing case (seed + configuration), a summary at the end; exit code 1 on any failure."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+import numpy as np
+import sphx
+from oracle import oracle as O
+
+COMMON = ["POS", "VEL", "DENSITY", "PRESSURE", "CELL", "CELLSTART_F", "ID"]
+EXTRA = {1: ["ALPHA", "KAPPA", "WARM"], 2: ["POS_LAST", "LAMBDA"]}
+
+
+def make_state(rng, n, P):
+    s = P.space[0]
+    kind = rng.integers(0, 5)
+    if kind == 0:      # uniform splash in a random sub-box
+        lo = rng.uniform(0.0, 0.1) * s; hi = rng.uniform(0.3, 0.99) * s
+        pos = rng.uniform(lo, hi, (n, 3))
+        pos[:, 1] = rng.uniform(lo, rng.uniform(0.15, 0.6) * s, n)
+    elif kind == 1:    # jittered lattice block
+        m = int(round(n ** (1 / 3))) + 1
+        g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+        pos = 0.1 * s + 0.02 * g + rng.normal(0, rng.uniform(0, 0.004), (n, 3))
+    elif kind == 2:    # dense blob (long rows, row growth) + sparse rest
+        k = n // 3
+        pos = np.concatenate([rng.normal(0.3 * s, 0.03, (k, 3)), rng.uniform(0.02 * s, 0.9 * s, (n - k, 3))])
+    elif kind == 3:    # thin sheet on the floor and against a wall (clamps, boundary neighbours)
+        pos = rng.uniform(0.0, 0.99 * s, (n, 3)); pos[: n // 2, 1] = rng.uniform(0.0, 0.02, n // 2); pos[n // 2:, 0] = rng.uniform(0.97 * s, 0.99 * s, n - n // 2)
+    else:              # splash with a few particles outside the grid, a few coincident ones, a few exactly on cell faces
+        pos = rng.uniform(0.02 * s, 0.8 * s, (n, 3))
+        pos[:3] = [[-0.3, 0.1, 0.1], [0.1, 5.0, 0.1], [0.2, 0.2, -1.0]]
+        pos[3] = pos[4]; pos[5] = pos[6]
+        pos[7:12] = np.float32(P.cell_length) * rng.integers(1, 5, (5, 3))
+    vel = rng.normal(0, rng.choice([0.0, 0.3, 1.5, 4.0]), (n, 3))
+    return np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(vel, np.float32)
+
+
+def run_case(seed):
+    rng = np.random.default_rng(seed)
+    nx = int(rng.choice([6, 8, 10, 12, 16]))
+    P, fluid, boundary = sphx.scene(nx)
+    solver = int(rng.integers(0, 3))
+    P.solver = solver
+    P.dt = float(rng.choice([0.0005, 0.001, 0.002]))
+    P.pbd_iters = int(rng.integers(1, 6))
+    if rng.random() < 0.5:
+        P.dfsph_fixed_div, P.dfsph_fixed_den = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    if rng.random() < 0.3:
+        P.visc = float(rng.uniform(1e-4, 5e-3)); P.stiff = float(rng.uniform(2, 40))
+    if rng.random() < 0.2:
+        P.surface_tension = 0.0; P.air_pressure = 0.0
+    if rng.random() < 0.15:
+        boundary = boundary[:0]
+    n = int(rng.integers(40, len(fluid)))
+    pos, vel = make_state(rng, n, P)
+    flags = int(rng.choice([0, 0, 0, 1, 2, 16]))
+    env = {}
+    r = rng.random()
+    if r < 0.15: env["SPHX_QUAD_MASK"] = "255"
+    elif r < 0.3: env["SPHX_QUAD_MASK"] = "0"; env["SPHX_DUO_MASK"] = "255"
+    if rng.random() < 0.2: env["SPHX_NBR_CAP"] = str(int(rng.choice([8, 12, 24])))
+    P.reserved[0] = flags
+    for k in ("SPHX_QUAD_MASK", "SPHX_DUO_MASK", "SPHX_NBR_CAP"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    Po = O.Params()
+    for name, _ in P._fields_:
+        setattr(Po, name, getattr(P, name))
+    Po.reserved[0] = 0
+    desc = "seed %d nx %d n %d solver %d dt %g flags %d env %s fixed (%d,%d) pbd %d nb %d" % (seed, nx, n, solver, P.dt, flags, env, P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters, len(boundary))
+    g = sphx.System(P, pos, boundary, ctor_step=False)
+    o = O.System(Po, pos, boundary, ctor_step=False)
+    try:
+        ids = g.get(sphx.F_ID)
+        if not np.array_equal(ids, o.get(O.F_ID)):
+            return desc + " :: initial sort differs"
+        g.set(sphx.F_VEL, vel[ids]); o.set(O.F_VEL, vel[ids])
+        for step in range(int(rng.integers(3, 9))):
+            g.step(); o.step()
+            for nm in COMMON + EXTRA.get(solver, []):
+                a = g.get(getattr(sphx, "F_" + nm)); b = o.get(getattr(O, "F_" + nm))
+                av = a.view(np.uint32) if a.dtype == np.float32 else a
+                bv = b.view(np.uint32) if b.dtype == np.float32 else b
+                if av.shape != bv.shape or not np.array_equal(av, bv):
+                    bad = int(np.count_nonzero(av != bv)) if av.shape == bv.shape else -1
+                    return desc + " :: step %d field %s: %d elements differ" % (step + 1, nm, bad)
+            if solver == 1 and g.iters() != o.iters():
+                return desc + " :: step %d iterations %s vs %s" % (step + 1, g.iters(), o.iters())
+    finally:
+        g.close(); o.close()
+    return None
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    O.lib().oracle_set_threads(min(O.lib().oracle_max_threads(), 32))
+    t0 = time.time(); failures = []
+    for seed in range(first, first + cases):
+        try:
+            f = run_case(seed)
+        except Exception as e:      # an engine error is a finding too
+            f = "seed %d :: exception %r" % (seed, e)
+        if f:
+            failures.append(f); print("FAIL", f, flush=True)
+    print("stress parity: %d cases (seeds %d..%d), %d failures, %.0f s" % (cases, first, first + cases - 1, len(failures), time.time() - t0))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
