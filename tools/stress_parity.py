@@ -1,5 +1,5 @@
 """Randomised parity stress (GPU box): many small random scenes, states, constants and engine schedules; every fp32 and integer field
-of the engine must equal the CPU oracle bit for bit after every step.  python tools/stress_parity.py [cases=150] [first_seed=0]
+of the engine must equal the CPU oracle bit for bit after every step.  python tools/stress_parity.py [cases=150] [first_seed=0] [report file]
 Prints one line per failing case (seed + configuration), a summary at the end; exit code 1 on any failure."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -105,7 +105,12 @@ def main():
             f = "seed %d :: exception %r" % (seed, e)
         if f:
             failures.append(f); print("FAIL", f, flush=True)
-    print("stress parity: %d cases (seeds %d..%d), %d failures, %.0f s" % (cases, first, first + cases - 1, len(failures), time.time() - t0))
+    summary = "stress parity: %d cases (seeds %d..%d), %d failures, %.0f s" % (cases, first, first + cases - 1, len(failures), time.time() - t0)
+    sys.stdout.flush()
+    sys.stderr.write("\n" + "\n".join(["FAIL " + f for f in failures] + [summary]) + "\n")      # (stdout also carries the engine's own prints)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            f.write("\n".join(["FAIL " + x for x in failures] + [summary]) + "\n")
     sys.exit(1 if failures else 0)
 
 
