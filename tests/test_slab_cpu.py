@@ -109,8 +109,11 @@ def test_native_layer_cut_planning_matches_protocol_driver(sphx):
     assert sphx.slab_cut_rule(1200, 1000, 10, 10) == -1
     assert sphx.slab_cut_rule(1000, 1200, 10, 10) == +1
     assert sphx.slab_cut_rule(1040, 1000, 10, 10) == 0
-    assert sphx.slab_cut_rule(1200, 1000, 4, 10) == 0 and sphx.slab_cut_rule(1200, 1000, 5, 10) == -1
-    assert sphx.slab_cut_rule(1000, 1200, 10, 5, ghost=2) == 0 and sphx.slab_cut_rule(1000, 1200, 10, 6, ghost=2) == +1
+    assert sphx.slab_cut_rule(1200, 1000, 4, 10) == 0 and sphx.slab_cut_rule(2000, 1000, 5, 10) == -1
+    assert sphx.slab_cut_rule(1000, 1200, 10, 5, ghost=2) == 0 and sphx.slab_cut_rule(1000, 2000, 10, 6, ghost=2) == +1
+    # ... and never when the column that would move outweighs the difference (that only swaps the roles: r03, 10 M over 8 slabs)
+    assert sphx.slab_cut_rule(1200, 1000, 5, 10) == 0          # a column of the heavier slab ~ 240 > 200
+    assert sphx.slab_cut_rule(1407900, 1191300, 13, 11) == -1 and sphx.slab_cut_rule(1353750, 1245450, 12, 11) == 0
     rng = np.random.default_rng(3)
     for _ in range(200):                                # mirror symmetry: swapping the sides flips the decision
         a, b = (int(v) for v in rng.integers(1, 5000, 2)); wa, wb = (int(v) for v in rng.integers(2, 12, 2))
