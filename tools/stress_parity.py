@@ -1,5 +1,5 @@
 """Randomised parity stress (GPU box): many small random scenes, states, constants and engine schedules; every fp32 and integer field
-of the engine must equal the CPU oracle bit for bit after every step.  python tools/stress_parity.py [cases=150] [first_seed=0] [report file]
+of the engine must equal the CPU oracle bit for bit after every step.  python tools/stress_parity.py [cases=150] [first_seed=0] [report file] [tol]
 Prints one line per failing case (seed + configuration), a summary at the end; exit code 1 on any failure."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,7 +93,51 @@ def run_case(seed):
     return None
 
 
+def run_case_tolerance(seed):
+    """the same random cases under the tolerance arithmetic (incl. its quad walks, forced on with SPHX_QUAD_MASK_TOL): integer
+    fields identical, fp32 fields within 1e-3 of their scale after 2 steps -- a net for gross errors (dropped entries, wrong
+    reductions), not the 1e-5 contract, which tests/test_gpu_tolerance.py holds on well-conditioned states"""
+    rng = np.random.default_rng(seed)
+    nx = int(rng.choice([8, 10, 12, 16]))
+    P, fluid, boundary = sphx.scene(nx)
+    solver = int(rng.integers(0, 3))
+    P.solver = solver; P.dt = float(rng.choice([0.0005, 0.001])); P.pbd_iters = int(rng.integers(1, 4))
+    P.dfsph_fixed_div, P.dfsph_fixed_den = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+    n = int(rng.integers(64, len(fluid)))
+    pos, vel = make_state(rng, n, P)
+    vel *= np.float32(0.3)
+    for k in ("SPHX_QUAD_MASK", "SPHX_DUO_MASK", "SPHX_NBR_CAP", "SPHX_QUAD_MASK_TOL"):
+        os.environ.pop(k, None)
+    os.environ["SPHX_QUAD_MASK_TOL"] = str(int(rng.choice([0, 1, 7, 15, 255])))
+    Po = O.Params()
+    for name, _ in P._fields_:
+        setattr(Po, name, getattr(P, name))
+    P.reserved[3] = 1
+    desc = "tol seed %d nx %d n %d solver %d quadmask %s" % (seed, nx, n, solver, os.environ["SPHX_QUAD_MASK_TOL"])
+    g = sphx.System(P, pos, boundary, ctor_step=False)
+    o = O.System(Po, pos, boundary, ctor_step=False)
+    try:
+        ids = g.get(sphx.F_ID)
+        g.set(sphx.F_VEL, vel[ids]); o.set(O.F_VEL, vel[ids])
+        for step in range(2):
+            g.step(); o.step()
+        if not np.array_equal(g.get(sphx.F_ID), o.get(O.F_ID)):
+            return None          # a particle ended on the other side of a cell face: orders differ, nothing to compare index by index
+        for nm, scale in (("POS", P.space[0]), ("DENSITY", max(float(np.abs(o.get(O.F_DENSITY)).max()), 1e-6)), ("VEL", max(float(np.abs(o.get(O.F_VEL)).max()), 1e-3))):
+            a = g.get(getattr(sphx, "F_" + nm)).astype(np.float64); b = o.get(getattr(O, "F_" + nm)).astype(np.float64)
+            if not np.isfinite(b).all():
+                return None
+            dev = float(np.abs(a - b).max() / scale)
+            if not (dev <= 1e-3):
+                return desc + " :: %s deviates by %.2e of its scale" % (nm, dev)
+    finally:
+        g.close(); o.close(); os.environ.pop("SPHX_QUAD_MASK_TOL", None)
+    return None
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "tol":
+        globals()["run_case"] = run_case_tolerance
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     O.lib().oracle_set_threads(min(O.lib().oracle_max_threads(), 32))
