@@ -144,8 +144,10 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total)
     return base + incl - v;
 }
 
-__global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int* __restrict__ blockSums, int n)
+// (guard: when given and *guard == guardEq the launch has nothing to do -- the out-of-grid ranks of a step without out-of-grid particles)
+__global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int* __restrict__ blockSums, int n, const int* __restrict__ guard = nullptr, int guardEq = 0)
 {
+    if (guard && *guard == guardEq) return;
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int v[kScanItems];
     int sum = 0;
@@ -158,8 +160,9 @@ __global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int*
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 // one block walks all tile totals with a running carry (any length)
-__global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ blockSums, int m)
+__global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ blockSums, int m, const int* __restrict__ guard = nullptr, int guardEq = 0)
 {
+    if (guard && *guard == guardEq) return;
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -175,8 +178,9 @@ __global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ block
         __syncthreads();
     }
 }
-__global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict__ blockSums, int n)
+__global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict__ blockSums, int n, const int* __restrict__ guard = nullptr, int guardEq = 0)
 {
+    if (guard && *guard == guardEq) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) data[i] += blockSums[i / kScanTile];
 }
@@ -193,8 +197,9 @@ __global__ void k_place(int* __restrict__ order, const int* __restrict__ p2c, co
 // The out-of-grid sentinel bucket can hold any number of particles (a blown-up run, parked slots),
 // so its stable rank comes from an exclusive scan of the "is out of grid" flags instead of the
 // quadratic bucket loop.
-__global__ void k_flag_out_of_grid(int* __restrict__ flag, const int* __restrict__ p2c, int sentinel, int n)
+__global__ void k_flag_out_of_grid(int* __restrict__ flag, const int* __restrict__ p2c, int sentinel, int n, const int* __restrict__ guard, int guardEq)
 {
+    if (*guard == guardEq) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= n) flag[i] = (i < n && p2c[i] == sentinel) ? 1 : 0;
 }
@@ -214,6 +219,23 @@ __global__ void k_stable_rank(int* __restrict__ perm, const int* __restrict__ or
     int rank = 0;
     for (int t = s; t < e; ++t) rank += (order[t] < i) ? 1 : 0;
     perm[s + rank] = i;
+}
+
+// the sort's payload in one pass each way: positions, velocities and ids follow the permutation (into scratch), then go back
+__global__ void k_gather_sorted(float3* __restrict__ tp, float3* __restrict__ tv, int* __restrict__ ti, const float3* __restrict__ pos,
+                                const float3* __restrict__ vel, const int* __restrict__ id, const int* __restrict__ perm, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = perm[i];
+    tp[i] = pos[p]; tv[i] = vel[p]; ti[i] = id[p];
+}
+__global__ void k_copy_back_sorted(float3* __restrict__ pos, float3* __restrict__ vel, int* __restrict__ id, const float3* __restrict__ tp,
+                                   const float3* __restrict__ tv, const int* __restrict__ ti, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pos[i] = tp[i]; vel[i] = tv[i]; id[i] = ti[i];
 }
 
 // computeBoundaryMass_CUDA, SPHSystem.cu:79-105: mass_b = rhoB / max(EPS, sum_j W_ij) over the
@@ -447,20 +469,30 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
     if (num <= 0) return;
     {
         ScopedKernel t("grid_stable_rank");
-        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num);
-        exclusiveScan(_grid->outRank.addr(), num + 1);
+        // the sentinel bucket's ranks: after the scan cellStart[C] = num - (out-of-grid particles), so "== num" means there are
+        // none and the flag + scan launches (4 passes over num + 1 words) return at once
+        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
+        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
+        {
+            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
+            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            if (tiles > 1) {
+                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
+                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            }
+        }
         k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
         k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(),
                                                        num, cellsPlusOne);
     }
     {
         ScopedKernel t("grid_gather");
-        ew_gather_float3(_grid->tmp3.addr(), particles->getPosPtr(), perm, num);
-        ew_copy(particles->getPosPtr(), _grid->tmp3.addr(), sizeof(float3) * num);
-        ew_gather_float3(_grid->tmp3.addr(), particles->getVelPtr(), perm, num);
-        ew_copy(particles->getVelPtr(), _grid->tmp3.addr(), sizeof(float3) * num);
-        ew_gather_int(_grid->tmpi.addr(), particles->getIdPtr(), perm, num);
-        ew_copy(particles->getIdPtr(), _grid->tmpi.addr(), sizeof(int) * num);
+        // (the boundary-mass scratch, 16 bytes per particle and idle after construction, is the second float3 target)
+        float3* tv = reinterpret_cast<float3*>(_grid->posm.addr());
+        k_gather_sorted<<<blocks_for(num), 256, 0, st>>>(_grid->tmp3.addr(), tv, _grid->tmpi.addr(), particles->getPosPtr(), particles->getVelPtr(),
+                                                         particles->getIdPtr(), perm, num);
+        k_copy_back_sorted<<<blocks_for(num), 256, 0, st>>>(particles->getPosPtr(), particles->getVelPtr(), particles->getIdPtr(), _grid->tmp3.addr(), tv,
+                                                            _grid->tmpi.addr(), num);
     }
 }
 
