@@ -314,6 +314,61 @@ __global__ void __launch_bounds__(256) k_qgi(Consts c, const float4* __restrict_
 }
 
 
+// ---- QGX: the quad walk on 32-byte interleaved records with PAIRED half gathers: in one gather instruction the two lanes of a
+// lane pair fetch the two 16-byte halves of ONE record (first the even lane's entry, then the odd lane's), so a wave instruction
+// touches the lines of 32 records instead of 64 — every line is visited by one instruction, not by two.  The halves change lanes
+// through a select and a quad-permute (DPP) afterwards.  Results are bit-identical to QGI.
+__device__ __forceinline__ float swap_pair(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+template <int U, bool EXACT>
+__global__ void __launch_bounds__(256) k_qgx(Consts c, const float4* __restrict__ pv, const unsigned int* __restrict__ rows,
+                                             const int* __restrict__ tileSteps, float* __restrict__ out, int n, int numTilesQ, int capSteps)
+{
+    constexpr int G = 4, PPW = 16;
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTilesQ) return;
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const int ip = tile * PPW + lane / G;
+    const int i = min(ip, n - 1);
+    const float4 self = pv[2 * i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const float4 sv = pv[2 * i + 1];
+    const float3 vi = v3(sv.x, sv.y, sv.z);
+    const unsigned int* row = rows + ((size_t)tile * capSteps) * 64u + (unsigned)lane;
+    const int steps = tileSteps[tile];
+    float e = 0.0f;
+    for (int s = 0; s < steps; s += U) {
+        unsigned int idx[U];
+        float4 a[U], b[U];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = (s + u < steps) ? row[(size_t)(s + u) * 64u] : (unsigned)n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned own = idx[u] << 5;
+            const unsigned partner = ((unsigned)__builtin_amdgcn_mov_dpp((int)idx[u], 0xB1, 0xf, 0xf, true) << 5) + 16u;
+            a[u] = gather16(pv, odd ? partner : own);       // the even lane's record: position half | velocity half
+            b[u] = gather16(pv, odd ? own : partner);       // the odd lane's record:  velocity half | position half
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 pj = odd ? b[u] : a[u];
+            const float zx = odd ? a[u].x : b[u].x, zy = odd ? a[u].y : b[u].y, zz = odd ? a[u].z : b[u].z;
+            const float4 vj = make_float4(swap_pair(zx), swap_pair(zy), swap_pair(zz), 0.f);
+            t[u] = pair_term<EXACT>(c, pi, vi, pj, vj);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) e += group_term<G>(t[u], g, lane);
+    }
+    if (ip < n && (lane % G) == 0) out[i] = e;
+}
+
+
 // ---- QG16: the quad walk (G = 4, E = 1, 4 steps in flight) on 16-bit tile-relative row entries: entry = column (4 bits) | offset
 // (12 bits) inside the tile's candidate window of that (dx,dy) column; 9 window bases per 16-particle tile.  Halves the row stream.
 template <bool EXACT, bool TWO>
@@ -1152,6 +1207,15 @@ int main(int argc, char** argv)
                                  else hipLaunchKernelGGL((k_qgi<4, true, false>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
                     else { if (two) hipLaunchKernelGGL((k_qgi<4, false, true>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
                            else hipLaunchKernelGGL((k_qgi<4, false, false>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps); }
+                });
+            }
+            if (two) {   // ... and with paired half gathers (one instruction per record instead of two)
+                const QSet& Q = qsets[1];
+                const unsigned gridQ = xcd_grid(Q.numTiles * 64, 256);
+                snprintf(nm, sizeof(nm), "Q4x1 u4 paired-half %s 2f", exact ? "exact" : "tol");
+                run(nm, exact, two, [&] {
+                    if (exact) hipLaunchKernelGGL((k_qgx<4, true>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
+                    else hipLaunchKernelGGL((k_qgx<4, false>), dim3(gridQ), dim3(256), 0, st, c, dPV, Q.dRows, Q.dSteps, dOut, n, Q.numTiles, Q.capSteps);
                 });
             }
             for (int v = 0; v < ((argc > 5 && argv[3][0] != 'b') ? 2 : 0); ++v) {
