@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--force-slab", action="store_true", help="run the x-slab layer with one process: --slabs loopback slabs on one device")
     ap.add_argument("--slabs", type=int, default=1, help="with --force-slab: number of loopback slabs")
+    ap.add_argument("--slab-transport", default="loopback", choices=["loopback", "rccl"],
+                    help="with --force-slab: device-to-device copies, or the installed RCCL (grouped sends to self on the communication stream)")
     ap.add_argument("--no-overlap", action="store_true", help="slab layer: stage-then-exchange instead of edge-first stages")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=8)

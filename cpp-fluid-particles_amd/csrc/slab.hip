@@ -111,8 +111,12 @@ struct LoopbackTransport final : Transport {
     long long allreduce_sum(long long v) override { return v; }
 };
 
-// one process per GPU: grouped ncclSend / ncclRecv on a communication stream of its own
+// one process per GPU: grouped ncclSend / ncclRecv on a communication stream of its own.  A process may drive several
+// CONSECUTIVE slabs (slabsPerProcess, the same number everywhere): slab r lives in process r / slabsPerProcess, and a
+// message between two slabs of one process is an RCCL send to self.  RCCL matches the sends and receives of a pair of
+// processes in the order they were posted, so both sides post theirs sorted by (from, to).
 struct RcclTransport final : Transport {
+    int slabsPerProcess = 1;
     ncclComm_t comm = nullptr;
     hipStream_t commStream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
@@ -120,7 +124,7 @@ struct RcclTransport final : Transport {
     long long* dScalar = nullptr;       // 2 x int64 on the device for the all-reduce
     long long* hScalar = nullptr;       // pinned
 
-    RcclTransport(int rank, int world, const char* id128)
+    RcclTransport(int rank, int world, const char* id128, int slabsPerProcess_) : slabsPerProcess(slabsPerProcess_)
     {
         std::string why;
         if (!g_rccl.load(why)) die(why);
@@ -156,9 +160,14 @@ struct RcclTransport final : Transport {
         if (pending) wait();
         hip_ok(hipEventRecord(ready, sphx::stream()), "event record");
         hip_ok(hipStreamWaitEvent(commStream, ready, 0), "stream wait");
+        if (slabsPerProcess > 1) {
+            auto byPair = [](const Msg& a, const Msg& b) { return a.from != b.from ? a.from < b.from : a.to < b.to; };
+            std::stable_sort(sends.begin(), sends.end(), byPair);
+            std::stable_sort(recvs.begin(), recvs.end(), byPair);
+        }
         nccl_ok(g_rccl.GroupStart(), "ncclGroupStart");
-        for (const Msg& m : sends) if (m.bytes) nccl_ok(g_rccl.Send(m.buf, m.bytes, ncclInt8, m.to, comm, commStream), "ncclSend");
-        for (const Msg& m : recvs) if (m.bytes) nccl_ok(g_rccl.Recv(m.buf, m.bytes, ncclInt8, m.from, comm, commStream), "ncclRecv");
+        for (const Msg& m : sends) if (m.bytes) nccl_ok(g_rccl.Send(m.buf, m.bytes, ncclInt8, m.to / slabsPerProcess, comm, commStream), "ncclSend");
+        for (const Msg& m : recvs) if (m.bytes) nccl_ok(g_rccl.Recv(m.buf, m.bytes, ncclInt8, m.from / slabsPerProcess, comm, commStream), "ncclRecv");
         nccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd");
         hip_ok(hipEventRecord(done, commStream), "event record");
         pending = true; pendingAsync = async;
@@ -803,7 +812,8 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: bad argument");
     if (!rccl_id128 && (first_rank != 0 || local_ranks != world))
         return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: without an RCCL token all slabs must be local (loopback)");
-    if (rccl_id128 && local_ranks != 1) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: RCCL drives one slab per process");
+    if (rccl_id128 && (world % local_ranks != 0 || first_rank % local_ranks != 0))
+        return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: with RCCL every process drives the same number of consecutive slabs");
     return slab_guarded("sphx_slab_create", [&] {
         *out = nullptr;
         std::unique_ptr<sphx_slab_group> G(new sphx_slab_group());
@@ -814,7 +824,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         const int gx = P.cells[0], gy = P.cells[1], gz = P.cells[2];
         const int ghost = P.solver == SPHX_PBD ? 2 : 1;
         // transport first: it binds this process to its device-side communicator
-        if (rccl_id128) G->transport.reset(new RcclTransport(first_rank, world, rccl_id128));
+        if (rccl_id128) G->transport.reset(new RcclTransport(first_rank / local_ranks, world / local_ranks, rccl_id128, local_ranks));
         else G->transport.reset(new LoopbackTransport());
 
         const SlabPlan plan = plan_slabs(P, fluid_xyz, n_fluid, world);

@@ -41,8 +41,12 @@ def run_slab_bench(args, rank, world, local_rank):
         slabs_here, transport = 1, "RCCL point-to-point (ncclSend/ncclRecv grouped per exchange) over xGMI"
     else:
         slabs_here = max(1, int(getattr(args, "slabs", 1)))
-        group = sphx.SlabGroup(P, fluid, boundary, slabs_here, flags=flags)
-        transport = "loopback (%d slabs on one device)" % slabs_here
+        if getattr(args, "slab_transport", "loopback") == "rccl":      # the installed RCCL on one device: every message a send to self
+            group = sphx.SlabGroup(P, fluid, boundary, slabs_here, first_rank=0, local_ranks=slabs_here, rccl_id=sphx.rccl_unique_id(), flags=flags)
+            transport = "RCCL sends to self (%d slabs on one device, one-rank communicator)" % slabs_here
+        else:
+            group = sphx.SlabGroup(P, fluid, boundary, slabs_here, flags=flags)
+            transport = "loopback (%d slabs on one device)" % slabs_here
     n_total = len(fluid)
     group.step(1)                                # = the constructor step of the single-device path
     if P.solver == sphx.PBD:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-typedef struct sphx_slab_group sphx_slab_group;   /* the slabs driven by this process: 1 (RCCL) or all (loopback) */
+typedef struct sphx_slab_group sphx_slab_group;   /* the slabs driven by this process: 1 or a few (RCCL), or all (loopback) */
 
 enum {
     SPHX_SLAB_NO_OVERLAP = 1,       /* run every stage on all particles, then exchange (the simple schedule) */
@@ -42,7 +42,10 @@ int sphx_slab_rccl_unique_id(char id128[128]);
 /*
  * Cuts the GLOBAL scene (the same arrays on every rank; fluid velocities optional) into `world` x-slabs balancing
  * the initial particle counts and creates the slabs [first_rank, first_rank + local_ranks).
- *   RCCL:     local_ranks = 1, rccl_id128 = the token, one call per process after sphx_set_device
+ *   RCCL:     rccl_id128 = the token, one call per process after sphx_set_device; normally local_ranks = 1 (one slab
+ *             per GPU).  A process may drive local_ranks > 1 CONSECUTIVE slabs (the same number in every process,
+ *             first_rank a multiple of it): the communicator then has world / local_ranks ranks and slabs of one
+ *             process talk through RCCL sends to self.
  *   loopback: first_rank = 0, local_ranks = world, rccl_id128 = NULL
  * params: the whole-domain scalars (as for sphx_create); DFSPH runs fixed or adaptive iterations as params say.
  */

@@ -226,7 +226,7 @@ int run_group()
 
 int post(bool send, void* buf, size_t count, int type, int peer, Comm* c, hipStream_t stream)
 {
-    if (!c || peer < 0 || peer >= c->world || peer == c->rank) return fail("bad peer");
+    if (!c || peer < 0 || peer >= c->world) return fail("bad peer");     // (peer == own rank: a send to self, as RCCL allows inside a group)
     const size_t width = (type == 0 || type == 1) ? 1 : (type == 2 || type == 3 || type == 7) ? 4 : 8;
     if (count == 0) return fail("zero-byte message (RCCL would hang on an unmatched empty message)");
     t_ops.push_back(Op{send, (char*)buf, count * width, 0, peer, c, stream, false, nullptr});

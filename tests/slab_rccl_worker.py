@@ -1,6 +1,7 @@
 """One rank of the native slab layer on its RCCL transport (spawned by tests/test_gpu_slab.py, one process per rank).
 argv: rank world nx steps seed solver adaptive(0|1) rebalance(0|1) outdir.  The communicator token travels through a
-file in outdir, as a launcher's side channel would carry it."""
+file in outdir, as a launcher's side channel would carry it.  SPHX_TEST_SLABS_PER_PROCESS = L: every process drives L
+consecutive slabs (world * L slabs in all), messages between slabs of one process are RCCL sends to self."""
 import os
 import sys
 import time
@@ -32,14 +33,15 @@ def main():
                 raise SystemExit("rank %d: no communicator token" % rank)
             time.sleep(0.05)
         token = open(token_file, "rb").read()
-    g = sphx.SlabGroup(P, pos, boundary, world, first_rank=rank, local_ranks=1, rccl_id=token, velocity=vel)
+    per = int(os.environ.get("SPHX_TEST_SLABS_PER_PROCESS", "1"))
+    g = sphx.SlabGroup(P, pos, boundary, world * per, first_rank=rank * per, local_ranks=per, rccl_id=token, velocity=vel)
     if rebalance:
         g.set_rebalance(1, 0.0)
     cuts = set()
     try:
         for _ in range(steps):
             g.step()
-            cuts.add(g.info(0)[:2])
+            cuts.update(g.info(k)[:2] for k in range(per))
     except sphx.SphxError as e:       # (the failure tests expect every rank to arrive here together)
         print("rank %d: %s" % (rank, e), flush=True)
         try:
@@ -48,8 +50,9 @@ def main():
             assert "earlier step" in str(e2), e2
         raise SystemExit(3)
     ids, p, v, d = g.gather_all()
+    loaded = sorted({line.split()[-1] for line in open("/proc/self/maps") if "rccl" in line.lower()})      # which RCCL served the calls
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), ids=ids, pos=p, vel=v, density=d, iters=np.array(g.iters()),
-             distinct_cuts=len(cuts), held=g.info(0)[3])
+             distinct_cuts=len(cuts) - per + 1, held=g.info(0)[3], rccl_library=np.array(";".join(loaded)))
     g.close()
 
 

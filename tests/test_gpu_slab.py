@@ -116,7 +116,10 @@ def _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, li
     """one process per slab on the shared test GPU; returns the per-rank result files"""
     import os, subprocess, sys
     env = dict(os.environ)
-    env["SPHX_RCCL_LIBRARY"] = library
+    if library:
+        env["SPHX_RCCL_LIBRARY"] = library
+    else:
+        env.pop("SPHX_RCCL_LIBRARY", None)        # the installed librccl
     env.update(extra_env or {})
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(slab_worker.ROOT, "tests"), os.path.join(slab_worker.ROOT, "cpp-fluid-particles_amd"),
                                          slab_worker.ROOT, env.get("PYTHONPATH", "")])
@@ -317,6 +320,38 @@ def test_native_slab_layer_rccl_transport_deferred_completion(oracle, tmp_path, 
     assert same, "deferred completion changed the results"
     if solver == "dfsph":
         assert all(tuple(p["iters"]) == rit for p in parts)
+
+
+@pytest.mark.parametrize("procs,per,solver,adaptive,defer", [(2, 2, "dfsph", True, "0"), (2, 3, "pbd", False, "300"), (4, 2, "wcsph", False, "300")])
+def test_native_slab_layer_rccl_transport_several_slabs_per_process(oracle, tmp_path, procs, per, solver, adaptive, defer):
+    """a process may drive several consecutive slabs over the RCCL transport: slab r lives in process r / per, messages between
+    slabs of one process are sends to self, both sides post the messages of a process pair in (from, to) order.  Stand-in
+    library, immediate and deferred completion, cuts moving."""
+    nx, steps, seed = 24, 6, 43
+    parts = _run_ranks(tmp_path, procs, nx, steps, seed, solver, adaptive, True, _mock_library(),
+                       {"SPHX_TEST_SLABS_PER_PROCESS": str(per), "SPHX_MOCK_RCCL_DEFER_US": defer})
+    same, rit = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, adaptive)
+    assert same, "several slabs per process changed the results"
+    if solver == "dfsph":
+        assert all(tuple(p["iters"]) == rit for p in parts)
+
+
+@pytest.mark.parametrize("slabs,solver,adaptive", [(4, "dfsph", True), (3, "pbd", False), (5, "wcsph", False)])
+def test_native_slab_layer_on_the_installed_rccl_sends_to_self(oracle, tmp_path, slabs, solver, adaptive):
+    """the REAL librccl on the one-GPU box: one process, a one-rank communicator, 3-5 slabs -- so every size message,
+    migration payload and halo of the protocol is a real grouped ncclSend / ncclRecv (to self) on the communication stream,
+    completing when RCCL completes it, and the engine streams are ordered against it by the layer's own events: the
+    edge-first overlap schedule, moving cuts and the adaptive all-reduce included.  Bit-identical to the oracle.
+    (What this cannot show is a transfer between two devices; everything on the calling side of RCCL is the shipped code.)"""
+    nx, steps, seed = 24, 6, 47
+    parts = _run_ranks(tmp_path, 1, nx, steps, seed, solver, adaptive, True, None, {"SPHX_TEST_SLABS_PER_PROCESS": str(slabs)})
+    same, rit = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, adaptive)
+    library = str(parts[0]["rccl_library"])
+    assert "librccl" in library and "mock" not in library, "the installed RCCL must have served the calls: " + library
+    assert same, "the run over the installed RCCL differs from the oracle"
+    if solver == "dfsph":
+        assert tuple(parts[0]["iters"]) == rit
+    assert int(parts[0]["distinct_cuts"]) > 1 or solver == "pbd", "the cuts must have moved"
 
 
 @pytest.mark.parametrize("solver", ["dfsph", "wcsph"])

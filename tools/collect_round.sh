@@ -10,6 +10,7 @@ python bench.py > gpurun_out/bench_${TAG}_1gpu.json 2> gpurun_out/bench_${TAG}_1
 python tools/probe_step.py wcsph263k dfsph1m pbd1m dfsph10m 2>/dev/null | grep -v amdgpu > gpurun_out/probe_$TAG.txt
 python tools/pcie_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/pcie_$TAG.txt
 for s in 1 8; do python bench.py --force-slab --slabs $s --steps 20 2>/dev/null > gpurun_out/bench_${TAG}_loopback_${s}slabs.json; done
+python bench.py --force-slab --slabs 8 --slab-transport rccl --steps 20 2>/dev/null > gpurun_out/bench_${TAG}_rcclself_8slabs.json
 python tools/settle_probe.py 190 300 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_fixed14.txt
 python tools/settle_probe.py 190 350 -1 -1 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_190_adaptive.txt
 python tools/settle_probe.py 88 450 1 4 2>/dev/null | grep -v amdgpu > gpurun_out/settle_${TAG}_88_fixed14.txt

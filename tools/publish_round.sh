@@ -9,6 +9,7 @@ CSV=$(grep -o "[0-9]*_kernel_stats.csv" gpurun_out/profile_summary_$T.txt | head
 cp "$(find gpurun_out/prof_$T -name "$CSV" | head -1)" profiles/${T}_rocprofv3_dfsph10m_kernel_stats.csv
 cp gpurun_out/bench_${T}_loopback_1slabs.json profiles/${T}_bench_dfsph10m_loopback_1slab.json
 cp gpurun_out/bench_${T}_loopback_8slabs.json profiles/${T}_bench_dfsph10m_loopback_8slabs_one_gpu.json
+[ -s gpurun_out/bench_${T}_rcclself_8slabs.json ] && cp gpurun_out/bench_${T}_rcclself_8slabs.json profiles/${T}_bench_dfsph10m_rccl_self_8slabs_one_gpu.json
 cp gpurun_out/pcie_$T.txt                     profiles/${T}_pcie_inclusive.txt
 cp gpurun_out/probe_$T.txt                    profiles/${T}_probe_per_kernel_hipevents.txt
 cp gpurun_out/settle_${T}_190_adaptive.txt    profiles/${T}_settle_10m_adaptive.txt
