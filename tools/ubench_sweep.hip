@@ -721,6 +721,55 @@ __global__ void __launch_bounds__(256) k_build_global(const float4* __restrict__
     counts[i] = cnt;
     if ((cnt & 3) != 0 && cnt < cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
 }
+// the same builder reading its candidates from a float3 position array: 4 consecutive candidates = 48 bytes = THREE 16-byte loads
+// (dword-aligned), 12 bytes per candidate instead of 16 on the vector memory path
+struct __attribute__((packed, aligned(4))) U4 { float a, b, c, d; };
+__global__ void __launch_bounds__(256) k_build_global3(const F3* __restrict__ pos3, const int* __restrict__ cs, int gx, int gy, int gz,
+                                                       float cellLength, float cut, unsigned int* __restrict__ rows, int* __restrict__ counts,
+                                                       int n, int numTiles, int cap)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int i = tile * 64 + (int)(threadIdx.x & 63);
+    if (i >= n) return;
+    const F3 self = pos3[i];
+    const float3 pi = v3(self.x, self.y, self.z);
+    const int cx = (int)(pi.x / cellLength), cy = (int)(pi.y / cellLength), cz = (int)(pi.z / cellLength);
+    unsigned int* row = rows + ((size_t)(i >> 6) * cap) * 64u + (size_t)(i & 63) * 4u;
+    const int zlo = max(cz - 1, 0), zhi = min(cz + 1, gz - 1);
+    int cnt = 0; uint4 pend = make_uint4(0, 0, 0, 0);
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int X = cx + dx; if (X < 0 || X >= gx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int Y = cy + dy; if (Y < 0 || Y >= gy) continue;
+            const int base = (X * gy + Y) * gz;
+            const int e = cs[base + zhi + 1];
+            int j = cs[base + zlo];
+            for (; j + 4 <= e; j += 4) {
+                const U4* q = reinterpret_cast<const U4*>(pos3 + j);
+                const U4 a = q[0], b = q[1], c = q[2];
+                const float3 pj[4] = {v3(a.a, a.b, a.c), v3(a.d, b.a, b.b), v3(b.c, b.d, c.a), v3(c.b, c.c, c.d)};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float3 d = sub3(pi, pj[u]);
+                    const float r2 = dot3(d, d);
+                    if (r2 > cut || j + u == i) continue;
+                    ub_put(row, cnt, (unsigned)(j + u), pend, cap); ++cnt;
+                }
+            }
+            for (; j < e; ++j) {
+                const F3 pj = pos3[j];
+                const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                const float r2 = dot3(d, d);
+                if (r2 > cut || j == i) continue;
+                ub_put(row, cnt, (unsigned)j, pend, cap); ++cnt;
+            }
+        }
+    }
+    counts[i] = cnt;
+    if ((cnt & 3) != 0 && cnt < cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+}
+
 template <int T>
 __global__ void __launch_bounds__(T) k_build_brick(const float4* __restrict__ posm, const int* __restrict__ cs, int gx, int gy, int gz,
                                                    float cellLength, float cut, const BrickDesc* __restrict__ bricks,
@@ -1043,6 +1092,26 @@ int main(int argc, char** argv)
         };
         timeit("BUILD global lane-per-particle", [&] {
             hipLaunchKernelGGL(k_build_global, dim3(gridG), dim3(256), 0, st, dPos, dCs, gx, gy, gz, cellLength, tCut, dRowsA, dCntA, n, numTiles, capB); });
+        {
+            std::vector<F3> p3(n + 4);
+            for (int q = 0; q <= n; ++q) p3[q] = F3{posm[q].x, posm[q].y, posm[q].z};
+            F3* dP3; CK(hipMalloc(&dP3, 12 * p3.size())); CK(hipMemcpy(dP3, p3.data(), 12 * p3.size(), hipMemcpyHostToDevice));
+            timeit("BUILD global, float3 candidates (3 x 16 B / 4)", [&] {
+                hipLaunchKernelGGL(k_build_global3, dim3(gridG), dim3(256), 0, st, dP3, dCs, gx, gy, gz, cellLength, tCut, dRowsB2, dCntB, n, numTiles, capB); });
+            std::vector<int> ca(n), cb(n); std::vector<unsigned int> ra(rowWords), rb(rowWords);
+            CK(hipMemcpy(ca.data(), dCntA, 4 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(cb.data(), dCntB, 4 * n, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ra.data(), dRowsA, 4 * rowWords, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), dRowsB2, 4 * rowWords, hipMemcpyDeviceToHost));
+            long long badCnt = 0, badEnt = 0;
+            for (int i = 0; i < n; ++i) {
+                if (ca[i] != cb[i]) { ++badCnt; continue; }
+                for (int k = 0; k < std::min(ca[i], capB); ++k) {
+                    const size_t at = ((size_t)(i >> 6) * capB) * 64u + (size_t)(i & 63) * 4u + (size_t)(k >> 2) * 256u + (k & 3);
+                    if (ra[at] != rb[at]) ++badEnt;
+                }
+            }
+            printf("   float3 rows vs the float4 builder: %lld counts differ, %lld entries differ\n", badCnt, badEnt);
+            CK(hipFree(dP3));
+        }
         struct Shape { int bx, by, bz, T; };
         const Shape shapes[] = {{4, 4, 4, 256}, {4, 4, 4, 512}, {4, 4, 8, 512}, {2, 2, 8, 256}};
         for (const Shape& S : shapes) {
