@@ -125,7 +125,11 @@ def run_case_tolerance(seed):
             return None          # a particle ended on the other side of a cell face: orders differ, nothing to compare index by index
         if float(np.abs(o.get(O.F_VEL)).max()) > 30.0 or float(o.get(O.F_DENSITY).max()) > 2.0 * P.rho0:
             return None          # an exploding state (dense blob): every perturbation is amplified by orders of magnitude per step
-        for nm, scale in (("POS", P.space[0]), ("DENSITY", max(float(np.abs(o.get(O.F_DENSITY)).max()), 1e-6)), ("VEL", max(float(np.abs(o.get(O.F_VEL)).max()), 1e-3))):
+        # PBD's velocity is a position difference over dt: one ulp of a position is already ulp(space)/dt of velocity, so a slow
+        # state cannot be held to 1e-3 of its own speed (seed 42265: the ORACLE moves by 1.1e-3 of the scale when its input positions
+        # move by one ulp, tools/stress_case_probe.py); the net for PBD is 1e-3 of at least 8 position ulps per dt
+        pbd_velocity_floor = (8.0 * float(np.spacing(np.float32(P.space[0]))) / P.dt / 1e-3) if solver == 2 else 0.0
+        for nm, scale in (("POS", P.space[0]), ("DENSITY", max(float(np.abs(o.get(O.F_DENSITY)).max()), 1e-6)), ("VEL", max(float(np.abs(o.get(O.F_VEL)).max()), 1e-3, pbd_velocity_floor))):
             a = g.get(getattr(sphx, "F_" + nm)).astype(np.float64); b = o.get(getattr(O, "F_" + nm)).astype(np.float64)
             if not np.isfinite(b).all():
                 return None
