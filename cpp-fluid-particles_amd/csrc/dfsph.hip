@@ -308,6 +308,10 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
             ScopedKernel t("add_delta_v");
             const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, num) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, num) : num;
             launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
+            if (c.rangeLo >= 0 && c.rangeLo2 >= 0) {       // the second range of a two-range stage
+                const int lo2 = std::min(std::max(c.rangeLo2, hi), num), hi2 = std::min(std::max(c.rangeHi2, lo2), num);
+                launch_add3(fluids->getVelPtr() + lo2, c.vel4w() + lo2, c.aux3.addr() + lo2, hi2 - lo2);
+            }
         }
         break;
     }

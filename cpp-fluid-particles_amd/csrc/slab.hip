@@ -523,8 +523,7 @@ struct sphx_slab_group {
         for (auto& sp : slabs) {
             Slab& s = *sp;
             const int* l = s.layer;
-            s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, false);
-            s.sys->system->phaseEx(phase, l[2], l[3], reduce, s.o0, s.o1, true);
+            s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, false, l[2], l[3]);       // both edge layers in one launch
         }
         postHalo(halo, true);
         for (auto& sp : slabs) {

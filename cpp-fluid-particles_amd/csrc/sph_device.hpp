@@ -474,6 +474,8 @@ struct SweepCtx {
     int numTiles;                           // tiles this launch covers
     int tile0;                              // first tile of a range-restricted launch (0 otherwise; no schedule then)
     int lo, hi;                             // particles [lo, hi) are processed; lanes outside only take part in wave-wide staging
+    int lo2, hi2;                           // ... and [lo2, hi2), a second range behind the first (empty unless a two-range launch)
+    int tileSplit, tile1;                   // launch tiles >= tileSplit belong to the second range: tile = lt + tile1
     int n;
     int* overflowMax;                       // row builder only: longest row that did not fit `cap` (atomicMax; nullptr otherwise)
     int brick;                              // 1: rows hold 16-bit slots of the compact-brick LDS stage (tolerance arithmetic, see "brick" below)
@@ -487,13 +489,21 @@ struct SweepCtx {
 // do not depend on it — so tiles are ordered by (y-chunk, x) rather than the array's x-major order:
 // each XCD then walks along x inside one y-chunk and the x+-1 neighbour layers of that chunk stay
 // in its 4 MB L2 (at 10 M particles a full x-layer is ~3 MB per array and would not).
+// a scheduled launch restricted to a particle range visits every tile of the schedule: tiles wholly outside the range leave at once
+__device__ __forceinline__ bool tile_outside(const SweepCtx& c, int tile)
+{
+    const int a = tile * kTile, b = a + kTile;
+    return (b <= c.lo || a >= c.hi) && (b <= c.lo2 || a >= c.hi2);
+}
 __device__ __forceinline__ int wave_tile(const SweepCtx& c)
 {
     const int lt = logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6);
     if (lt >= c.numTiles) return -1;
-    return c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
+    if (!c.tileOrder) return lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
+    const int tile = c.tileOrder[lt];
+    return tile_outside(c, tile) ? -1 : tile;
 }
-__device__ __forceinline__ bool in_range(const SweepCtx& c, int i) { return i >= c.lo && i < c.hi; }
+__device__ __forceinline__ bool in_range(const SweepCtx& c, int i) { return (i >= c.lo && i < c.hi) || (i >= c.lo2 && i < c.hi2); }
 
 // The 18 neighbour ranges of a tile, one per lane (lanes 0..8 fluid, 9..17 boundary; r = 3*(dx+1) +
 // (dy+1)), with each range's offset inside the LDS stage of its dx group (fluid dy=-1,0,1 first,
@@ -920,7 +930,8 @@ __device__ __forceinline__ int quad_particle(const SweepCtx& c)
 {
     const int lt = logical_block();
     if (lt >= c.numTiles) return -1;
-    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
+    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
+    if (c.tileOrder && tile_outside(c, tile)) return -1;
     return tile * kTile + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
 }
 
@@ -1059,7 +1070,8 @@ __device__ __forceinline__ int duo_particle(const SweepCtx& c)
 {
     const int lt = logical_block() * 2 + (int)(threadIdx.x >> 7);
     if (lt >= c.numTiles) return -1;
-    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + c.tile0;
+    const int tile = c.tileOrder ? c.tileOrder[lt] : lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
+    if (c.tileOrder && tile_outside(c, tile)) return -1;
     return tile * kTile + (int)((threadIdx.x >> 6) & 1) * 32 + (int)((threadIdx.x & 63) >> 1);
 }
 

@@ -337,11 +337,13 @@ void device_exclusive_scan(int* data, int count, int* blockSums)
 
 // a stage restricted to particles [lo, hi) (lo < 0: all), optionally accumulating the |error| total of
 // particles [sumLo, sumHi) (DFSPH error stages); keepAccum: add to the running total (a later part of a split stage)
-void SPHSystem::phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum)
+void SPHSystem::phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum, int lo2, int hi2)
 {
     auto* basic = dynamic_cast<BasicSPHSolver*>(_solver.get());
     if (!basic) throw "SPHSystem::phaseEx: needs an engine solver";
-    basic->setSweepRange(lo, hi, keepAccum);
+    if (lo2 >= 0 && (lo < 0 || lo2 < hi || dynamic_cast<PBDSolver*>(_solver.get())))
+        throw "SPHSystem::phaseEx: a second range must lie behind the first (WCSPH / DFSPH sweep stages only)";
+    basic->setSweepRange(lo, hi, keepAccum, lo2, hi2);
     try {
         if (reduce) phaseReduce(p, sumLo, sumHi);
         else phase(p);

@@ -39,7 +39,11 @@ int BasicSPHSolver::engineRowCapacity() const { return _cache->cap; }
 const int* BasicSPHSolver::engineStaleFlag() const { return (_cache->skinRows && _cache->skin > 0.0f) ? _cache->staleFlag.addr(2) : nullptr; }
 void BasicSPHSolver::reserveBoundary(int count) { _cache->reserveBoundary(count); }
 void BasicSPHSolver::invalidateBoundary() { _cache->boundaryValid = false; _cache->listValid = false; ++_cache->generation; }
-void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum) { _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum; }
+void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum, int lo2, int hi2)
+{
+    _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum;
+    _cache->rangeLo2 = lo >= 0 ? lo2 : -1; _cache->rangeHi2 = lo >= 0 ? hi2 : -1;
+}
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX)
 {
     _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true;
@@ -216,6 +220,10 @@ void BasicSPHSolver::runWcsphPhase(int phase, std::shared_ptr<SPHParticles>& flu
             ScopedKernel t("add_delta_v");
             const int lo = c.rangeLo >= 0 ? std::min(c.rangeLo, n) : 0, hi = c.rangeLo >= 0 ? std::min(c.rangeHi, n) : n;
             launch_add3(fluids->getVelPtr() + lo, c.vel4w() + lo, c.aux3.addr() + lo, hi - lo);
+            if (c.rangeLo >= 0 && c.rangeLo2 >= 0) {       // the second range of a two-range stage
+                const int lo2 = std::min(std::max(c.rangeLo2, hi), n), hi2 = std::min(std::max(c.rangeHi2, lo2), n);
+                launch_add3(fluids->getVelPtr() + lo2, c.vel4w() + lo2, c.aux3.addr() + lo2, hi2 - lo2);
+            }
         }
         return;
     }

@@ -64,7 +64,7 @@ public:
                        float surfaceTensionIntensity, float airPressure);
     // restrict the sweeps of the following stages to particles [lo, hi) (lo < 0: all).  Slab drivers run a
     // stage on the edge particles first, start the halo exchange, then run it on the interior.
-    void setSweepRange(int lo, int hi, bool keepErrorAccum = false);
+    void setSweepRange(int lo, int hi, bool keepErrorAccum = false, int lo2 = -1, int hi2 = -1);
     // call after writing boundary positions/masses through raw pointers
     void invalidateBoundary();
 

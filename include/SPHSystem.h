@@ -70,7 +70,7 @@ public:
     long long errorTotalFixed();
     // a stage on particles [lo, hi) only (lo < 0: all): slab drivers sweep the edge layers first, start the halo
     // exchange of the stage's output, then sweep the interior
-    void phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum);
+    void phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum, int lo2 = -1, int hi2 = -1);
     const DArray<int>& getCellStartFluid() const { return _fluidCellStart; }
     const DArray<int>& getCellStartBoundary() const { return _wallCellStart; }
     BaseSolver* getSolver() const { return _solver.get(); }
