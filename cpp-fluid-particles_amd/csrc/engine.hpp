@@ -192,6 +192,7 @@ void ew_fill_float(float* dst, float value, int n);
 void ew_iota(int* dst, int n);
 
 void device_exclusive_scan(int* data, int count, int* blockSums);
+void device_exclusive_scan3(int* a, int* b, int* c, int count, int* blockSums);   // blockSums: 3 x (count / 2048 + 2) ints
 void use_external_stream(hipStream_t s);
 const std::string& last_error_text();
 void set_error_text(const std::string& s);

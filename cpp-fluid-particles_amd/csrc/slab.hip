@@ -203,18 +203,29 @@ struct RcclTransport final : Transport {
 // expression (true fp32 division, truncation: cell_of), which neighbour needs a copy, and a sanity flag
 __global__ void k_slab_classify(const float3* __restrict__ pos, int m, float cellLength, int x0, int x1, int g, int hasLeft,
                                 int hasRight, int slackL, int slackR, int* __restrict__ flagL, int* __restrict__ flagR,
-                                int* __restrict__ flagK, int* __restrict__ violation)
+                                int* __restrict__ flagK, int* __restrict__ scanL, int* __restrict__ scanR, int* __restrict__ scanK,
+                                int* __restrict__ violation)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int col = (int)(pos[k].x / cellLength);
-    flagL[k] = (hasLeft && col <= x0 + g - 1) ? 1 : 0;
-    flagR[k] = (hasRight && col >= x1 - g) ? 1 : 0;
+    const int fl = (hasLeft && col <= x0 + g - 1) ? 1 : 0;
+    const int fr = (hasRight && col >= x1 - g) ? 1 : 0;
     // still inside this slab's ghost range?  (after a cut moved, a former owner may hold particles two columns out:
     // they travel to the neighbour like every migrant and are dropped here)
-    flagK[k] = (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0;
+    const int fk = (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0;
+    flagL[k] = fl; flagR[k] = fr; flagK[k] = fk;
+    scanL[k] = fl; scanR[k] = fr; scanK[k] = fk;            // scanned in place next (device_exclusive_scan3)
     // moved more than one column in one step (a cut that itself moved this step widens the allowance by its shift)
     if (col < x0 - 1 - slackL || col > x1 + slackR) *violation = 1;
+}
+
+// the size words of a step before the classification fills in the rest: everything zero, {0, owned, width} for both neighbours
+__global__ void k_slab_prepare(long long* __restrict__ counts, int* __restrict__ violation, long long owned, long long width)
+{
+    const int t = threadIdx.x;
+    if (t < 13) counts[t] = (t == 1 || t == 4) ? owned : ((t == 2 || t == 5) ? width : 0);
+    if (t == 13) *violation = 0;
 }
 
 // payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives the owned particles still in
@@ -293,7 +304,7 @@ struct Slab {
     //   [0..2] to left  [3..5] to right  [6..8] from left  [9..11] from right   [12] owned particles kept here
     DevBuf<long long> counts;
     long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 12 size words; 6 layer offsets + violation
-    long long* hSend = nullptr;                            // pinned: the host-known size words
+    hipEvent_t layersReady = nullptr;                      // the layer offsets of this step have arrived in hInts
     long long sentOwned = 0; int sentWidth = 0;            // what this slab reported with its last size message
 
     ~Slab()
@@ -301,7 +312,7 @@ struct Slab {
         if (sys) sphx_destroy(sys);
         if (hCounts) (void)hipHostFree(hCounts);
         if (hInts) (void)hipHostFree(hInts);
-        if (hSend) (void)hipHostFree(hSend);
+        if (layersReady) (void)hipEventDestroy(layersReady);
     }
     int width() const { return 7 + extraFloats; }
     void* field(int f, size_t* bytesPerParticle) const
@@ -381,20 +392,12 @@ struct sphx_slab_group {
             const int m = s.o1 - s.o0;
             // size words that do not come from the device: owned count and width, for both neighbours
             s.sentOwned = m; s.sentWidth = s.x1 - s.x0;
-            s.hSend[0] = 0; s.hSend[1] = m; s.hSend[2] = s.x1 - s.x0;
-            hip_ok(hipMemsetAsync(s.counts.p, 0, 13 * sizeof(long long), st), "memset");
-            hip_ok(hipMemcpyAsync(s.counts.p + 0, s.hSend, 3 * sizeof(long long), hipMemcpyHostToDevice, st), "size words");
-            hip_ok(hipMemcpyAsync(s.counts.p + 3, s.hSend, 3 * sizeof(long long), hipMemcpyHostToDevice, st), "size words");
-            hip_ok(hipMemsetAsync(s.violation.p, 0, sizeof(int), st), "memset");
+            k_slab_prepare<<<1, 64, 0, st>>>(s.counts.p, s.violation.p, (long long)m, (long long)(s.x1 - s.x0));
             if (m > 0) {
                 k_slab_classify<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, m, s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0,
-                                                                s.hasRight ? 1 : 0, slackL, slackR, s.flagL.p, s.flagR.p, s.flagK.p, s.violation.p);
-                hip_ok(hipMemcpyAsync(s.scanL.p, s.flagL.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
-                hip_ok(hipMemcpyAsync(s.scanR.p, s.flagR.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
-                hip_ok(hipMemcpyAsync(s.scanK.p, s.flagK.p, sizeof(int) * m, hipMemcpyDeviceToDevice, st), "copy");
-                device_exclusive_scan(s.scanL.p, m, s.blockSums.p);
-                device_exclusive_scan(s.scanR.p, m, s.blockSums.p);
-                device_exclusive_scan(s.scanK.p, m, s.blockSums.p);
+                                                                s.hasRight ? 1 : 0, slackL, slackR, s.flagL.p, s.flagR.p, s.flagK.p,
+                                                                s.scanL.p, s.scanR.p, s.scanK.p, s.violation.p);
+                device_exclusive_scan3(s.scanL.p, s.scanR.p, s.scanK.p, m, s.blockSums.p);      // three stable compactions, three launches
                 k_slab_pack<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, s.vel + s.o0, s.ids + s.o0,
                                                             s.extraFloats ? s.extra + (size_t)s.o0 * s.extraFloats : nullptr, s.extraFloats, m,
                                                             s.flagL.p, s.flagR.p, s.flagK.p, s.scanL.p, s.scanR.p, s.scanK.p, s.own.p, s.sendL.p, s.sendR.p,
@@ -454,18 +457,23 @@ struct sphx_slab_group {
         }
     }
 
-    // after the local sort: where the ghost and edge layers are (cell starts at six column boundaries of the global grid)
-    void updateLayers()
+    // after the local sort: where the ghost and edge layers are (cell starts at six column boundaries of the global grid).
+    // The read-back is enqueued by the engine's after-sort hook, i.e. BEFORE the packing and the row build of the SEARCH stage:
+    // the host waits for that copy only and issues the first sweep stage while the rows are still being built.
+    static void readLayers(Slab& s)
     {
         hipStream_t st = sphx::stream();
-        for (auto& sp : slabs) {
-            Slab& s = *sp;
-            const int L = s.cellsPerColumn, w = s.ghost;
-            auto at = [&](int column) { return std::min(std::max(column, 0), s.gx) * L; };
-            k_slab_pick6<<<1, 64, 0, st>>>(s.cellStart, at(s.x0 - w), at(s.x0), at(s.x0 + w), at(s.x1 - w), at(s.x1), at(s.x1 + w), s.layerOut.p);
-            hip_ok(hipMemcpyAsync(s.hInts, s.layerOut.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st), "layers");
-        }
-        sync("layer offsets");
+        const int L = s.cellsPerColumn, w = s.ghost;
+        auto at = [&](int column) { return std::min(std::max(column, 0), s.gx) * L; };
+        k_slab_pick6<<<1, 64, 0, st>>>(s.cellStart, at(s.x0 - w), at(s.x0), at(s.x0 + w), at(s.x1 - w), at(s.x1), at(s.x1 + w), s.layerOut.p);
+        hip_ok(hipMemcpyAsync(s.hInts, s.layerOut.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st), "layers");
+        hip_ok(hipEventRecord(s.layersReady, st), "event record");
+    }
+    void updateLayers()
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (auto& sp : slabs) hip_ok(hipEventSynchronize(sp->layersReady), "layer offsets");
+        waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (auto& sp : slabs) {
             Slab& s = *sp;
             if (s.hInts[0] != 0 || s.hInts[5] != s.held) die("slab: a held particle lies outside the slab's ghost range");
@@ -856,12 +864,13 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             if (P.solver == SPHX_PBD) s.extra = reinterpret_cast<float*>(s.sys->pbd->getPosLast().addr());
             // scratch
             const size_t cap = (size_t)s.capacity, W = (size_t)s.width();
-            s.flagL.alloc(cap); s.flagR.alloc(cap); s.flagK.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.scanK.alloc(cap); s.blockSums.alloc(cap / 2048 + 2);
+            s.flagL.alloc(cap); s.flagR.alloc(cap); s.flagK.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.scanK.alloc(cap); s.blockSums.alloc(3 * (cap / 2048 + 2));
             s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(13);
             s.own.alloc(cap * W); s.sendL.alloc(cap * W); s.sendR.alloc(cap * W); s.recvL.alloc(cap * W); s.recvR.alloc(cap * W);
             hip_ok(hipHostMalloc((void**)&s.hCounts, 13 * sizeof(long long), hipHostMallocDefault), "pinned counts");
-            hip_ok(hipHostMalloc((void**)&s.hSend, 3 * sizeof(long long), hipHostMallocDefault), "pinned size words");
             hip_ok(hipHostMalloc((void**)&s.hInts, 8 * sizeof(int), hipHostMallocDefault), "pinned ints");
+            hip_ok(hipEventCreateWithFlags(&s.layersReady, hipEventDisableTiming), "event");
+            { Slab* self = S.get(); s.sys->system->setAfterSortHook([self] { sphx_slab_group::readLayers(*self); }); }
             // initial distribution: this slab's particles in generation order, ids = global generation index
             std::vector<float> p0, v0; std::vector<int> id0;
             for (int i = 0; i < n_fluid; ++i) {

@@ -185,6 +185,46 @@ __global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict
     if (i < n) data[i] += blockSums[i / kScanTile];
 }
 
+// three independent scans of equal length in the same three launches (blockIdx.y = channel; the slab layer's three stable compactions)
+struct Scan3 { int* data[3]; };
+__global__ void __launch_bounds__(256) k_scan3_tiles(Scan3 s, int* __restrict__ blockSums, int n, int sumsStride)
+{
+    int* __restrict__ data = s.data[blockIdx.y];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) { v[t] = (base + t < n) ? data[base + t] : 0; sum += v[t]; }
+    int total;
+    int run = block_exclusive_scan_256(sum, &total);
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) { if (base + t < n) data[base + t] = run; run += v[t]; }
+    if (threadIdx.x == 0) blockSums[blockIdx.y * sumsStride + blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) k_scan3_block_sums(int* __restrict__ blockSums, int m, int sumsStride)
+{
+    int* __restrict__ sums = blockSums + blockIdx.x * sumsStride;
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += 256) {
+        const int idx = base + threadIdx.x;
+        const int v = idx < m ? sums[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, &total);
+        const int c = carry;
+        if (idx < m) sums[idx] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+__global__ void k_scan3_add_offsets(Scan3 s, const int* __restrict__ blockSums, int n, int sumsStride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s.data[blockIdx.y][i] += blockSums[blockIdx.y * sumsStride + i / kScanTile];
+}
+
 // bucket placement in arrival order, then the stable fix-up: inside a cell the reference order is
 // ascending original index (stable sort), so the rank of particle i is the number of bucket
 // mates with a smaller index.  Cells hold a handful of particles, so the count is a short loop.
@@ -333,6 +373,19 @@ void device_exclusive_scan(int* data, int count, int* blockSums)
         k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(data, blockSums, count);
     }
 }
+// the same for three arrays of `count` ints at once; blockSums: 3 x (count / 2048 + 2) ints
+void device_exclusive_scan3(int* a, int* b, int* c, int count, int* blockSums)
+{
+    if (count <= 0) return;
+    hipStream_t st = sphx::stream();
+    const int tiles = (count - 1) / kScanTile + 1, stride = tiles + 1;
+    const Scan3 s{{a, b, c}};
+    k_scan3_tiles<<<dim3(tiles, 3), 256, 0, st>>>(s, blockSums, count, stride);
+    if (tiles > 1) {
+        k_scan3_block_sums<<<3, 256, 0, st>>>(blockSums, tiles, stride);
+        k_scan3_add_offsets<<<dim3(blocks_for(count), 3), 256, 0, st>>>(s, blockSums, count, stride);
+    }
+}
 }  // namespace sphx
 
 // a stage restricted to particles [lo, hi) (lo < 0: all), optionally accumulating the |error| total of
@@ -385,7 +438,7 @@ void SPHSystem::phase(int p)
     if ((p >= SPHX_PH_P_SEARCH && p <= SPHX_PH_P_TAIL) || p == SPHX_PH_P_DELTA_SWEEP || p == SPHX_PH_P_APPLY) {
         auto* pbd = dynamic_cast<PBDSolver*>(_solver.get());
         if (!pbd) throw "SPHSystem::phase: PBD stages need a PBDSolver";
-        if (p == SPHX_PH_P_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+        if (p == SPHX_PH_P_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
         pbd->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                       _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.gravity, _sc.surfaceTension, _sc.airPressure);
         if (p == SPHX_PH_P_TAIL) _graph->stepsRun++;
@@ -394,7 +447,7 @@ void SPHSystem::phase(int p)
     if ((p >= SPHX_PH_W_SEARCH && p <= SPHX_PH_W_PRESSURE) || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
-        if (p == SPHX_PH_W_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+        if (p == SPHX_PH_W_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
         w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                          _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
                          _sc.surfaceTension, _sc.airPressure);
@@ -403,7 +456,7 @@ void SPHSystem::phase(int p)
     }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
     if (!dfsph) throw "SPHSystem::phase: stage-wise stepping needs a DFSPHSolver";
-    if (p == SPHX_PH_SEARCH) neighborSearch(_fluids, _fluidCellStart);
+    if (p == SPHX_PH_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
     dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                     _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
                     _sc.airPressure, false);

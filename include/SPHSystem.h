@@ -9,6 +9,7 @@
 // permutation exactly (DESIGN.md "Neighbour grid").
 #pragma once
 
+#include <functional>
 #include <memory>
 #include "BaseSolver.h"
 
@@ -71,6 +72,9 @@ public:
     // a stage on particles [lo, hi) only (lo < 0: all): slab drivers sweep the edge layers first, start the halo
     // exchange of the stage's output, then sweep the interior
     void phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum, int lo2 = -1, int hi2 = -1);
+    // called inside a SEARCH stage right after the sort, before packing and row construction are enqueued: a slab driver reads
+    // its layer boundaries from the fresh cell table there, so that the read-back overlaps the row build
+    void setAfterSortHook(std::function<void()> hook) { _afterSort = std::move(hook); }
     const DArray<int>& getCellStartFluid() const { return _fluidCellStart; }
     const DArray<int>& getCellStartBoundary() const { return _wallCellStart; }
     BaseSolver* getSolver() const { return _solver.get(); }
@@ -97,6 +101,7 @@ private:
     DArray<int> _intScratch;
     std::unique_ptr<sphx::GridScratch> _grid;
     std::unique_ptr<sphx::StepGraph> _graph;
+    std::function<void()> _afterSort;
     int _cellOffsetX = 0;     // slab decompositions: global x index of local cell column 0
     bool _slab = false;
 };
