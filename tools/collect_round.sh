@@ -6,6 +6,9 @@ TAG=${1:-r03}
 R=$PWD
 mkdir -p gpurun_out
 bash tools/profile_gpu.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
+# the counters just collected become profiles/traffic.json of THIS copy, so that the bench line below carries them (hash-checked)
+# and comes from the same box as the rocprofv3 summary; publish_round.sh regenerates the same file in the repository
+python tools/make_traffic_json.py $TAG dfsph_nx190 > /dev/null 2>&1
 python bench.py > gpurun_out/bench_${TAG}_1gpu.json 2> gpurun_out/bench_${TAG}_1gpu.err
 python tools/probe_step.py wcsph263k dfsph1m pbd1m dfsph10m 2>/dev/null | grep -v amdgpu > gpurun_out/probe_$TAG.txt
 python tools/pcie_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/pcie_$TAG.txt

@@ -18,4 +18,5 @@ cp gpurun_out/settle_${T}_88_fixed14.txt      profiles/${T}_settle_1m_fixed_1_4.
 cp gpurun_out/big_$T.txt                      profiles/${T}_big_scenes.txt
 cp gpurun_out/pytest_gpu_tail_$T.txt          profiles/${T}_pytest_gpu_tail.txt
 python tools/make_traffic_json.py $T dfsph_nx190 > /dev/null
-echo "published $T; now re-run bench.py on the GPU so that profiles/${T}_bench_dfsph10m_1gpu.json carries the hash-checked traffic"
+cp gpurun_out/bench_${T}_1gpu.json profiles/${T}_bench_dfsph10m_1gpu.json      # same box and call as the rocprofv3 summary above
+echo "published $T"
