@@ -108,6 +108,7 @@ struct SweepCache {
     // traffic overlaps the interior): particles [rangeLo, rangeHi) of the next launches; -1 = all
     int rangeLo = -1, rangeHi = -1;
     bool rangeOrder = true;                 // SPHX_RANGE_ORDER=0: ranged launches always walk their tiles linearly (experiments)
+    int rangeOrderMin = 3000000;            // particles a range must hold to keep the tile schedule (SPHX_RANGE_ORDER_MIN; tests lower it)
     int rangeLo2 = -1, rangeHi2 = -1;       // a second range behind the first, swept by the SAME launches (the two edge layers of a slab)
     bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
     // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps

@@ -454,6 +454,7 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
     if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
     if (const char* e = getenv("SPHX_RANGE_ORDER")) rangeOrder = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_RANGE_ORDER_MIN")) rangeOrderMin = atoi(e);
     if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
     if (const char* e = getenv("SPHX_DUO_MASK")) { duoMask = atoi(e); duoMaskLarge = 0; }   // ... and which with two lanes per particle
     if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
@@ -562,7 +563,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
         // a big range that covers most of the tiles (the interior of a wide slab) keeps the schedule: the launch visits every tile
         // and the tiles outside leave at once (tile_outside).  Measured at 10.3 M particles: -1.2 % per step with 1 or 2 slabs,
         // +1.2 % with 8 (1.3 M particles per slab: its x-layers fit the L2 anyway), so smaller ranges walk their tiles linearly.
-        const bool scheduled = c.tileOrder && rangeLo2 < 0 && rangeOrder && 2LL * (c.hi - c.lo) >= n && c.hi - c.lo >= 3000000;
+        const bool scheduled = c.tileOrder && rangeLo2 < 0 && rangeOrder && 2LL * (c.hi - c.lo) >= n && c.hi - c.lo >= rangeOrderMin;
         if (!scheduled) {
             c.tile0 = c.lo / kTile;
             c.numTiles = c.hi > c.lo ? (c.hi - 1) / kTile - c.tile0 + 1 : 0;

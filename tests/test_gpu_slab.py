@@ -34,9 +34,11 @@ def test_hip_slab_driver_matches_single_domain_oracle(oracle, tmp_path, world, s
 
 
 # ------------------------------------------------------------------------------------ the native layer (csrc/slab.hip)
-def _native(sphx, world, solver, adaptive, nx, steps, seed, flags):
+def _native(sphx, world, solver, adaptive, nx, steps, seed, flags, tweak=None):
     P, fluid, boundary = sphx.scene(nx)
     slab_worker.configure(P, sphx, solver, adaptive)
+    if tweak:
+        tweak(P)
     pos, vel = slab_worker.splash(len(fluid), P, seed)
     g = sphx.SlabGroup(P, pos, boundary, world, flags=flags, velocity=vel)       # loopback: every slab on this device
     moved = 0
@@ -74,6 +76,49 @@ def test_native_slab_layer_matches_single_domain_oracle(sphx, oracle, world, sol
         assert iters == it
     if world > 1:
         assert moved > 0, "the test must exercise migration across cuts"
+
+
+@pytest.mark.parametrize("world,solver", [(1, "dfsph"), (2, "dfsph"), (2, "wcsph"), (2, "pbd")])
+def test_scheduled_interior_launches_of_wide_slabs(sphx, oracle, monkeypatch, world, solver):
+    """an interior range that is most of a big slab keeps the (y-chunk, x) tile schedule: the launch visits every tile of the
+    schedule and the tiles outside the range leave at once.  Forced on for a small scene (the schedule itself and the 3 M
+    threshold are both meant for 10 M particles): results must not change."""
+    monkeypatch.setenv("SPHX_FORCE_TILE_ORDER", "1")
+    monkeypatch.setenv("SPHX_RANGE_ORDER_MIN", "1")
+    nx, steps, seed = 16, 6, 29
+    ids, pos, vel, den, iters, _ = _native(sphx, world, solver, False, nx, steps, seed, 0)
+    rp, rv, rd, it = _single_domain(oracle, nx, steps, seed, solver, False, want_iters=True)
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32))
+    assert_bit_equal(pos, rp, "scheduled ranges pos"); assert_bit_equal(vel, rv, "scheduled ranges vel")
+    assert_bit_equal(den, rd, "scheduled ranges density")
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "wcsph", "pbd"])
+@pytest.mark.parametrize("flags", [0, 1], ids=["overlap", "no-overlap"])
+def test_native_slab_layer_without_surface_effects(sphx, oracle, solver, flags):
+    """surface tension and air pressure off: the step takes its other stages (a plain add-delta-v and a separate warm-start
+    correction instead of the fused surface sweeps; PBD commits the XSPH velocities in a stage of its own) -- also under
+    the two-range edge launches"""
+    nx, steps, seed, world = 16, 6, 33, 3
+
+    def tweak(P):
+        P.surface_tension = 0.0; P.air_pressure = 0.0
+    ids, pos, vel, den, iters, _ = _native(sphx, world, solver, False, nx, steps, seed, flags, tweak)
+    P, fluid, boundary = oracle.scene(nx)
+    slab_worker.configure(P, oracle, solver, False)
+    tweak(P)
+    p0, v0 = slab_worker.splash(len(fluid), P, seed)
+    s = oracle.System(P, p0, boundary, ctor_step=False)
+    s.set(oracle.F_VEL, v0[s.get(oracle.F_ID)])
+    for k in range(steps):
+        s.step()
+        if solver == "pbd" and k == 0:
+            s.set(oracle.F_POS_LAST, slab_worker.pbd_last_positions(p0, v0, P)[s.get(oracle.F_ID)])
+    order = np.argsort(s.get(oracle.F_ID))
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32))
+    assert_bit_equal(pos, s.get(oracle.F_POS)[order], "no-surface slab pos")
+    assert_bit_equal(vel, s.get(oracle.F_VEL)[order], "no-surface slab vel")
+    assert_bit_equal(den, s.get(oracle.F_DENSITY)[order], "no-surface slab density")
 
 
 def test_native_slab_layer_rejects_bad_geometry(sphx):

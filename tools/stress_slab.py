@@ -19,6 +19,9 @@ def run_case(seed):
     world = int(rng.integers(1, max(2, min(8, gx // (ghost + 1)) + 1)))
     P.solver = solver; P.dt = float(rng.choice([0.0005, 0.001])); P.pbd_iters = int(rng.integers(1, 5))
     adaptive = rng.random() < 0.4
+    no_surface = rng.random() < 0.25
+    if no_surface:
+        P.surface_tension = 0.0; P.air_pressure = 0.0          # the stages without surface effects (separate add-delta-v / warm-start stages)
     if not adaptive:
         P.dfsph_fixed_div, P.dfsph_fixed_den = int(rng.integers(1, 3)), int(rng.integers(1, 4))
     n = len(fluid)
@@ -30,7 +33,7 @@ def run_case(seed):
     vel[:, 0] += np.where(pos[:, 0] < 0.5 * s, 1.0, -1.0).astype(np.float32) * np.float32(rng.choice([0.0, 1.5, 3.0]))
     flags = int(rng.choice([0, 0, sphx.SLAB_NO_OVERLAP]))
     steps = int(rng.integers(3, 9))
-    desc = "seed %d nx %d world %d solver %d adaptive %s flags %d steps %d dt %g" % (seed, nx, world, solver, adaptive, flags, steps, P.dt)
+    desc = "seed %d nx %d world %d solver %d adaptive %s flags %d steps %d dt %g surface %s" % (seed, nx, world, solver, adaptive, flags, steps, P.dt, not no_surface)
     Po = O.Params()
     for name, _ in P._fields_:
         setattr(Po, name, getattr(P, name))
