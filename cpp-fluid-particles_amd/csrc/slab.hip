@@ -133,7 +133,15 @@ struct RcclTransport final : Transport {
         std::memcpy(&id, id128, 128);
         nccl_ok(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
         try {       // a constructor that throws runs no destructor: give back what exists before passing the error on
-            hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+            // the transfers run beside the interior sweep of the same stage, which fills every CU: the communication stream gets
+            // the highest priority so that RCCL's copy kernels are dispatched as soon as wave slots free up instead of behind
+            // the sweep's remaining workgroups (SPHX_COMM_PRIORITY=0: default priority, for measurements)
+            int least = 0, greatest = 0;
+            hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
+            const char* pr = std::getenv("SPHX_COMM_PRIORITY");
+            const bool high = !(pr && std::strcmp(pr, "0") == 0);
+            if (pr && std::strcmp(pr, "default") == 0) hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+            else hip_ok(hipStreamCreateWithPriority(&commStream, hipStreamNonBlocking, high ? greatest : least), "comm stream");
             hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
             hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
             hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
