@@ -38,6 +38,11 @@ long long DFSPHSolver::readErrorTotalFixed()
     return (long long)acc;
 }
 
+void DFSPHSolver::resetErrorTotal()
+{
+    HIP_CALL(hipMemsetAsync(errorAccum.addr(), 0, sizeof(unsigned long long) * kErrorSlots * kErrorSlotStride, sphx::stream()));
+}
+
 float DFSPHSolver::readErrorTotal()
 {
     return (float)((double)readErrorTotalFixed() * (1.0 / 4294967296.0));

@@ -195,6 +195,15 @@ void ew_iota(int* dst, int n);
 void device_exclusive_scan(int* data, int count, int* blockSums);
 void device_exclusive_scan3(int* a, int* b, int* c, int count, int* blockSums);   // blockSums: 3 x (count / 2048 + 2) ints
 void use_external_stream(hipStream_t s);
+// every launch of the enclosed scope goes to `s` instead of the engine stream (single host thread; the slab layer sweeps the edge
+// layers of a stage on a stream of their own beside the interior)
+struct ScopedStream {
+    explicit ScopedStream(hipStream_t s);
+    ~ScopedStream();
+    ScopedStream(const ScopedStream&) = delete;
+    ScopedStream& operator=(const ScopedStream&) = delete;
+    hipStream_t previous;
+};
 const std::string& last_error_text();
 void set_error_text(const std::string& s);
 

@@ -20,8 +20,13 @@ static hipStream_t g_external_stream = nullptr;
 static bool g_use_external = false;
 void use_external_stream(hipStream_t s) { g_external_stream = s; g_use_external = true; }
 
+static hipStream_t g_scoped_stream = nullptr;
+ScopedStream::ScopedStream(hipStream_t s) : previous(g_scoped_stream) { g_scoped_stream = s; }
+ScopedStream::~ScopedStream() { g_scoped_stream = previous; }
+
 hipStream_t stream()
 {
+    if (g_scoped_stream) return g_scoped_stream;
     if (g_use_external) return g_external_stream;
     std::call_once(g_stream_once, [] {
         if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr;

@@ -346,6 +346,25 @@ struct sphx_slab_group {
     double waitSeconds = 0.0;
     std::vector<Msg> sends, recvs;
     bool failed = false;        // a step threw: posted messages were dropped, slabs may be half-updated -> only destroy is allowed
+    hipStream_t edgeStream = nullptr;                     // DFSPH edge layers + their halo, beside the interior (SPHX_SLAB_EDGE_STREAM=0: off)
+    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
+
+    ~sphx_slab_group()
+    {
+        if (edgeStream) { (void)hipStreamSynchronize(edgeStream); (void)hipStreamDestroy(edgeStream); }
+        if (forkEvent) (void)hipEventDestroy(forkEvent);
+        if (joinEvent) (void)hipEventDestroy(joinEvent);
+    }
+    void createEdgeStream()
+    {
+        const char* e = std::getenv("SPHX_SLAB_EDGE_STREAM");
+        if (e && std::strcmp(e, "0") == 0) return;
+        int least = 0, greatest = 0;
+        hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
+        hip_ok(hipStreamCreateWithPriority(&edgeStream, hipStreamNonBlocking, greatest), "edge stream");
+        hip_ok(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "event");
+        hip_ok(hipEventCreateWithFlags(&joinEvent, hipEventDisableTiming), "event");
+    }
 
     bool overlap() const { return (flags & SPHX_SLAB_NO_OVERLAP) == 0; }
 
@@ -534,6 +553,33 @@ struct sphx_slab_group {
                 else s.sys->system->phaseEx(phase, s.o0, s.o1, reduce, s.o0, s.o1, false);
             }
             postHalo(halo, false);
+            return;
+        }
+        if (edgeStream && global.solver == SPHX_DFSPH) {
+            // DFSPH: the edge layers and the interior of a stage are independent (both read the previous stage's output, each writes
+            // its own particles), so the edges -- one small launch -- and the halo they feed run on a stream of their own BESIDE the
+            // interior instead of in front of it.  fork: the edge stream starts where the engine stream stands (halo of the previous
+            // stage arrived, previous interior done); join: the engine stream's next work waits for the edges and, with the loopback
+            // transport, for the halo copies behind them.  An error stage zeroes its accumulators before the fork; both parts add.
+            hipStream_t main = sphx::stream();
+            if (reduce) for (auto& sp : slabs) sp->sys->system->resetErrorTotal();
+            hip_ok(hipEventRecord(forkEvent, main), "event record");
+            hip_ok(hipStreamWaitEvent(edgeStream, forkEvent, 0), "stream wait");
+            {
+                ScopedStream onEdges(edgeStream);
+                for (auto& sp : slabs) {
+                    Slab& s = *sp;
+                    const int* l = s.layer;
+                    s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, true, l[2], l[3]);
+                }
+                postHalo(halo, true);
+                hip_ok(hipEventRecord(joinEvent, edgeStream), "event record");
+            }
+            for (auto& sp : slabs) {
+                Slab& s = *sp;
+                s.sys->system->phaseEx(phase, s.layer[1], s.layer[2], reduce, s.o0, s.o1, true);
+            }
+            hip_ok(hipStreamWaitEvent(main, joinEvent, 0), "stream wait");
             return;
         }
         for (auto& sp : slabs) {
@@ -841,6 +887,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         // transport first: it binds this process to its device-side communicator
         if (rccl_id128) G->transport.reset(new RcclTransport(first_rank / local_ranks, world / local_ranks, rccl_id128, local_ranks));
         else G->transport.reset(new LoopbackTransport());
+        if (P.solver == SPHX_DFSPH && G->overlap()) G->createEdgeStream();
 
         const SlabPlan plan = plan_slabs(P, fluid_xyz, n_fluid, world);
         const std::vector<int>& cuts = plan.cuts;

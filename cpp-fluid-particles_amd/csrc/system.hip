@@ -418,6 +418,13 @@ void SPHSystem::phaseReduce(int p, int sumLo, int sumHi)
                     _sc.airPressure, true);
 }
 
+void SPHSystem::resetErrorTotal()
+{
+    auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
+    if (!dfsph) throw "SPHSystem::resetErrorTotal: needs a DFSPHSolver";
+    dfsph->resetErrorTotal();
+}
+
 long long SPHSystem::errorTotalFixed()
 {
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());

@@ -43,6 +43,7 @@ public:
     // distributed adaptive mode: restrict the |error| total to [lo, hi) and read it as the raw integer
     void setErrorSumRange(int lo, int hi) { sumLo = lo; sumHi = hi; }
     long long readErrorTotalFixed();
+    void resetErrorTotal();          // zero the |error| accumulators on the current stream (split error stages then all ADD)
     void noteIterations(int div, int den) { lastDiv = div; lastDen = den; }
     const DArray<float>& getAlpha() const { return alpha; }
     const DArray<float>& getStiffness() const { return bufferFloat; }

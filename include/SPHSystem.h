@@ -69,6 +69,7 @@ public:
     void phase(int p);
     void phaseReduce(int p, int sumLo, int sumHi);   // error stages with the |error| total over [lo, hi)
     long long errorTotalFixed();
+    void resetErrorTotal();
     // a stage on particles [lo, hi) only (lo < 0: all): slab drivers sweep the edge layers first, start the halo
     // exchange of the stage's output, then sweep the interior
     void phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum, int lo2 = -1, int hi2 = -1);
