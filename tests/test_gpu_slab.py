@@ -121,6 +121,19 @@ def test_native_slab_layer_without_surface_effects(sphx, oracle, solver, flags):
     assert_bit_equal(den, s.get(oracle.F_DENSITY)[order], "no-surface slab density")
 
 
+@pytest.mark.parametrize("world,adaptive", [(3, True), (8, False)])
+def test_dfsph_stage_order_without_the_edge_stream(sphx, oracle, monkeypatch, world, adaptive):
+    """DFSPH slabs sweep the edge layers of a stage on a stream of their own beside the interior (the default, which every other test
+    runs); SPHX_SLAB_EDGE_STREAM=0 keeps the serial order edges -> halo -> interior on the engine stream.  Same results."""
+    monkeypatch.setenv("SPHX_SLAB_EDGE_STREAM", "0")
+    nx, steps, seed = (24 if world == 8 else 12), 6, 19
+    ids, pos, vel, den, iters, _ = _native(sphx, world, "dfsph", adaptive, nx, steps, seed, 0)
+    rp, rv, rd, it = _single_domain(oracle, nx, steps, seed, "dfsph", adaptive, want_iters=True)
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32))
+    assert_bit_equal(pos, rp, "serial edges pos"); assert_bit_equal(vel, rv, "serial edges vel"); assert_bit_equal(den, rd, "serial edges density")
+    assert iters == it
+
+
 def test_native_slab_layer_rejects_bad_geometry(sphx):
     P, fluid, boundary = sphx.scene(8)                 # 9 cell columns: too narrow for 8 slabs
     P.solver = sphx.DFSPH
