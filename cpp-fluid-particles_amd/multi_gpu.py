@@ -103,13 +103,14 @@ def run_slab_bench(args, rank, world, local_rank):
         sphx.kernel_timer(False)
         if span in spans and spans[span][1] > 0:
             tot_ms, launches = spans[span]
-            # a stage is launched on the two edge layers and the interior: one logical launch = 3 spans per slab
-            logical = launches / (3.0 if not flags else 1.0) / slabs_here
+            # a stage is launched on the two edge layers (ONE two-range launch) and on the interior: one logical launch = 2 timed
+            # spans per slab (an empty edge range still opens its span)
+            logical = launches / (1.0 if flags else 2.0)              # logical launches of ALL local slabs; each works on `owned` particles
             avg_ms = tot_ms / logical
             owned = sum(o for _, _, o, _ in infos) / float(slabs_here)
             per_launch = 44.0 * owned                                   # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": "k_rate<DENSITY_MODE> (span '%s'), rank 0's slab, owned particles" % span,
+            result["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s'), rank 0's slab, owned particles" % span,
                                   "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                   "traffic": None, "avg_launch_ms": avg_ms, "launches": logical,
                                   "algorithmic_bytes_per_launch": per_launch}
