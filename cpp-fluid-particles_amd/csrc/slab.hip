@@ -135,13 +135,14 @@ struct RcclTransport final : Transport {
         try {       // a constructor that throws runs no destructor: give back what exists before passing the error on
             // the transfers run beside the interior sweep of the same stage, which fills every CU: the communication stream gets
             // the highest priority so that RCCL's copy kernels are dispatched as soon as wave slots free up instead of behind
-            // the sweep's remaining workgroups (SPHX_COMM_PRIORITY=0: default priority, for measurements)
+            // the sweep's remaining workgroups (SPHX_COMM_PRIORITY=0 or default: a default-priority stream, =low: the least priority; for measurements)
             int least = 0, greatest = 0;
             hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
             const char* pr = std::getenv("SPHX_COMM_PRIORITY");
-            const bool high = !(pr && std::strcmp(pr, "0") == 0);
-            if (pr && std::strcmp(pr, "default") == 0) hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
-            else hip_ok(hipStreamCreateWithPriority(&commStream, hipStreamNonBlocking, high ? greatest : least), "comm stream");
+            const bool plain = pr && (std::strcmp(pr, "0") == 0 || std::strcmp(pr, "default") == 0);   // a flags-created stream: default priority
+            const bool low = pr && std::strcmp(pr, "low") == 0;                                       // the least priority the device has
+            if (plain) hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+            else hip_ok(hipStreamCreateWithPriority(&commStream, hipStreamNonBlocking, low ? least : greatest), "comm stream");
             hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
             hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
             hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
@@ -188,8 +189,12 @@ struct RcclTransport final : Transport {
         // fault injection for the tests ("skipwait"): the engine stream is NOT ordered after an overlapped halo transfer.
         // With a transport that really completes late (tests/mock_rccl.cpp, deferred mode) results must then be wrong;
         // tests/test_gpu_slab.py asserts that, which proves the several-ranks tests can see a missing wait().
+        // Compiled only into the TEST build of the library (-DSPHX_TEST_HOOKS, tests/libsphx_hooks.so); the product has no such hook.
+#ifdef SPHX_TEST_HOOKS
         static const bool skip = [] { const char* f = std::getenv("SPHX_SLAB_FAULT"); return f && std::strcmp(f, "skipwait") == 0; }();
-        if (!(skip && pendingAsync)) hip_ok(hipStreamWaitEvent(sphx::stream(), done, 0), "stream wait");
+        if (skip && pendingAsync) { pending = false; return; }
+#endif
+        hip_ok(hipStreamWaitEvent(sphx::stream(), done, 0), "stream wait");
         pending = false;
     }
     long long allreduce_sum(long long v) override
@@ -452,11 +457,13 @@ struct sphx_slab_group {
             if (s.hInts[6]) bad += 1;
             if (s.hCounts[12] + rl + rr > s.capacity) bad += 1LL << 20;
         }
-        if (const char* f = std::getenv("SPHX_SLAB_FAULT")) {      // fault injection for the tests: "capacity:<rank>:<step>"
+#ifdef SPHX_TEST_HOOKS
+        if (const char* f = std::getenv("SPHX_SLAB_FAULT")) {      // fault injection, test build only: "capacity:<rank>:<step>"
             int r = -1, st = -1;
             if (std::sscanf(f, "capacity:%d:%d", &r, &st) == 2)
                 for (auto& sp : slabs) if (sp->rank == r && sp->stepsDone == st) bad += 1LL << 20;
         }
+#endif
         const long long anyBad = world > (int)slabs.size() ? transport->allreduce_sum(bad) : bad;
         if (anyBad) {
             const char* here = bad ? "this process" : "another rank";

@@ -356,6 +356,14 @@ def _mock_library():
     return library
 
 
+def _hooks_library():
+    """the TEST build of the engine (slab.hip under -DSPHX_TEST_HOOKS): the only library that reads SPHX_SLAB_FAULT"""
+    import os
+    library = os.path.join(slab_worker.ROOT, "tests", "libsphx_hooks.so")
+    assert os.path.exists(library), "tests/libsphx_hooks.so is built by __graft_entry__.build() (make -C tests)"
+    return library
+
+
 def _compare_with_oracle(oracle, parts, nx, steps, seed, solver, adaptive):
     ids = np.concatenate([p["ids"] for p in parts])
     assert np.array_equal(np.sort(ids), np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
@@ -420,7 +428,7 @@ def test_a_missing_transport_wait_is_detected(oracle, tmp_path, solver):
     which is asserted too: that is the blind spot VERDICT r02 named.)"""
     nx, steps, seed = 16, 6, 41
     codes = _run_ranks(tmp_path, 2, nx, steps, seed, solver, False, False, _mock_library(),
-                       {"SPHX_MOCK_RCCL_DEFER_US": "2000", "SPHX_SLAB_FAULT": "skipwait"}, expect_codes=True)
+                       {"SPHX_MOCK_RCCL_DEFER_US": "2000", "SPHX_SLAB_FAULT": "skipwait", "SPHX_LIB": _hooks_library()}, expect_codes=True)
     if codes == [0, 0]:          # the run survived its stale ghosts: then its results must be wrong
         parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
         same, _ = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, False)
@@ -428,7 +436,7 @@ def test_a_missing_transport_wait_is_detected(oracle, tmp_path, solver):
     else:                        # ... or the garbage tripped the layer's own checks ("crossed more than one cell column"): detected as well
         assert all(c in (0, 3) for c in codes), codes
     blind = tmp_path / "immediate"; blind.mkdir()
-    parts = _run_ranks(blind, 2, nx, steps, seed, solver, False, False, _mock_library(), {"SPHX_SLAB_FAULT": "skipwait"})
+    parts = _run_ranks(blind, 2, nx, steps, seed, solver, False, False, _mock_library(), {"SPHX_SLAB_FAULT": "skipwait", "SPHX_LIB": _hooks_library()})
     same, _ = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, False)
     assert same, "the immediate stand-in completes inside ncclGroupEnd: the fault cannot show there"
 
@@ -439,7 +447,7 @@ def test_rank_local_failure_stops_every_rank(tmp_path):
     well inside the time limit, and none of them hangs."""
     import time
     t0 = time.time()
-    codes = _run_ranks(tmp_path, 3, 16, 5, 41, "dfsph", False, False, _mock_library(), {"SPHX_SLAB_FAULT": "capacity:1:2"}, expect_codes=True)
+    codes = _run_ranks(tmp_path, 3, 16, 5, 41, "dfsph", False, False, _mock_library(), {"SPHX_SLAB_FAULT": "capacity:1:2", "SPHX_LIB": _hooks_library()}, expect_codes=True)
     assert time.time() - t0 < 120, "the ranks must not wait for a timeout"
     assert all(c == 3 for c in codes), "every rank reports the failure (exit code 3 = SphxError): %s" % (codes,)
 

@@ -1,0 +1,671 @@
+// ubench_tiles.hip — round-4 micro-benchmark: gather-free "cell-cluster tile" structures against the engine's quad walk.
+//
+// VERDICT r03 #1 asked for the structure molecular-dynamics codes use against a TA-bound pair loop: all-pairs tiles of a cell's
+// particles against the particles of its 27 neighbour cells, j records arriving with coalesced loads instead of per-lane gathers.
+// This file measures, on the scene ubench_sweep.hip uses (jittered dam-break lattice, cell = 1.01 R, ~29 pairs per particle):
+//
+//   Q4      the engine's quad walk over neighbour rows (tolerance arithmetic), 4 chunks in flight: the baseline
+//           (+ variants with non-temporal row loads / result stores)
+//   AP64    all-pairs, one wave per cell: the cell's particles are broadcast one after the other (v_readlane), the 64 lanes hold
+//           64 CANDIDATES of the 9 contiguous z-runs around the cell (coalesced 16-byte loads, no gathers, no rows); every lane
+//           keeps one partial sum per i-particle, transposed butterfly at the end
+//   AP8x8   the form the verdict spelled out: lane = (i-row a, j-column b), 8 j records of a neighbour cell per step, masked pair
+//           body, 3-step reduction over b
+//   BUILD   row builders: lane-per-particle walk over global memory (the engine's form) against a cell-tile builder (candidates in
+//           lanes as in AP64, ballot + mbcnt compaction into an LDS row buffer, rows written as 16-byte chunks) — same rows, same
+//           order, compared entry by entry
+//   CAL     kernels with exactly known byte counts for calibrating FETCH_SIZE / WRITE_SIZE in THIS path's access widths
+//           (run under rocprofv3 --pmc; MI355X_MICROARCH.md: only wide coalesced reads are calibrated there)
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I cpp-fluid-particles_amd/csrc -I include tools/ubench_tiles.hip -o tools/ubench_tiles
+//   ./ubench_tiles [nx=88] [reps=20] [modes: any of q a b B c]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "sph_device.hpp"
+
+using namespace sphx;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int kCap = 48;          // row capacity (entries), the engine's starting value
+struct Consts { float twoOverR, gradScale, cut; };
+
+// tolerance pair term from the difference vector (same arithmetic as ubench_sweep.hip's pair_tol)
+__device__ __forceinline__ float pair_tol_d(const Consts& c, float dx, float dy, float dz, float r2, float dvx, float dvy, float dvz, float mj)
+{
+#pragma clang fp contract(fast)
+    const float r = r2 * __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    const float q = r * c.twoOverR;
+    const float poly = (q > 1.0f) ? __builtin_fmaf(__builtin_fmaf(-3.0f, q, 12.0f), q, -12.0f) : __builtin_fmaf(9.0f, q, -12.0f) * q;
+    const float s = poly * c.gradScale * __builtin_amdgcn_rcpf(q + kEps);
+    const float dv = __builtin_fmaf(dvz, dz, __builtin_fmaf(dvy, dy, dvx * dx));
+    return mj * s * dv;
+}
+
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // (the builtin is int-typed)
+template <bool NT> __device__ __forceinline__ unsigned int ld_row(const unsigned int* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st_out(float* p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// ---- Q4: the engine's quad walk (rows in the engine's chunk layout), tolerance arithmetic -------------------------------------------
+template <bool TWO, bool NTROW, bool NTOUT>
+__global__ void __launch_bounds__(256) k_q4(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                            const unsigned int* __restrict__ rows, const int* __restrict__ counts,
+                                            float* __restrict__ out, int n, int numTiles, int cap)
+{
+    const int tile = logical_block();
+    if (tile >= numTiles) return;
+    const int g = threadIdx.x & 3;
+    const int ip = tile * 64 + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+    const bool valid = ip < n;
+    const int i = valid ? ip : n - 1;
+    const float4 self = posm[i];
+    const float4 sv = vel4[i];
+    const int cnt = valid ? min(counts[i], cap) : 0;
+    const unsigned int* rowq = rows + row_base_offset(i, cap) + g;
+    int steps = (cnt + 3) >> 2;
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    float e = 0.0f;
+    // U chunks in flight, straight-line: all row loads (unconditional: chunks past a row's end hold stale entries inside the row
+    // storage and are dropped), then all gathers, then the terms -- the engine's quad_chunks
+    auto chunks = [&](auto UC, int s) {
+        constexpr int U = decltype(UC)::value;
+        unsigned int idx[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = 4 * (s + u) + g < cnt;
+            const unsigned int raw = ld_row<NTROW>(rowq + (size_t)(s + u) * 256u);
+            idx[u] = ok[u] ? raw : 0u;
+        }
+        float4 pj[U], vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float dx = self.x - pj[u].x, dy = self.y - pj[u].y, dz = self.z - pj[u].z;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            e += pair_tol_d(c, dx, dy, dz, r2, sv.x - vj[u].x, sv.y - vj[u].y, sv.z - vj[u].z, ok[u] ? pj[u].w : 0.0f);
+        }
+    };
+    int s = 0;
+    for (; s + 4 <= steps; s += 4) chunks(std::integral_constant<int, 4>{}, s);
+    for (; s < steps; ++s) chunks(std::integral_constant<int, 1>{}, s);
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xB1, 0xf, 0xf, true));
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x4E, 0xf, 0xf, true));
+    if (valid && g == 0) st_out<NTOUT>(out + i, e);
+}
+
+// ---- shared: the candidate runs of one cell (9 (dx,dy) columns, each the contiguous particles of cells z-1..z+1) ---------------------
+struct CellRuns { int vd, vp, total; };
+// candidate t of run k is particle t + o_k for p_k <= t < p_(k+1).  Lane k (< 9) holds p_k in vp and o_k - o_(k-1) in vd (o_0 in lane 0);
+// the lookup adds the deltas of the runs that start at or before t (v_readlane + compare + select + add per run, no branches, and
+// only two long-lived VGPRs: 18 long-lived scalars made the compiler spill them into a scratch table)
+__device__ __forceinline__ CellRuns cell_runs(const int* __restrict__ cs, int cell, int gx, int gy, int gz)
+{
+    const int lane = threadIdx.x & 63;
+    const int cz = cell % gz, cy = (cell / gz) % gy, cx = cell / (gz * gy);
+    int rs = 0, rl = 0;
+    if (lane < 9) {
+        const int X = cx + lane / 3 - 1, Y = cy + lane % 3 - 1;
+        if (X >= 0 && X < gx && Y >= 0 && Y < gy) {
+            const int base = (X * gy + Y) * gz;
+            rs = cs[base + max(cz - 1, 0)];
+            rl = cs[base + min(cz + 1, gz - 1) + 1] - rs;
+        }
+    }
+    int pre = 0, run = 0;      // exclusive prefix of the run lengths, per lane
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        pre = lane == k ? run : pre;
+        run += __builtin_amdgcn_readlane(rl, k);
+    }
+    const int o = rs - pre;
+    const int oPrev = __shfl_up(o, 1, 64);
+    CellRuns R;
+    R.vp = pre; R.vd = lane == 0 ? o : o - oPrev; R.total = run;
+    return R;
+}
+__device__ __forceinline__ int run_particle(const CellRuns& R, int t)
+{
+    int j = t + __builtin_amdgcn_readlane(R.vd, 0);
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+        const int p = __builtin_amdgcn_readlane(R.vp, k), d = __builtin_amdgcn_readlane(R.vd, k);
+        j += t >= p ? d : 0;
+    }
+    return j;
+}
+
+// ---- AP64: all pairs, i broadcast, 64 candidates per batch ---------------------------------------------------------------------------
+template <bool TWO>
+__global__ void __launch_bounds__(256) k_ap64(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                              const int* __restrict__ cellOf, const int* __restrict__ cs, int gx, int gy, int gz,
+                                              float* __restrict__ out, int n, int numTiles)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = tile * 64 + lane;
+    const int myCell = i < n ? cellOf[i] : -1;
+    const int prevCell = (i > 0 && i < n) ? cellOf[i - 1] : -2;
+    unsigned long long heads = __ballot(i < n && myCell != prevCell);     // cells that START in this tile
+    while (heads) {
+        const int hl = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int cell = __builtin_amdgcn_readlane(myCell, hl);
+        const int i0 = tile * 64 + hl, i1 = cs[cell + 1];
+        const CellRuns R = cell_runs(cs, cell, gx, gy, gz);
+        const int T = R.total;
+        for (int ig = i0; ig < i1; ig += 8) {
+            const int nig = min(8, i1 - ig);
+            const float4 op = posm[min(ig + (lane & 7), n - 1)];
+            const float4 ov = vel4[min(ig + (lane & 7), n - 1)];
+            float acc[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = 0.0f;
+            for (int b = 0; b < T; b += 64) {
+                const int t = b + lane;
+                const bool has = t < T;
+                const int j = has ? run_particle(R, t) : n;
+                const float4 pj = posm[j];
+                const float4 vj = TWO ? vel4[j] : make_float4(pj.w, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    if (a < nig) {
+                        const float px = rlf(op.x, a), py = rlf(op.y, a), pz = rlf(op.z, a);
+                        const float dx = px - pj.x, dy = py - pj.y, dz = pz - pj.z;
+                        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        if (r2 <= c.cut && j != ig + a) {
+                            const float vx = rlf(ov.x, a), vy = rlf(ov.y, a), vz = rlf(ov.z, a);
+                            acc[a] += pair_tol_d(c, dx, dy, dz, r2, vx - vj.x, vy - vj.y, vz - vj.z, pj.w);
+                        }
+                    }
+                }
+            }
+            // transposed butterfly: 8 sums x 64 lanes -> lane L (L % 8 == 0) holds the total of a = L / 8
+            float r4[4], r2v[2], r1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool hi = (lane & 32) != 0;
+                const float send = hi ? acc[k] : acc[k + 4], keep = hi ? acc[k + 4] : acc[k];
+                r4[k] = keep + __shfl_xor(send, 32, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool hi = (lane & 16) != 0;
+                const float send = hi ? r4[k] : r4[k + 2], keep = hi ? r4[k + 2] : r4[k];
+                r2v[k] = keep + __shfl_xor(send, 16, 64);
+            }
+            {
+                const bool hi = (lane & 8) != 0;
+                const float send = hi ? r2v[0] : r2v[1], keep = hi ? r2v[1] : r2v[0];
+                r1 = keep + __shfl_xor(send, 8, 64);
+            }
+            r1 += __shfl_xor(r1, 4, 64); r1 += __shfl_xor(r1, 2, 64); r1 += __shfl_xor(r1, 1, 64);
+            const int a = ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 5) & 1);
+            if ((lane & 7) == 0 && a < nig) out[ig + a] = r1;
+        }
+    }
+}
+
+// ---- AP8x8: lane = (i-row a, j-column b); 8 j records of one neighbour cell per step ---------------------------------------------------
+template <bool TWO>
+__global__ void __launch_bounds__(256) k_ap88(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                              const int* __restrict__ cellOf, const int* __restrict__ cs, int gx, int gy, int gz,
+                                              float* __restrict__ out, int n, int numTiles)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = tile * 64 + lane;
+    const int myCell = i < n ? cellOf[i] : -1;
+    const int prevCell = (i > 0 && i < n) ? cellOf[i - 1] : -2;
+    unsigned long long heads = __ballot(i < n && myCell != prevCell);
+    const int a = lane >> 3, b = lane & 7;
+    while (heads) {
+        const int hl = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int cell = __builtin_amdgcn_readlane(myCell, hl);
+        const int i0 = tile * 64 + hl, i1 = cs[cell + 1];
+        const int cz = cell % gz, cy = (cell / gz) % gy, cx = cell / (gz * gy);
+        for (int ig = i0; ig < i1; ig += 8) {
+            const int me = ig + a;
+            const bool mine = me < i1;
+            const float4 op = posm[mine ? me : ig];
+            const float4 ov = vel4[mine ? me : ig];
+            float acc = 0.0f;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int X = cx + dx; if (X < 0 || X >= gx) continue;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int Y = cy + dy; if (Y < 0 || Y >= gy) continue;
+                    const int base = (X * gy + Y) * gz;
+                    const int jb = cs[base + max(cz - 1, 0)], je = cs[base + min(cz + 1, gz - 1) + 1];
+                    for (int j0 = jb; j0 < je; j0 += 8) {
+                        const int j = j0 + b;
+                        const bool has = j < je;
+                        const float4 pj = posm[has ? j : n];
+                        const float4 vj = TWO ? vel4[has ? j : n] : make_float4(pj.w, 0.f, 0.f, 0.f);
+                        const float ddx = op.x - pj.x, ddy = op.y - pj.y, ddz = op.z - pj.z;
+                        const float r2 = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                        if (mine && r2 <= c.cut && j != me)
+                            acc += pair_tol_d(c, ddx, ddy, ddz, r2, ov.x - vj.x, ov.y - vj.y, ov.z - vj.z, pj.w);
+                    }
+                }
+            }
+            acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+            acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+            acc += __shfl_xor(acc, 4, 64);
+            if (mine && b == 0) out[me] = acc;
+        }
+    }
+}
+
+// ---- BUILD: lane-per-particle walk over global memory (the engine's shape; fluid only) ------------------------------------------------
+__device__ __forceinline__ void ub_put(unsigned int* row, int cnt, unsigned int e, uint4& pend, int cap)
+{
+    const int w = cnt & 3;
+    pend.x = w == 0 ? e : pend.x; pend.y = w == 1 ? e : pend.y; pend.z = w == 2 ? e : pend.z; pend.w = w == 3 ? e : pend.w;
+    if (w == 3 && cnt < cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+}
+__global__ void __launch_bounds__(256) k_build_lane(const float4* __restrict__ posm, const int* __restrict__ cellOf, const int* __restrict__ cs,
+                                                    int gx, int gy, int gz, float cut, unsigned int* __restrict__ rows, int* __restrict__ counts,
+                                                    int n, int numTiles, int cap)
+{
+    const int tile = logical_block() * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= numTiles) return;
+    const int i = tile * 64 + (int)(threadIdx.x & 63);
+    if (i >= n) return;
+    const float4 self = posm[i];
+    const int cell = cellOf[i];
+    const int cz = cell % gz, cy = (cell / gz) % gy, cx = cell / (gz * gy);
+    unsigned int* row = rows + row_base_offset(i, cap);
+    const int zlo = max(cz - 1, 0), zhi = min(cz + 1, gz - 1);
+    int cnt = 0; uint4 pend = make_uint4(0, 0, 0, 0);
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int X = cx + dx; if (X < 0 || X >= gx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int Y = cy + dy; if (Y < 0 || Y >= gy) continue;
+            const int base = (X * gy + Y) * gz;
+            const int e = cs[base + zhi + 1];
+            int j = cs[base + zlo];
+            for (; j + 4 <= e; j += 4) {
+                float4 pj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pj[u] = posm[j + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float3 d = v3(self.x - pj[u].x, self.y - pj[u].y, self.z - pj[u].z);
+                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    if (r2 > cut || j + u == i) continue;
+                    ub_put(row, cnt, (unsigned)(j + u) | (pair_needs_plain_ops(d, r2) ? kPlainBit : 0u), pend, cap); ++cnt;
+                }
+            }
+            for (; j < e; ++j) {
+                const float4 pj = posm[j];
+                const float3 d = v3(self.x - pj.x, self.y - pj.y, self.z - pj.z);
+                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                if (r2 > cut || j == i) continue;
+                ub_put(row, cnt, (unsigned)j | (pair_needs_plain_ops(d, r2) ? kPlainBit : 0u), pend, cap); ++cnt;
+            }
+        }
+    }
+    counts[i] = cnt;
+    if ((cnt & 3) != 0 && cnt < cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+}
+
+// ---- BUILD: cell-tile builder.  One wave per cell: candidates in lanes (coalesced), i broadcast, accepted lanes are compacted in
+// visit order (ballot + mbcnt) into an LDS row buffer; the rows leave as 16-byte chunks.  No gathers.
+constexpr int kBufCap = 64;       // LDS row buffer entries per i-particle (rows longer than the capacity only count on)
+__global__ void __launch_bounds__(256) k_build_tile(const float4* __restrict__ posm, const int* __restrict__ cellOf, const int* __restrict__ cs,
+                                                    int gx, int gy, int gz, float cut, unsigned int* __restrict__ rows, int* __restrict__ counts,
+                                                    int n, int numTiles, int cap)
+{
+    __shared__ unsigned int rowbuf[4][8][kBufCap];
+    const int wave = threadIdx.x >> 6;
+    const int tile = logical_block() * 4 + wave;
+    if (tile >= numTiles) return;
+    const int lane = threadIdx.x & 63;
+    const int i = tile * 64 + lane;
+    const int myCell = i < n ? cellOf[i] : -1;
+    const int prevCell = (i > 0 && i < n) ? cellOf[i - 1] : -2;
+    unsigned long long heads = __ballot(i < n && myCell != prevCell);
+    const int cap4 = cap >> 2;
+    while (heads) {
+        const int hl = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int cell = __builtin_amdgcn_readlane(myCell, hl);
+        const int i0 = tile * 64 + hl, i1 = cs[cell + 1];
+        const CellRuns R = cell_runs(cs, cell, gx, gy, gz);
+        const int T = R.total;
+        for (int ig = i0; ig < i1; ig += 8) {
+            const int nig = min(8, i1 - ig);
+            const float4 op = posm[min(ig + (lane & 7), n - 1)];
+            int cnt[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) cnt[a] = 0;
+            for (int b = 0; b < T; b += 64) {
+                const int t = b + lane;
+                const bool has = t < T;
+                const int j = has ? run_particle(R, t) : n;
+                const float4 pj = posm[j];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    if (a < nig) {
+                        const float px = rlf(op.x, a), py = rlf(op.y, a), pz = rlf(op.z, a);
+                        const float3 d = v3(px - pj.x, py - pj.y, pz - pj.z);
+                        const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                        const bool acc = has && r2 <= cut && j != ig + a;
+                        const unsigned long long m = __ballot(acc);
+                        if (m) {
+                            const int k = cnt[a] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if (acc && k < kBufCap) rowbuf[wave][a][k] = (unsigned)j | (pair_needs_plain_ops(d, r2) ? kPlainBit : 0u);
+                            cnt[a] += __builtin_popcountll(m);
+                        }
+                    }
+                }
+            }
+            wave_lds_fence();
+            // rows out: chunk slots (a, ch), 8 * cap/4 of them, one 16-byte store per lane and pass
+            for (int idx = lane; idx < 8 * cap4; idx += 64) {
+                const int a = idx / cap4, ch = idx - a * cap4;
+                int ca = cnt[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) ca = a == k ? cnt[k] : ca;
+                if (a < nig && 4 * ch < min(ca, cap))
+                    *reinterpret_cast<uint4*>(rows + row_base_offset(ig + a, cap) + (size_t)ch * 256u) = *reinterpret_cast<const uint4*>(&rowbuf[wave][a][4 * ch]);
+            }
+            if (lane < nig) {
+                int ca = cnt[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) ca = lane == k ? cnt[k] : ca;
+                counts[ig + lane] = ca;
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// ---- CAL: exactly known byte counts --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cal_stream16(const float4* __restrict__ p, size_t n4, float* __restrict__ out)
+{
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = p[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 123.456f) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_cal_stream4(const unsigned int* __restrict__ p, size_t n1, float* __restrict__ out)
+{
+    unsigned int s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) s += p[i];
+    if (s == 0x12345678u) out[0] = 1.0f;
+}
+// the quad walk's row read: a block = one tile; a wave reads 64 consecutive dwords (16 particles x 4 entries) of every chunk step
+__global__ void __launch_bounds__(256) k_cal_quadrows(const unsigned int* __restrict__ rows, int numTiles, int cap, float* __restrict__ out)
+{
+    const int tile = logical_block();
+    if (tile >= numTiles) return;
+    const unsigned int* rowq = rows + ((size_t)tile * cap) * 64u + threadIdx.x;
+    unsigned int s = 0;
+    for (int st = 0; st < cap / 4; ++st) s += rowq[(size_t)st * 256u];
+    if (s == 0x12345678u) out[0] = 1.0f;
+}
+// one 16-byte record per `stride` records: every line is touched once, 16 bytes of it are used
+__global__ void __launch_bounds__(256) k_cal_gather(const float4* __restrict__ p, size_t nrec, int stride, float* __restrict__ out)
+{
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i * stride < nrec; i += (size_t)gridDim.x * 256) { const float4 v = p[i * stride]; s += v.x + v.w; }
+    if (s == 123.456f) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_cal_store16(float4* __restrict__ p, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+__global__ void __launch_bounds__(256) k_cal_store4of16(float4* __restrict__ p, size_t n4)     // the posf.w update: 4 bytes of every 16-byte record
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i].w = 5.0f;
+}
+__global__ void __launch_bounds__(256) k_cal_store4(float* __restrict__ p, size_t n1)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) p[i] = 6.0f;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------------
+int main(int argc, char** argv)
+{
+    const int nx = argc > 1 ? atoi(argv[1]) : 88;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const char* modes = argc > 3 ? argv[3] : "qabB";
+    const float spacing = 0.02f, R = 0.04f, cellLength = 1.01f * R, scale = nx / 24.0f;
+    const int ny = 3 * nx / 2, nz = nx;
+    const int n = nx * ny * nz;
+    const int gx = (int)ceilf(scale / cellLength), gy = gx, gz = gx, C = gx * gy * gz;
+    printf("scene: %d x %d x %d = %d particles, grid %d^3, R = %g\n", nx, ny, nz, n, gx, R);
+
+    std::vector<float4> P0(n);
+    std::vector<int> cell(n);
+    unsigned int rng = 12345u;
+    auto jitter = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.08f * spacing; };
+    {
+        int q = 0;
+        for (int iy = 0; iy < ny; ++iy) for (int ix = 0; ix < nx; ++ix) for (int iz = 0; iz < nz; ++iz, ++q) {
+            P0[q] = make_float4(0.27f * scale + spacing * ix + jitter(), 0.10f * scale + spacing * iy + jitter(),
+                                0.27f * scale + spacing * iz + jitter(), 76.596750762082e-6f);
+            const int cx = (int)(P0[q].x / cellLength), cy = (int)(P0[q].y / cellLength), cz = (int)(P0[q].z / cellLength);
+            cell[q] = (cx * gy + cy) * gz + cz;
+        }
+    }
+    std::vector<int> cs(C + 2, 0), order(n);
+    for (int q = 0; q < n; ++q) cs[cell[q] + 1]++;
+    for (int k = 0; k < C + 1; ++k) cs[k + 1] += cs[k];
+    {
+        std::vector<int> cur(cs.begin(), cs.begin() + C + 1);
+        for (int q = 0; q < n; ++q) order[cur[cell[q]]++] = q;
+    }
+    std::vector<float4> posm(n + 1), vel4(n + 1);
+    std::vector<int> scell(n);
+    for (int q = 0; q < n; ++q) {
+        posm[q] = P0[order[q]]; scell[q] = cell[order[q]];
+        rng = rng * 1664525u + 1013904223u;
+        vel4[q] = make_float4(jitter() * 50.f, -0.04f + jitter() * 50.f, jitter() * 50.f, 0.0f);
+    }
+    posm[n] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
+    vel4[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int numTiles = (n + 63) / 64;
+    const float tCut = R * R;
+    int maxCell = 0; long long nonEmpty = 0;
+    for (int k = 0; k < C; ++k) { maxCell = std::max(maxCell, cs[k + 1] - cs[k]); nonEmpty += cs[k + 1] > cs[k]; }
+    printf("cells: %lld non-empty, %.2f particles per non-empty cell, max %d\n", nonEmpty, (double)n / nonEmpty, maxCell);
+
+    Consts c; c.twoOverR = 2.0f / R; c.gradScale = 1.0f / (kPi * R * R * R * R * R); c.cut = tCut;
+
+    float4 *dPos, *dVel; int *dCell, *dCs; unsigned int *dRowsA, *dRowsB; int *dCntA, *dCntB; float* dOut;
+    const size_t rowWords = (size_t)numTiles * kCap * 64;
+    CK(hipMalloc(&dPos, sizeof(float4) * (n + 1))); CK(hipMalloc(&dVel, sizeof(float4) * (n + 1)));
+    CK(hipMalloc(&dCell, 4 * (size_t)n)); CK(hipMalloc(&dCs, 4 * (size_t)(C + 2)));
+    CK(hipMalloc(&dRowsA, 4 * rowWords)); CK(hipMalloc(&dRowsB, 4 * rowWords)); CK(hipMalloc(&dCntA, 4 * (size_t)n)); CK(hipMalloc(&dCntB, 4 * (size_t)n));
+    CK(hipMalloc(&dOut, 4 * (size_t)n));
+    CK(hipMemcpy(dPos, posm.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dVel, vel4.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dCell, scell.data(), 4 * (size_t)n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dCs, cs.data(), 4 * (size_t)(C + 2), hipMemcpyHostToDevice));
+    CK(hipMemset(dRowsA, 0, 4 * rowWords)); CK(hipMemset(dRowsB, 0, 4 * rowWords));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](auto&& launch) {
+        for (int w = 0; w < 2; ++w) launch();
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / reps;
+    };
+    const unsigned gridW = xcd_grid(n, 256);                 // 4 waves = 4 tiles per block
+    const unsigned gridQ = xcd_grid(numTiles * 256, 256);    // one block per tile
+
+    // rows: always built on the device by the lane builder (the baseline the sweeps read)
+    hipLaunchKernelGGL(k_build_lane, dim3(gridW), dim3(256), 0, st, dPos, dCell, dCs, gx, gy, gz, tCut, dRowsA, dCntA, n, numTiles, kCap);
+    CK(hipStreamSynchronize(st));
+    std::vector<int> ca(n);
+    CK(hipMemcpy(ca.data(), dCntA, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    long long pairs = 0; int maxCnt = 0;
+    for (int i = 0; i < n; ++i) { pairs += ca[i]; maxCnt = std::max(maxCnt, ca[i]); }
+    printf("pairs: %lld (%.1f per particle), longest row %d (capacity %d)\n", pairs, (double)pairs / n, maxCnt, kCap);
+
+    if (strchr(modes, 'B')) {
+        const float a = timeit([&] { hipLaunchKernelGGL(k_build_lane, dim3(gridW), dim3(256), 0, st, dPos, dCell, dCs, gx, gy, gz, tCut, dRowsA, dCntA, n, numTiles, kCap); });
+        printf("%-52s %8.3f ms\n", "BUILD lane-per-particle (global gathers)", a);
+        const float b = timeit([&] { hipLaunchKernelGGL(k_build_tile, dim3(gridW), dim3(256), 0, st, dPos, dCell, dCs, gx, gy, gz, tCut, dRowsB, dCntB, n, numTiles, kCap); });
+        printf("%-52s %8.3f ms\n", "BUILD cell tile (candidates in lanes, no gathers)", b);
+        std::vector<int> cb(n); std::vector<unsigned int> ra(rowWords), rb(rowWords);
+        CK(hipMemcpy(cb.data(), dCntB, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ra.data(), dRowsA, 4 * rowWords, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), dRowsB, 4 * rowWords, hipMemcpyDeviceToHost));
+        long long badCnt = 0, badEnt = 0;
+        for (int i = 0; i < n; ++i) {
+            if (ca[i] != cb[i]) { ++badCnt; continue; }
+            for (int k = 0; k < std::min(ca[i], kCap); ++k) {
+                const size_t at = ((size_t)(i >> 6) * kCap) * 64u + (size_t)(i & 63) * 4u + (size_t)(k >> 2) * 256u + (k & 3);
+                if (ra[at] != rb[at]) ++badEnt;
+            }
+        }
+        printf("   cell-tile rows vs the lane builder: %lld counts differ, %lld entries differ\n", badCnt, badEnt);
+    }
+
+    std::vector<float> ref[2], got(n);
+    auto run = [&](const char* name, int two, auto&& launch) {
+        CK(hipMemsetAsync(dOut, 0, 4 * (size_t)n, st));
+        const float ms = timeit(launch);
+        CK(hipMemcpy(got.data(), dOut, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        char verdict[96] = "reference";
+        if (ref[two].empty()) ref[two] = got;
+        else {
+            double maxAbs = 0, scaleV = 0;
+            for (int i = 0; i < n; ++i) { maxAbs = std::max(maxAbs, fabs((double)got[i] - ref[two][i])); scaleV = std::max(scaleV, fabs((double)ref[two][i])); }
+            snprintf(verdict, sizeof(verdict), "max |diff| %.2e of field scale %.2e", maxAbs, scaleV);
+        }
+        printf("%-52s %8.3f ms   %7.1f Gpair/s   alg %6.1f GB/s (44 B/particle)   [%s]\n", name, ms, pairs / ms * 1e-6, 44.0 * n / ms * 1e-6, verdict);
+    };
+    for (int two = 1; two >= 0; --two) {
+        char nm[96];
+        auto tag = [&](const char* s) { snprintf(nm, sizeof(nm), "%s tol %s", s, two ? "2f" : "1f"); return nm; };
+#define LQ4(NR, NO) do { if (two) hipLaunchKernelGGL((k_q4<true, NR, NO>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRowsA, dCntA, dOut, n, numTiles, kCap); \
+                         else hipLaunchKernelGGL((k_q4<false, NR, NO>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRowsA, dCntA, dOut, n, numTiles, kCap); } while (0)
+        if (strchr(modes, 'q')) {
+            run(tag("Q4 quad walk (engine rows)"), two, [&] { LQ4(false, false); });
+            run(tag("Q4 + non-temporal row loads"), two, [&] { LQ4(true, false); });
+            run(tag("Q4 + non-temporal row loads and stores"), two, [&] { LQ4(true, true); });
+        }
+        if (strchr(modes, 'a'))
+            run(tag("AP64 all-pairs, i broadcast, 64 candidates/batch"), two, [&] {
+                if (two) hipLaunchKernelGGL((k_ap64<true>), dim3(gridW), dim3(256), 0, st, c, dPos, dVel, dCell, dCs, gx, gy, gz, dOut, n, numTiles);
+                else hipLaunchKernelGGL((k_ap64<false>), dim3(gridW), dim3(256), 0, st, c, dPos, dVel, dCell, dCs, gx, gy, gz, dOut, n, numTiles); });
+        if (strchr(modes, 'b'))
+            run(tag("AP8x8 all-pairs, 8 i x 8 j per step"), two, [&] {
+                if (two) hipLaunchKernelGGL((k_ap88<true>), dim3(gridW), dim3(256), 0, st, c, dPos, dVel, dCell, dCs, gx, gy, gz, dOut, n, numTiles);
+                else hipLaunchKernelGGL((k_ap88<false>), dim3(gridW), dim3(256), 0, st, c, dPos, dVel, dCell, dCs, gx, gy, gz, dOut, n, numTiles); });
+    }
+
+    if (strchr(modes, 'o')) {      // particle ORDER: the same rows and records re-laid brick-major / Morton instead of cell-major (x, y, z)
+        std::vector<unsigned int> ra(rowWords);
+        CK(hipMemcpy(ra.data(), dRowsA, 4 * rowWords, hipMemcpyDeviceToHost));
+        float4 *dPos2, *dVel2; CK(hipMalloc(&dPos2, sizeof(float4) * (n + 1))); CK(hipMalloc(&dVel2, sizeof(float4) * (n + 1)));
+        auto part1by2 = [](unsigned int x) { x &= 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x; };
+        for (int ord = 0; ord < 3; ++ord) {
+            const char* oname = ord == 0 ? "bricks 4x4x4 cells" : (ord == 1 ? "bricks 2x2x2 cells" : "Morton over cells");
+            std::vector<std::pair<unsigned long long, int>> keyed; keyed.reserve(nonEmpty);
+            for (int cc = 0; cc < C; ++cc) {
+                if (cs[cc + 1] == cs[cc]) continue;
+                const unsigned cz = cc % gz, cy = (cc / gz) % gy, cx = cc / (gz * gy);
+                unsigned long long key;
+                if (ord == 2) key = (unsigned long long)part1by2(cz) | ((unsigned long long)part1by2(cy) << 1) | ((unsigned long long)part1by2(cx) << 2);
+                else {
+                    const unsigned B = ord == 0 ? 4 : 2;
+                    const unsigned long long brick = ((unsigned long long)(cx / B) * (gy / B + 1) + cy / B) * (gz / B + 1) + cz / B;
+                    key = brick * 64 + ((cx % B) * B + cy % B) * B + cz % B;
+                }
+                keyed.push_back({key, cc});
+            }
+            std::sort(keyed.begin(), keyed.end());
+            std::vector<int> newOf(n + 1), oldOf(n);
+            int at = 0;
+            for (auto& kc : keyed) for (int j = cs[kc.second]; j < cs[kc.second + 1]; ++j) { newOf[j] = at; oldOf[at] = j; ++at; }
+            newOf[n] = n;
+            std::vector<float4> p2(n + 1), v2(n + 1);
+            for (int q = 0; q < n; ++q) { p2[newOf[q]] = posm[q]; v2[newOf[q]] = vel4[q]; }
+            p2[n] = posm[n]; v2[n] = vel4[n];
+            std::vector<unsigned int> r2(rowWords, 0u); std::vector<int> c2(n);
+            for (int i = 0; i < n; ++i) {
+                const int ni = newOf[i]; c2[ni] = ca[i];
+                for (int k = 0; k < std::min(ca[i], kCap); ++k) {
+                    const size_t from = ((size_t)(i >> 6) * kCap) * 64u + (size_t)(i & 63) * 4u + (size_t)(k >> 2) * 256u + (k & 3);
+                    const size_t to = ((size_t)(ni >> 6) * kCap) * 64u + (size_t)(ni & 63) * 4u + (size_t)(k >> 2) * 256u + (k & 3);
+                    r2[to] = (unsigned)newOf[ra[from] & kIndexMask];
+                }
+            }
+            // rows keep their visit order; a variant with each row sorted by (new) index: neighbours of consecutive entries adjacent in memory
+            CK(hipMemcpy(dPos2, p2.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dVel2, v2.data(), sizeof(float4) * (n + 1), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dCntB, c2.data(), 4 * (size_t)n, hipMemcpyHostToDevice));
+            for (int sorted = 0; sorted < 2; ++sorted) {
+                if (sorted)
+                    for (int ni = 0; ni < n; ++ni) {
+                        unsigned int tmp[kCap]; const int m = std::min(c2[ni], kCap);
+                        const size_t base = ((size_t)(ni >> 6) * kCap) * 64u + (size_t)(ni & 63) * 4u;
+                        for (int k = 0; k < m; ++k) tmp[k] = r2[base + (size_t)(k >> 2) * 256u + (k & 3)];
+                        std::sort(tmp, tmp + m);
+                        for (int k = 0; k < m; ++k) r2[base + (size_t)(k >> 2) * 256u + (k & 3)] = tmp[k];
+                    }
+                CK(hipMemcpy(dRowsB, r2.data(), 4 * rowWords, hipMemcpyHostToDevice));
+                for (int two = 1; two >= 0; --two) for (int nt = 0; nt < 2; ++nt) {
+                    CK(hipMemsetAsync(dOut, 0, 4 * (size_t)n, st));
+                    const float ms = timeit([&] {
+                        if (two) { if (nt) hipLaunchKernelGGL((k_q4<true, true, false>), dim3(gridQ), dim3(256), 0, st, c, dPos2, dVel2, dRowsB, dCntB, dOut, n, numTiles, kCap);
+                                   else hipLaunchKernelGGL((k_q4<true, false, false>), dim3(gridQ), dim3(256), 0, st, c, dPos2, dVel2, dRowsB, dCntB, dOut, n, numTiles, kCap); }
+                        else { if (nt) hipLaunchKernelGGL((k_q4<false, true, false>), dim3(gridQ), dim3(256), 0, st, c, dPos2, dVel2, dRowsB, dCntB, dOut, n, numTiles, kCap);
+                               else hipLaunchKernelGGL((k_q4<false, false, false>), dim3(gridQ), dim3(256), 0, st, c, dPos2, dVel2, dRowsB, dCntB, dOut, n, numTiles, kCap); } });
+                    CK(hipMemcpy(got.data(), dOut, 4 * (size_t)n, hipMemcpyDeviceToHost));
+                    double maxAbs = 0;
+                    if (!ref[two].empty()) for (int i = 0; i < n; ++i) maxAbs = std::max(maxAbs, fabs((double)got[newOf[i]] - ref[two][i]));
+                    char nm[128]; snprintf(nm, sizeof(nm), "Q4 %s%s, %s rows tol %s", oname, nt ? " + nt rows" : "", sorted ? "index-sorted" : "visit-order", two ? "2f" : "1f");
+                    printf("%-72s %8.3f ms   %7.1f Gpair/s   [max |diff| %.2e]\n", nm, ms, pairs / ms * 1e-6, maxAbs);
+                }
+            }
+        }
+        CK(hipFree(dPos2)); CK(hipFree(dVel2));
+    }
+
+    if (strchr(modes, 'c')) {      // calibration dispatches (run once each; read FETCH_SIZE / WRITE_SIZE per dispatch from rocprofv3 --pmc)
+        const size_t bytes = (size_t)1 << 30;            // 1 GiB: beyond the 256 MB Infinity Cache
+        float4* big; CK(hipMalloc(&big, bytes)); CK(hipMemset(big, 0, bytes));
+        const unsigned g = 256 * 8 * 4;
+        printf("CAL: known bytes per dispatch\n");
+        printf("  k_cal_stream16   reads  %zu\n", bytes);
+        hipLaunchKernelGGL(k_cal_stream16, dim3(g), dim3(256), 0, st, big, bytes / 16, dOut);
+        printf("  k_cal_stream4    reads  %zu\n", bytes);
+        hipLaunchKernelGGL(k_cal_stream4, dim3(g), dim3(256), 0, st, reinterpret_cast<const unsigned int*>(big), bytes / 4, dOut);
+        printf("  k_cal_quadrows   reads  %zu (the row array, every chunk step)\n", 4 * rowWords);
+        hipLaunchKernelGGL(k_cal_quadrows, dim3(gridQ), dim3(256), 0, st, dRowsA, numTiles, kCap, dOut);
+        printf("  k_cal_gather s=4 touches %zu lines of 64 B, uses 16 B of each (useful %zu)\n", bytes / 64, bytes / 4);
+        hipLaunchKernelGGL(k_cal_gather, dim3(g), dim3(256), 0, st, big, bytes / 16, 4, dOut);
+        printf("  k_cal_gather s=8 touches %zu lines of 128 B, uses 16 B of each (useful %zu)\n", bytes / 128, bytes / 8);
+        hipLaunchKernelGGL(k_cal_gather, dim3(g), dim3(256), 0, st, big, bytes / 16, 8, dOut);
+        printf("  k_cal_store16    writes %zu\n", bytes);
+        hipLaunchKernelGGL(k_cal_store16, dim3(g), dim3(256), 0, st, big, bytes / 16);
+        printf("  k_cal_store4of16 writes %zu (4 bytes of every 16-byte record of a %zu-byte array)\n", bytes / 4, bytes);
+        hipLaunchKernelGGL(k_cal_store4of16, dim3(g), dim3(256), 0, st, big, bytes / 16);
+        printf("  k_cal_store4     writes %zu\n", bytes / 4);
+        hipLaunchKernelGGL(k_cal_store4, dim3(g), dim3(256), 0, st, reinterpret_cast<float*>(big), bytes / 16);
+        CK(hipStreamSynchronize(st));
+        CK(hipFree(big));
+    }
+    return 0;
+}
