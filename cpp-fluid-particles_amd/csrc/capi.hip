@@ -197,8 +197,11 @@ int sphx_create_impl(const sphx_params* P, const float* fluid, int n, const floa
     default: return fail(SPHX_ERR_INVALID, "sphx_create: unknown solver");
     }
     if (P->reserved[0]) h->wcsph->setEngineFlags(P->reserved[0]);
-    if (P->reserved[3] != 0 && P->reserved[3] != 1) return fail(SPHX_ERR_INVALID, "sphx_create: reserved[3] (arithmetic) must be 0 (strict) or 1 (tolerance)");
-    if (P->reserved[3] == 1) h->wcsph->setToleranceArithmetic(true);
+    if (P->reserved[3] < 0 || P->reserved[3] > 2)
+        return fail(SPHX_ERR_INVALID, "sphx_create: reserved[3] (arithmetic) must be 0 (strict), 1 (tolerance) or 2 (tolerance with persistent rows)");
+    if (P->reserved[3] >= 1) h->wcsph->setToleranceArithmetic(true);
+    if (P->reserved[3] == 2 && (P->reserved[1] != 0 || P->reserved[2] != 0))
+        return fail(SPHX_ERR_INVALID, "sphx_create: persistent rows (reserved[3] = 2) are a whole-domain mode, not available to slab systems");
     const float3 space = make_float3(P->space[0], P->space[1], P->space[2]);
     const float3 G = make_float3(P->gravity[0], P->gravity[1], P->gravity[2]);
     const int3 cells = make_int3(P->cells[0], P->cells[1], P->cells[2]);
@@ -218,6 +221,8 @@ int sphx_create_impl(const sphx_params* P, const float* fluid, int n, const floa
         h->system.reset(new SPHSystem(SPHSystem::NoInitialStep{}, fluids, walls, solver, space, P->cell_length, P->radius,
                                       P->dt, P->m0, P->rho0, P->rho_boundary, P->stiff, P->visc, P->surface_tension,
                                       P->air_pressure, G, cells));
+    // persistent rows: WCSPH / DFSPH (PBD moves positions inside the step and keeps its own skin scheme: plain tolerance mode there)
+    if (P->reserved[3] == 2 && !h->pbd) h->system->setPersistentRows(true);
     if (hipStreamSynchronize(sphx::stream()) != hipSuccess) return fail(SPHX_ERR_HIP, last_error_text());
     *out = h.release();
     return SPHX_OK;
@@ -307,6 +312,20 @@ int sphx_rows_stale(const sphx_system* h, int* stale)
     return SPHX_OK;
 }
 
+int sphx_persistent_stats(const sphx_system* h, int* in_use, int* row_builds, int* steps)
+{
+    if (!h || !h->wcsph) return fail(SPHX_ERR_INVALID, "sphx_persistent_stats: bad argument");
+    int words[4] = {0, 0, 0, 0};
+    const int* flags = h->system->persistentRows() ? h->wcsph->enginePersistFlags() : nullptr;
+    if (flags && (hipMemcpyAsync(words, flags, sizeof(words), hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+                  hipStreamSynchronize(sphx::stream()) != hipSuccess))
+        return fail(SPHX_ERR_HIP, "sphx_persistent_stats: copy failed");
+    if (in_use) *in_use = flags ? 1 : 0;
+    if (row_builds) *row_builds = words[2];
+    if (steps) *steps = words[3];
+    return SPHX_OK;
+}
+
 int sphx_iters(const sphx_system* h, int* div, int* den)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "null system");
@@ -318,6 +337,13 @@ int sphx_iters(const sphx_system* h, int* div, int* den)
 // ------------------------------------------------------------------------------------ fields
 int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
 {
+    // persistent rows: the API arrays and the grid tables are current after every step; the solver's own per-particle arrays
+    // live in the working order until somebody asks for them
+    switch (field) {
+    case SPHX_F_POS: case SPHX_F_VEL: case SPHX_F_DENSITY: case SPHX_F_PRESSURE: case SPHX_F_MASS: case SPHX_F_CELL:
+    case SPHX_F_CELLSTART_F: case SPHX_F_CELLSTART_B: case SPHX_F_ID: case SPHX_F_BPOS: case SPHX_F_BMASS: break;
+    default: h->system->invalidatePersistentOrder(); break;
+    }
     const auto f = h->system->getFluids();
     const auto b = h->system->getBoundaries();
     const size_t n = (size_t)h->n, nb = (size_t)h->nb;
@@ -385,6 +411,7 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
         field != SPHX_F_ID)
         return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
     void* p; size_t sz;
+    if (h) h->system->invalidatePersistentOrder();       // the working copy is re-primed from the API arrays by the next step
     if (!h || !src || sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
     if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
     if (!sz) return SPHX_OK;
@@ -417,6 +444,7 @@ int sphx_error_total_fixed(sphx_system* h, long long* total)
 int sphx_set_count(sphx_system* h, int n_fluid)
 {
     if (!h || n_fluid < 0 || n_fluid > h->n) return fail(SPHX_ERR_INVALID, "sphx_set_count: count exceeds the capacity given to sphx_create");
+    h->system->invalidatePersistentOrder();
     h->system->getFluids()->setActiveCount((unsigned)n_fluid);
     return SPHX_OK;
 }

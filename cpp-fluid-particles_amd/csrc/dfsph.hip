@@ -43,6 +43,15 @@ void DFSPHSolver::resetErrorTotal()
     HIP_CALL(hipMemsetAsync(errorAccum.addr(), 0, sizeof(unsigned long long) * kErrorSlots * kErrorSlotStride, sphx::stream()));
 }
 
+void DFSPHSolver::permuteState(const int* perm, int n)
+{
+    BasicSPHSolver::permuteState(perm, n);
+    for (DArray<float>* a : {&alpha, &bufferFloat, &error, &denWarmStiff}) {
+        ew_gather_float(scratch.addr(), a->addr(), perm, n);
+        ew_copy(a->addr(), scratch.addr(), sizeof(float) * (size_t)n);
+    }
+}
+
 float DFSPHSolver::readErrorTotal()
 {
     return (float)((double)readErrorTotalFixed() * (1.0 / 4294967296.0));
@@ -258,6 +267,11 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         c.packBoundary(*boundaries);
         c.ensureList(cellStartFluid, cellStartBoundary);
         ScopedKernel t("warm_permute");   // DFSPHSolver.cu:170-171
+        if (c.persistRows) {              // the arrays were re-sorted in this step only if the rows are being rebuilt (device flag)
+            ew_gather_float_if(scratch.addr(), denWarmStiff.addr(), fluids->getSortPerm(), num, c.persistFlags.addr(0));
+            ew_copy_float_if(denWarmStiff.addr(), scratch.addr(), num, c.persistFlags.addr(0));
+            return;
+        }
         ew_gather_float(scratch.addr(), denWarmStiff.addr(), fluids->getSortPerm(), num);
         ew_copy(denWarmStiff.addr(), scratch.addr(), sizeof(float) * num);
         return;

@@ -123,6 +123,15 @@ struct SweepCache {
     DArray<int> staleFlag;                   // two flags: [activeFlag] is raised by the coming position updates; [2] counts rebuilds
     int activeFlag = 0;
     float staleLimit2() const { return (0.45f * skin) * (0.45f * skin); }
+    // Persistent rows (SPHSystem's persistent mode; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems): the solver steps
+    // arrays that keep the order of the last row build; rows carry a skin no larger than the slack of the cell length
+    // (cellLength - R, so that the 27-cell candidate walk still sees every pair within R + skin) and are rebuilt only when the
+    // device-side check of the step's grid pass raises persistFlags[0].  csBuild = the fluid cell table of the build (the order
+    // the arrays are in), for the cell walks of particles without a row.
+    bool persistWanted = false, persistRows = false;
+    DArray<int> persistFlags;                // [0] rebuild in this step (device), [1] forced by the host, [2] rebuilds so far, [3] steps so far
+    std::unique_ptr<DArray<int>> csBuild;
+    void requestRebuild();                   // host side: the next step rebuilds (rows reallocated, state rewritten)
     bool fluidValid = false;
     bool boundaryValid = false;
     bool listValid = false;
@@ -189,6 +198,9 @@ void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n);
 void ew_gather_float(float* dst, const float* src, const int* perm, int n);
 void ew_gather_int(int* dst, const int* src, const int* perm, int n);
 void ew_copy(void* dst, const void* src, size_t bytes);
+// the same, executed only when the device word *flag is non-zero (persistent rows: launched every step, replayable in a graph)
+void ew_gather_float_if(float* dst, const float* src, const int* perm, int n, const int* flag);
+void ew_copy_float_if(float* dst, const float* src, int n, const int* flag);
 void ew_fill_float(float* dst, float value, int n);
 void ew_iota(int* dst, int n);
 

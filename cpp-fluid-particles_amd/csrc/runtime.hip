@@ -268,6 +268,26 @@ __global__ void k_pack_fluid(float4* __restrict__ posm, float4* __restrict__ vel
     if (m != mass[0]) *massUniform = 0;
 }
 
+__global__ void k_gather_float_if(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ perm, int n, const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[perm[q]];
+}
+__global__ void k_copy_float_if(float* __restrict__ dst, const float* __restrict__ src, int n, const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[q];
+}
+void ew_gather_float_if(float* dst, const float* src, const int* perm, int n, const int* flag)
+{
+    if (n > 0) k_gather_float_if<<<blocks_for(n), 256, 0, stream()>>>(dst, src, perm, n, flag);
+}
+void ew_copy_float_if(float* dst, const float* src, int n, const int* flag)
+{
+    if (n > 0) k_copy_float_if<<<blocks_for(n), 256, 0, stream()>>>(dst, src, n, flag);
+}
 void ew_gather_float3(float3* dst, const float3* src, const int* perm, int n)
 {
     if (n <= 0) return;
@@ -453,7 +473,7 @@ SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
-      rowOverflow(4u), staleFlag(3u)
+      rowOverflow(4u), staleFlag(3u), persistFlags(4u)
 {
     capAuto = true; cap = 48;
     if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
@@ -475,6 +495,21 @@ void SweepCache::setup(int3 cellSize, float cellLength, float radius)
         g = make_grid_desc(cellSize, cellLength, cellOffsetX);
         cellKey = cellLength; cellsKey = cellSize;
     }
+    if (persistWanted && !skinRows) {
+        // the skin may not exceed the slack of the cell length: a pair within R + skin must lie in adjacent cells for the 27-cell
+        // candidate walk of the builder to see it (the reference scene: cellLength = 1.01 R)
+        const float slack = cellLength - radius;
+        const float s = slack > 0.0f ? std::min(0.05f * radius, 0.95f * slack) : 0.0f;
+        const bool on = tolerance && !isSlab && s > 0.0f && !(flags & (kFlagNoList | kFlagTiles | kFlagUnfused));
+        if (on != persistRows || (on && s != skin)) { persistRows = on; skin = on ? s : 0.0f; listValid = false; ++generation; requestRebuild(); }
+    }
+}
+
+void SweepCache::requestRebuild()
+{
+    const int one = 1;
+    HIP_CALL(hipMemcpyAsync(persistFlags.addr(1), &one, sizeof(int), hipMemcpyHostToDevice, stream()));
+    HIP_CALL(hipStreamSynchronize(stream()));      // (`one` lives on this stack frame)
 }
 
 void SweepCache::packFluid(const SPHParticles& fluids)
@@ -589,7 +624,9 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.stale = skinNow ? staleFlag.addr(activeFlag) : nullptr;
     c.rowCell = (skinNow && rowCell) ? rowCell->addr() : nullptr;
     c.buildCut = k.tCut;
-    if (skinRows && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
+    if ((skinRows || persistRows) && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
+    c.persist = (persistRows && skin > 0.0f && use && rowCell) ? 1 : 0;
+    if (c.persist) { c.rowCell = rowCell->addr(); c.tileFmt = nullptr; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
     c.overflowMax = nullptr;
     c.brick = (use && listIsBrick) ? 1 : 0;
@@ -605,7 +642,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
 bool SweepCache::brickMode() const
 {
     return brickWanted && !brickFailed && tolerance && !isSlab && allowTiles && !(flags & (kFlagTiles | kFlagNoList)) && rangeLo < 0 &&
-           !(skinRows && skin > 0.0f) && n >= brickMin;
+           !(skinRows && skin > 0.0f) && !persistRows && n >= brickMin;
 }
 
 // Adaptive row capacity: called between steps (never inside a captured graph).  One 4-byte read every 8+ steps.
@@ -629,19 +666,62 @@ void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
     }
     const int longest = words[0];
     if (!capAuto || longest <= cap) return;
-    cap = std::min(1024, (longest + 8 + kRowChunk - 1) / kRowChunk * kRowChunk);
     HIP_CALL(hipMemsetAsync(rowOverflow.addr(), 0, sizeof(int), stream()));
-    // reallocate HERE, between steps: the next step may be captured into a hipGraph, and a capture must not allocate
-    const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
-    nbr.reset();
-    nbr.reset(new RowStore(entries));
+    // Bounded growth: one dense clump must not size the rows of ALL particles -- beyond kRowCapMax entries a
+    // particle walks the cells directly (same bits, slower), which is what the fixed 96-entry rows of r02 did.
+    constexpr int kRowCapMax = 192;
+    const int want = std::min(kRowCapMax, (longest + 8 + kRowChunk - 1) / kRowChunk * kRowChunk);
+    if (want <= cap) return;                   // already at the bound: nothing to reallocate, no graph to drop
+    // reallocate HERE, between steps: the next step may be captured into a hipGraph, and a capture must not allocate.  The new
+    // store is allocated BEFORE the old one is dropped; when that fails the old rows (and capacity) stay in service.
+    const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)want;
+    std::unique_ptr<RowStore> bigger;
+    try { bigger.reset(new RowStore(entries)); }
+    catch (const DeviceAllocError&) {
+        (void)hipGetLastError();
+        capAuto = false;                       // no further attempts: overflowing particles keep walking the cells
+        fprintf(stderr, "sphx: no memory for %d-entry neighbour rows; staying at %d entries per particle\n", want, cap);
+        return;
+    }
+    cap = want;
+    nbr = std::move(bigger);
     listValid = false;
     ++generation;
+    if (persistRows) requestRebuild();
+}
+
+// dst = src when *flag != 0 (persistent rows: the cell table of the build is kept beside the live one)
+__global__ void k_copy_int_if(int* __restrict__ dst, const int* __restrict__ src, int count, const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i];
 }
 
 void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
 {
     if (listValid || (flags & kFlagNoList) || n <= 0) return;
+    if (persistRows && skin > 0.0f) {
+        // Persistent rows: the same launches every step -- copy of the cell table, then the builder -- and every wave of them
+        // leaves at once unless the grid pass of this step raised persistFlags[0] (SPHSystem::persistentSearch: some particle
+        // moved more than 0.45 skin relative to the others since the build, or the host asked).  Graph-replayable.
+        const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
+        if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { persistRows = false; flags |= kFlagNoList; ++generation; return; }
+        if (!nbr || nbr->entries < entries) { nbr.reset(); nbr.reset(new RowStore(entries)); ++generation; requestRebuild(); }
+        if (!posBuild) { posBuild.reset(new DArray<float>(4u * (unsigned)capN)); rowCell.reset(new DArray<int>((unsigned)capN)); ++generation; requestRebuild(); }
+        if (!csBuild || csBuild->length() != csF.length()) { csBuild.reset(new DArray<int>(csF.length())); ++generation; requestRebuild(); }
+        ensureTileOrder();
+        listValid = false;                         // ctx() must hand out the LIVE cell tables to the builder
+        SweepCtx c = ctx(csF, csB);
+        c.nbr = nullptr; c.overflowMax = rowOverflow.addr(); c.persist = 0; c.rowCell = nullptr;
+        ScopedKernel t("build_neighbor_list");
+        k_copy_int_if<<<blocks_for((int)csF.length()), 256, 0, stream()>>>(csBuild->addr(), csF.addr(), (int)csF.length(), persistFlags.addr(0));
+        launchBuild(c, reinterpret_cast<float4*>(posBuild->addr()), persistFlags.addr(0), nullptr);
+        listCsF = csBuild->addr(); listCsB = csB.addr();
+        listIsBrick = false;
+        listValid = true;
+        return;
+    }
     // sized for the CAPACITY, not the current count: sphx_set_count may raise n up to capN later
     // (slab drivers do so every step) and the rows of all ceil(n/64) tiles must fit
     const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;

@@ -436,6 +436,25 @@ constexpr unsigned int kStreamSlotMask = 0x07ffffffu;
 //                       the 4 neighbours of a chunk are consecutive accepted candidates, i.e. (almost) adjacent
 //                       records, so the quad's gathers share cache lines (walk_row_quad).
 constexpr int kRowChunk = 4;
+// Row traffic: every entry is read once per sweep and the row storage of a 10 M scene is 1.3-2 GB, far beyond the 256 MB Infinity
+// Cache: streaming it with the non-temporal hint keeps the gathered records resident instead (-3 % per sweep at 10.3 M particles,
+// +14..19 % at 1 M where the rows themselves fit the cache: profiles/r04_ubench_tiles.txt).  A build-time switch of the library
+// (the kernels would otherwise need a second instantiation each); off by default.
+#ifndef SPHX_NT_ROWS
+#define SPHX_NT_ROWS 0
+#endif
+typedef unsigned int row_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned int row_load(const unsigned int* p) { return SPHX_NT_ROWS ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ uint4 row_load4(const unsigned int* p)
+{
+    if (SPHX_NT_ROWS) { const row_u4 v = __builtin_nontemporal_load(reinterpret_cast<const row_u4*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void row_store4(unsigned int* p, const uint4 v)
+{
+    if (SPHX_NT_ROWS) { row_u4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<row_u4*>(p)); }
+    else *reinterpret_cast<uint4*>(p) = v;
+}
 __device__ __forceinline__ size_t row_base_offset(int i, int cap) { return ((size_t)(i >> 6) * (size_t)cap) * 64u + (size_t)(i & 63) * kRowChunk; }
 __device__ __forceinline__ size_t row_entry_offset(int k) { return (size_t)(k >> 2) * 256u + (unsigned)(k & 3); }
 
@@ -469,6 +488,14 @@ struct SweepCtx {
                                             // 27 cells around the cell of the CURRENT position (PBDSolver.cu:139-141 on moved
                                             // positions), so a row is only valid while its particle stays in that cell
     float buildCut;                         // squared cutoff the row builder accepts candidates with
+    // Persistent rows (tolerance arithmetic, WCSPH / DFSPH; SPHSystem's persistent mode): the particle arrays keep the order of
+    // the last row build across steps (the API arrays are exported in the reference's order separately), rows were built with
+    // the skin, every pair re-tests its CURRENT distance.  A row stays valid while no particle has moved more than 0.45 skin
+    // RELATIVE to the others since the build (checked on the device at the start of every step), whatever cells the particles
+    // are in by now: the neighbour set of the reference is {r <= R}, and the order of a particle's sum is free under this
+    // contract.  Particles without a row (overflow) walk the cells around the cell their row was built around, in the cell
+    // table of the build (csF then points at that copy).
+    int persist;
     int quad;                               // QuadBits: sweeps that run quad-per-particle (walk_row_quad)
     int duo;                                // QuadBits: sweeps that run two lanes per particle (walk_row_duo); quad wins where both are set
     int numTiles;                           // tiles this launch covers
@@ -551,9 +578,29 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // direct walk in reference order; `visit(j, isBoundary, d, r2, mass_j)`
 template <bool WANT_BOUNDARY, class Visit>
+__device__ __forceinline__ void walk_cells_around(const SweepCtx& c, const int3 c0, const float3 pi, Visit&& visit);
+template <bool WANT_BOUNDARY, class Visit>
 __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, Visit&& visit)
 {
-    const int3 c0 = cell_of(pi, c.g);
+    walk_cells_around<WANT_BOUNDARY>(c, cell_of(pi, c.g), pi, visit);
+}
+// the fallback of a particle without a usable row: around the cell of its position, or (persistent rows) around the cell its row
+// was built around -- the arrays are still sorted by THOSE cells, and the skin is smaller than the slack of the cell length, so
+// every particle within R now was within the 27 cells then
+template <bool WANT_BOUNDARY, class Visit>
+__device__ __forceinline__ void walk_cells_fallback(const SweepCtx& c, const int i, const float3 pi, Visit&& visit)
+{
+    int3 c0;
+    if (c.persist) {
+        const int id = c.rowCell[i];
+        c0 = make_int3(id / (c.g.gz * c.g.gy), (id / c.g.gz) % c.g.gy, id % c.g.gz);
+        if (id >= c.g.C) c0.x = -4;          // built out of the grid (sentinel bucket): every cell of the walk is skipped
+    } else c0 = cell_of(pi, c.g);
+    walk_cells_around<WANT_BOUNDARY>(c, c0, pi, visit);     // ONE call site: the visit body is inlined once
+}
+template <bool WANT_BOUNDARY, class Visit>
+__device__ __forceinline__ void walk_cells_around(const SweepCtx& c, const int3 c0, const float3 pi, Visit&& visit)
+{
     for (int dx = -1; dx <= 1; ++dx) {
         const int X = c0.x + dx;
         if (X < 0 || X >= c.g.gx) continue;
@@ -649,7 +696,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
     for (; t + kAhead <= cnt; t += kAhead) {
         unsigned int e[kAhead];
         if constexpr (kAhead == kRowChunk) {      // t is a multiple of 4: one 16-byte load
-            const uint4 ch = *reinterpret_cast<const uint4*>(row + (size_t)(t >> 2) * 256u);
+            const uint4 ch = row_load4(row + (size_t)(t >> 2) * 256u);
             e[0] = ch.x; e[1] = ch.y; e[2] = ch.z; e[3] = ch.w;
         } else {
 #pragma unroll
@@ -707,12 +754,12 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                                       const int i, const bool valid, const float3 pi, Body& body)
 {
     const int lane = threadIdx.x & 63;
-    const bool skin = c.stale != nullptr;
-    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);    // stale skin rows: direct walks (launch-uniform)
+    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);    // stale skin rows: direct walks (launch-uniform)
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow) {                   // (normally never fails: the position update asks for a rebuild on a crossing)
+    if (skin && useRow && !c.persist) {     // (normally never fails: the position update asks for a rebuild on a crossing)
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -783,7 +830,7 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
         }
         return;
     }
-    walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+    walk_cells_fallback<WANT_BOUNDARY>(c, i, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
         body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
     });
 }
@@ -845,7 +892,7 @@ __device__ __forceinline__ void quad_chunks(const Op& op, const SweepCtx& c, con
         // unconditional load (chunks past this row's end hold stale entries), then: past the end -> record 0,
         // evaluated and dropped
         ok[u] = 4 * (s + u) + g < cnt;
-        const unsigned int raw = rowq[(size_t)(s + u) * 256u];
+        const unsigned int raw = row_load(rowq + (size_t)(s + u) * 256u);
         e[u] = ok[u] ? raw : 0u;
     }
     float4 pj[U];
@@ -939,12 +986,12 @@ __device__ __forceinline__ int quad_particle(const SweepCtx& c)
 template <bool WANT_BOUNDARY, class Op, class Body>
 __device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
 {
-    const bool skin = c.stale != nullptr;
-    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);
+    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow) {
+    if (skin && useRow && !c.persist) {
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -971,7 +1018,7 @@ __device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, cons
         }
     }
     if (valid && !useRow)      // no rows, or this particle's row overflowed / went stale: the 4 lanes walk the cells alike
-        walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+        walk_cells_fallback<WANT_BOUNDARY>(c, i, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
             body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
         });
 }
@@ -1078,12 +1125,12 @@ __device__ __forceinline__ int duo_particle(const SweepCtx& c)
 template <bool WANT_BOUNDARY, class Op, class Body>
 __device__ __forceinline__ void sweep_duo(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
 {
-    const bool skin = c.stale != nullptr;
-    const bool rows = c.nbr != nullptr && !(skin && *c.stale != 0);
+    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow) {
+    if (skin && useRow && !c.persist) {
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -1109,7 +1156,7 @@ __device__ __forceinline__ void sweep_duo(const Op& op, const SweepCtx& c, const
         }
     }
     if (valid && !useRow)      // both lanes walk the cells alike: the sums end up in lane 1 as well
-        walk_cells<WANT_BOUNDARY>(c, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
+        walk_cells_fallback<WANT_BOUNDARY>(c, i, pi, [&](int j, bool isB, float3 d, float r2, float mj) {
             body.template pair<false>(op.stage(isB, j + (isB ? c.bOff : 0)), isB, d, r2, mj, j);
         });
 }
@@ -1133,7 +1180,7 @@ __device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage
     if (SPHX_BUILD_REGSTAGE && !stage) {
         const int w = cnt & 3;
         pend.x = w == 0 ? e : pend.x; pend.y = w == 1 ? e : pend.y; pend.z = w == 2 ? e : pend.z; pend.w = w == 3 ? e : pend.w;
-        if (w == 3 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+        if (w == 3 && cnt < c.cap) row_store4(row + (size_t)(cnt >> 2) * 256u, pend);
         return;
     }
     if (stage && cnt < kRowStage) stage[cnt * 64 + lane] = e;
@@ -1236,7 +1283,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     }
     if (valid) nbrCount[i] = cnt;
     if (valid && cnt > c.cap && c.overflowMax) atomicMax(c.overflowMax, cnt);     // (rare: the host enlarges the rows, SweepCache::tuneRowCapacity)
-    if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
+    if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) row_store4(row + (size_t)(cnt >> 2) * 256u, pend);
     if (stage) {                                  // one coalesced 1 KB store per chunk index (slots past a row's end hold
         wave_lds_fence();                         // stale stage contents: readers never look past nbrCount)
         int top = valid ? min(min(cnt, c.cap), kRowStage) : 0;

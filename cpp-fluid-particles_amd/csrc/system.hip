@@ -40,6 +40,16 @@ void Particles::advect(float dt)
     k_advect_only<<<blocks_for(n), 256, 0, sphx::stream()>>>(pos.addr(), vel.addr(), dt, n);
 }
 
+Particles::Particles(Uninitialised u) : pos(u.count), vel(u.count), _active(u.count) {}
+
+SPHParticles::SPHParticles(Uninitialised u)
+    : Particles(u), pressure(u.count), density(u.count), mass(u.count), particle2Cell(u.count), sortPerm(u.count), ids(u.count)
+{
+    ew_iota(ids.addr(), (int)u.count);
+    ew_iota(sortPerm.addr(), (int)u.count);
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+}
+
 SPHParticles::SPHParticles(const std::vector<float3>& p)
     : Particles(p), pressure((unsigned)p.size()), density((unsigned)p.size()), mass((unsigned)p.size()),
       particle2Cell((unsigned)p.size()), sortPerm((unsigned)p.size()), ids((unsigned)p.size())
@@ -66,6 +76,17 @@ struct GridScratch {
     DArray<int> blockSums;  // scan scratch
     DArray<float> posm;     // packed boundary positions for the boundary-mass sweep
     DArray<int> outRank;    // stable rank of each out-of-grid particle inside the sentinel bucket
+};
+
+// SPHSystem's persistent mode (SPHSystem.h): the map from API slots (the reference's order) to the working arrays
+struct PersistState {
+    explicit PersistState(int capacity) : slotToWork((unsigned)capacity), tmpMap((unsigned)capacity), tmpMass((unsigned)capacity) {}
+    std::unique_ptr<DArray<int>> nearWall;   // per cell: 1 when one of the 27 cells around it holds boundary particles (static)
+    DArray<int> slotToWork;   // P: API slot s holds working particle P[s]
+    DArray<int> tmpMap;
+    DArray<float> tmpMass;
+    bool wanted = false;
+    bool primed = false;      // the working copy mirrors the API arrays through P
 };
 
 struct StepGraph {
@@ -434,6 +455,7 @@ long long SPHSystem::errorTotalFixed()
 
 void SPHSystem::phase(int p)
 {
+    if (_persist && _persist->wanted) throw "SPHSystem::phase: stage-wise stepping is not available with persistent rows";
     if (p == SPHX_PH_W_SURFACE_PRESSURE) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
@@ -448,7 +470,7 @@ void SPHSystem::phase(int p)
         if (p == SPHX_PH_P_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
         pbd->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                       _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.gravity, _sc.surfaceTension, _sc.airPressure);
-        if (p == SPHX_PH_P_TAIL) _graph->stepsRun++;
+        if (p == SPHX_PH_P_TAIL) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }
         return;
     }
     if ((p >= SPHX_PH_W_SEARCH && p <= SPHX_PH_W_PRESSURE) || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
@@ -458,7 +480,7 @@ void SPHSystem::phase(int p)
         w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                          _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
                          _sc.surfaceTension, _sc.airPressure);
-        if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
+        if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }
         return;
     }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
@@ -467,7 +489,7 @@ void SPHSystem::phase(int p)
     dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                     _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
                     _sc.airPressure, false);
-    if (p == SPHX_PH_ADVECT) _graph->stepsRun++;
+    if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }      // (whole-domain systems stepped stage by stage: ADVICE r03)
 }
 
 // the constructor sequence of SPHSystem.cu:68-76
@@ -558,8 +580,257 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
     }
 }
 
+// ================================================================================ persistent mode
+// flags: [0] rebuild in this step, [1] forced by the host (consumed here), [2] rebuilds so far, [3] steps so far
+__global__ void k_persist_begin(int* __restrict__ flags)
+{
+    flags[0] = flags[1] != 0 ? 1 : 0;
+    flags[1] = 0;
+    flags[3] += 1;
+}
+__global__ void k_persist_count(int* __restrict__ flags) { if (flags[0] != 0) flags[2] += 1; }
+
+// k_cell_and_count for the API slots of the previous step: slot s holds working particle P[s].  Also the displacement check of
+// the rows: d = (position now - position at the build) - the same difference of ONE reference particle (any common vector
+// works: a pair's separation changes by d_i - d_j, which is bounded by twice the largest |d - c|; with the reference particle's
+// own displacement as c a block of fluid in free fall has d - c = 0 to rounding).
+// Boundary particles do not move, so against THEM a fluid particle's displacement counts in full (no common drift to take out):
+// a particle that is within reach of the boundary now -- one of the 27 cells around its cell holds boundary particles, nearWall --
+// asks for a rebuild once it has moved 0.9 skin in absolute terms.
+__global__ void k_near_wall(int* __restrict__ nearWall, const int* __restrict__ csB, GridDesc g)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > g.C) return;
+    int any = 0;
+    if (c < g.C) {
+        const int z = c % g.gz, y = (c / g.gz) % g.gy, x = c / (g.gz * g.gy);
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) {
+            const int X = x + dx, Y = y + dy;
+            if (X < 0 || X >= g.gx || Y < 0 || Y >= g.gy) continue;
+            const int base = (X * g.gy + Y) * g.gz, zlo = max(z - 1, 0), zhi = min(z + 1, g.gz - 1);
+            any |= csB[base + zhi + 1] > csB[base + zlo] ? 1 : 0;
+        }
+    }
+    nearWall[c] = any;      // (slot C, the out-of-grid bucket: 0)
+}
+__global__ void __launch_bounds__(256) k_persist_cells(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts,
+                                                       const int* __restrict__ P, const float3* __restrict__ wpos,
+                                                       const float4* __restrict__ posBuild, const int* __restrict__ nearWall,
+                                                       GridDesc g, int n, int ref, float limit2, float wallLimit2,
+                                                       int* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    int id = -1;
+    if (valid) {
+        const int p = P[i];
+        const float3 x = wpos[p];
+        const int3 c = cell_of(x, g);
+        id = cell_id(c.x, c.y, c.z, g);
+        p2c[i] = id;
+        const float4 b = posBuild[p], br = posBuild[ref];
+        const float3 xr = wpos[ref];
+        const float3 da = sub3(x, v3(b.x, b.y, b.z));
+        const float3 d = sub3(da, sub3(xr, v3(br.x, br.y, br.z)));
+        if (!(dot3(d, d) <= limit2) || (nearWall[id] != 0 && !(dot3(da, da) <= wallLimit2))) flags[0] = 1;
+    }
+    const int prev = __shfl_up(id, 1, 64);
+    const bool head = valid && (lane == 0 || prev != id);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long live = __ballot(valid);
+    if (!valid) return;
+    const unsigned long long below = heads & (~0ull >> (63 - lane));
+    const int first = 63 - __builtin_clzll(below);
+    const unsigned long long above = heads & ~(~0ull >> (63 - lane));
+    const int end = above ? __builtin_ctzll(above) : (64 - __builtin_clzll(live));
+    int base = 0;
+    if (head) base = atomicAdd(&counts[id], end - first);
+    base = __shfl(base, first, 64);
+    slot[i] = base + (lane - first);
+}
+__global__ void k_persist_compose(int* __restrict__ dst, const int* __restrict__ P, const int* __restrict__ perm, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) dst[s] = P[perm[s]];
+}
+__global__ void k_copy_int(int* __restrict__ dst, const int* __restrict__ src, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) dst[s] = src[s];
+}
+// the re-sort of the working arrays into the API order of this step, only when the rows are being rebuilt
+__global__ void k_persist_resort_gather(float3* __restrict__ tp, float3* __restrict__ tv, int* __restrict__ ti, float* __restrict__ tm,
+                                        const float3* __restrict__ pos, const float3* __restrict__ vel, const int* __restrict__ id,
+                                        const float* __restrict__ mass, const int* __restrict__ P, int n, const int* __restrict__ flags)
+{
+    if (flags[0] == 0) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int p = P[s];
+    tp[s] = pos[p]; tv[s] = vel[p]; ti[s] = id[p]; tm[s] = mass[p];
+}
+__global__ void k_persist_resort_back(float3* __restrict__ pos, float3* __restrict__ vel, int* __restrict__ id, float* __restrict__ mass,
+                                      int* __restrict__ workPerm, int* __restrict__ P, const float3* __restrict__ tp,
+                                      const float3* __restrict__ tv, const int* __restrict__ ti, const float* __restrict__ tm, int n,
+                                      const int* __restrict__ flags)
+{
+    if (flags[0] == 0) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    pos[s] = tp[s]; vel[s] = tv[s]; id[s] = ti[s]; mass[s] = tm[s];
+    workPerm[s] = P[s];        // the permutation the solver's own persistent arrays follow (getSortPerm() of the working set)
+    P[s] = s;
+}
+__global__ void k_persist_export(float3* __restrict__ apos, float3* __restrict__ avel, float* __restrict__ aden, float* __restrict__ apre,
+                                 float* __restrict__ amass, int* __restrict__ aid, const float3* __restrict__ wpos,
+                                 const float3* __restrict__ wvel, const float* __restrict__ wden, const float* __restrict__ wpre,
+                                 const float* __restrict__ wmass, const int* __restrict__ wid, const int* __restrict__ P, int n)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int p = P[s];
+    apos[s] = wpos[p]; avel[s] = wvel[p]; aden[s] = wden[p]; apre[s] = wpre[p]; amass[s] = wmass[p]; aid[s] = wid[p];
+}
+
+bool SPHSystem::setPersistentRows(bool on)
+{
+    auto* basic = dynamic_cast<BasicSPHSolver*>(_solver.get());
+    if (!basic || dynamic_cast<PBDSolver*>(_solver.get()) || _slab) return !on;
+    if (!_persist) {
+        if (!on) return true;
+        _persist.reset(new PersistState((int)_fluids->capacity()));
+        _work = std::make_shared<SPHParticles>(Particles::Uninitialised{_fluids->capacity()});
+    }
+    if (_persist->wanted == on) return true;
+    invalidatePersistentOrder();
+    _persist->wanted = on;
+    basic->requestPersistentRows(on);
+    _graph->drop();
+    return true;
+}
+
+bool SPHSystem::persistentRows() const { return _persist && _persist->wanted; }
+
+bool SPHSystem::persistentActive()
+{
+    if (!_persist || !_persist->wanted) return false;
+    auto* basic = static_cast<BasicSPHSolver*>(_solver.get());
+    return basic->preparePersistent(_sc.cells, _sc.cellLength, _sc.radius).active;
+}
+
+void SPHSystem::invalidatePersistentOrder()
+{
+    if (!_persist || !_persist->primed) return;
+    // the API arrays are current (exported by every step); the solver's own arrays are in the working order: bring them along
+    static_cast<BasicSPHSolver*>(_solver.get())->permuteState(_persist->slotToWork.addr(), (int)_fluids->size());
+    _persist->primed = false;
+    _graph->drop();
+}
+
+void SPHSystem::persistentPrime()
+{
+    const int n = (int)_fluids->size();
+    _work->setActiveCount((unsigned)n);
+    ew_copy(_work->getPosPtr(), _fluids->getPosPtr(), sizeof(float3) * (size_t)n);
+    ew_copy(_work->getVelPtr(), _fluids->getVelPtr(), sizeof(float3) * (size_t)n);
+    ew_copy(_work->getMassPtr(), _fluids->getMassPtr(), sizeof(float) * (size_t)_fluids->capacity());
+    ew_copy(_work->getDensityPtr(), _fluids->getDensityPtr(), sizeof(float) * (size_t)n);
+    ew_copy(_work->getPressurePtr(), _fluids->getPressurePtr(), sizeof(float) * (size_t)n);
+    ew_copy(_work->getIdPtr(), _fluids->getIdPtr(), sizeof(int) * (size_t)n);
+    ew_iota(_persist->slotToWork.addr(), n);
+    static_cast<BasicSPHSolver*>(_solver.get())->requestRowRebuild();
+    _persist->primed = true;
+}
+
+// The grid pass of a persistent step.  What SPHSystem::neighborSearch does for the API order -- keys, histogram, scan, stable
+// ranks -- runs on the API slots of the previous step with the positions read through the slot map, so that particle2Cell,
+// getSortPerm(), the cell table and (after the export) every API array are what the reference's stable sort gives; the payload
+// of the sort is the slot map alone.  The working arrays move only when the rows are rebuilt.
+void SPHSystem::persistentSearch()
+{
+    auto* basic = static_cast<BasicSPHSolver*>(_solver.get());
+    const BasicSPHSolver::PersistentView pv = basic->preparePersistent(_sc.cells, _sc.cellLength, _sc.radius);
+    const int num = (int)_fluids->size();
+    const int cellsPlusOne = _sc.cells.x * _sc.cells.y * _sc.cells.z + 1;
+    const GridDesc g = make_grid_desc(_sc.cells, _sc.cellLength, _cellOffsetX);
+    hipStream_t st = sphx::stream();
+    int* p2c = _fluids->getParticle2Cell();
+    int* perm = _fluids->getSortPerm();
+    int* P = _persist->slotToWork.addr();
+    DArray<int>& cellStart = _fluidCellStart;
+    _work->setActiveCount((unsigned)num);
+    if (!_persist->nearWall) {          // (boundary particles are static: once)
+        _persist->nearWall.reset(new DArray<int>((unsigned)cellsPlusOne));
+        k_near_wall<<<blocks_for(cellsPlusOne), 256, 0, st>>>(_persist->nearWall->addr(), _wallCellStart.addr(), g);
+    }
+    k_persist_begin<<<1, 1, 0, st>>>(pv.flags);
+    HIP_CALL(hipMemsetAsync(cellStart.addr(), 0, sizeof(int) * cellsPlusOne, st));
+    if (num > 0) {
+        ScopedKernel t("grid_cell_count");
+        k_persist_cells<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), P, _work->getPosPtr(),
+                                                         static_cast<const float4*>(pv.posBuild), _persist->nearWall->addr(), g, num, num / 2,
+                                                         pv.limit2, 4.0f * pv.limit2, pv.flags);      // 4 x (0.45 skin)^2 = (0.9 skin)^2
+    }
+    {
+        ScopedKernel t("grid_scan");
+        device_exclusive_scan(cellStart.addr(), cellsPlusOne, _grid->blockSums.addr());
+    }
+    if (num <= 0) return;
+    {
+        ScopedKernel t("grid_stable_rank");
+        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
+        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
+        {
+            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
+            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            if (tiles > 1) {
+                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
+                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            }
+        }
+        k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
+        k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(), num, cellsPlusOne);
+    }
+    {
+        ScopedKernel t("grid_gather");
+        k_persist_compose<<<blocks_for(num), 256, 0, st>>>(_persist->tmpMap.addr(), P, perm, num);
+        k_copy_int<<<blocks_for(num), 256, 0, st>>>(P, _persist->tmpMap.addr(), num);
+        // rows to be rebuilt: the working arrays take the API order of this step (the order the builder's cell walk needs)
+        float3* tv = reinterpret_cast<float3*>(_grid->posm.addr());
+        k_persist_count<<<1, 1, 0, st>>>(pv.flags);
+        k_persist_resort_gather<<<blocks_for(num), 256, 0, st>>>(_grid->tmp3.addr(), tv, _grid->tmpi.addr(), _persist->tmpMass.addr(), _work->getPosPtr(),
+                                                                 _work->getVelPtr(), _work->getIdPtr(), _work->getMassPtr(), P, num, pv.flags);
+        k_persist_resort_back<<<blocks_for(num), 256, 0, st>>>(_work->getPosPtr(), _work->getVelPtr(), _work->getIdPtr(), _work->getMassPtr(),
+                                                               _work->getSortPerm(), P, _grid->tmp3.addr(), tv, _grid->tmpi.addr(),
+                                                               _persist->tmpMass.addr(), num, pv.flags);
+    }
+}
+
+void SPHSystem::persistentExport()
+{
+    const int num = (int)_fluids->size();
+    if (num <= 0) return;
+    ScopedKernel t("export_api_order");
+    k_persist_export<<<blocks_for(num), 256, 0, sphx::stream()>>>(_fluids->getPosPtr(), _fluids->getVelPtr(), _fluids->getDensityPtr(),
+                                                                  _fluids->getPressurePtr(), _fluids->getMassPtr(), _fluids->getIdPtr(),
+                                                                  _work->getPosPtr(), _work->getVelPtr(), _work->getDensityPtr(),
+                                                                  _work->getPressurePtr(), _work->getMassPtr(), _work->getIdPtr(),
+                                                                  _persist->slotToWork.addr(), num);
+}
+
 void SPHSystem::enqueueStep()
 {
+    if (persistentActive()) {
+        if (!_persist->primed) persistentPrime();
+        persistentSearch();
+        _solver->step(_work, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
+                      _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
+                      _sc.surfaceTension, _sc.airPressure);
+        persistentExport();
+        return;
+    }
+    if (_persist && _persist->primed) invalidatePersistentOrder();      // (the mode became unusable: back to the ordinary step)
     neighborSearch(_fluids, _fluidCellStart);
     _solver->step(_fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                   _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
@@ -604,7 +875,9 @@ float SPHSystem::stepN(int n)
     float extra = 0.0f;
     // a capture must not contain allocations: the engine's lazily created buffers (neighbour rows, tile
     // buckets) appear during the first step that runs the solver's full schedule, so that one is eager
-    while (n > 0 && (_graph->stepsRun == 0 || (_solver->graphSafe() && _graph->warmSteps == 0))) { extra += step(); --n; }
+    // ... and so is the step that primes the working copy of the persistent mode (host-side copies outside the captured schedule)
+    while (n > 0 && (_graph->stepsRun == 0 || (_solver->graphSafe() && _graph->warmSteps == 0) ||
+                     (_persist && _persist->wanted && !_persist->primed))) { extra += step(); --n; }
     if (n == 0) return extra;
     const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
     auto ensureGraph = [&] {

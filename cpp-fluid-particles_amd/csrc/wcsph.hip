@@ -44,6 +44,34 @@ void BasicSPHSolver::setSweepRange(int lo, int hi, bool keepErrorAccum, int lo2,
     _cache->rangeLo = lo; _cache->rangeHi = hi; _cache->keepErrorAccum = keepErrorAccum;
     _cache->rangeLo2 = lo >= 0 ? lo2 : -1; _cache->rangeHi2 = lo >= 0 ? hi2 : -1;
 }
+void BasicSPHSolver::requestPersistentRows(bool on)
+{
+    if (_cache->persistWanted == on) return;
+    _cache->persistWanted = on;
+    if (!on && _cache->persistRows) { _cache->persistRows = false; _cache->skin = 0.0f; _cache->listValid = false; }
+    ++_cache->generation;
+}
+BasicSPHSolver::PersistentView BasicSPHSolver::preparePersistent(int3 cellSize, float cellLength, float radius)
+{
+    SweepCache& c = *_cache;
+    c.setup(cellSize, cellLength, radius);
+    if (c.persistRows && !c.posBuild) {      // the grid pass measures against the build positions from its first launch on
+        c.posBuild.reset(new DArray<float>(4u * (unsigned)c.capN));
+        c.rowCell.reset(new DArray<int>((unsigned)c.capN));
+        ++c.generation;
+        c.requestRebuild();
+    }
+    return PersistentView{c.persistRows, c.persistFlags.addr(), c.persistRows ? (const void*)c.posBuild->addr() : nullptr, c.staleLimit2()};
+}
+const int* BasicSPHSolver::enginePersistFlags() const { return _cache->persistRows ? _cache->persistFlags.addr() : nullptr; }
+void BasicSPHSolver::requestRowRebuild() { if (_cache->persistRows) _cache->requestRebuild(); }
+void BasicSPHSolver::permuteState(const int* perm, int n)
+{
+    if (n <= 0) return;
+    SweepCache& c = *_cache;
+    ew_gather_float3(c.aux3.addr(), bufferFloat3.addr(), perm, n);          // (aux3 is per-step scratch)
+    ew_copy(bufferFloat3.addr(), c.aux3.addr(), sizeof(float3) * (size_t)n);
+}
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX)
 {
     _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true;

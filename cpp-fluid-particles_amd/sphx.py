@@ -33,7 +33,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
-    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
+    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -211,6 +211,13 @@ class System:
         lib().sphx_rows_stale.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _check(lib().sphx_rows_stale(self._h, C.byref(v)))
         return v.value
+
+    def persistent_stats(self):
+        """(in use, row builds, steps) of the persistent-rows mode (reserved[3] = 2)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        lib().sphx_persistent_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _check(lib().sphx_persistent_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return bool(a.value), b.value, c.value
 
     def device_ptr(self, field):
         p = C.c_void_p()

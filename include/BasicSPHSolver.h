@@ -40,6 +40,17 @@ public:
     // arithmetic of the neighbour sweeps: strict (default; every bit equals the IEEE evaluation of the reference's
     // expressions) or tolerance (hardware rsq / rcp and fused multiply-adds: deviations of a few 1e-7 per pair term)
     void setToleranceArithmetic(bool on);
+    // Persistent neighbour rows (tolerance arithmetic only; driven by SPHSystem::setPersistentRows): the rows carry a skin and
+    // survive from step to step until a device-side displacement check asks for a rebuild; the solver then steps particle
+    // arrays that stay in the order of the last build.  preparePersistent() decides whether the mode can be used for this
+    // grid (it needs cellLength > radius: the skin lives in that slack) and returns what SPHSystem's grid pass needs.
+    struct PersistentView { bool active; int* flags; const void* posBuild; float limit2; };
+    void requestPersistentRows(bool on);
+    PersistentView preparePersistent(int3 cellSize, float cellLength, float radius);
+    void requestRowRebuild();
+    const int* enginePersistFlags() const;  // device words {rebuild now, forced, row builds so far, steps so far}; nullptr when not in use
+    // bring the solver's own per-particle arrays from the persistent order into the order slot -> perm[slot]
+    virtual void permuteState(const int* perm, int n);
     // slab decompositions: global x index of this solver's local cell column 0
     void setCellOffsetX(int cellOffsetX);
     // raw device pointers of the float4 mirrors the sweeps gather from (halo exchange targets)

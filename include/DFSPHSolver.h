@@ -49,6 +49,7 @@ public:
     const DArray<float>& getStiffness() const { return bufferFloat; }
     const DArray<float>& getError() const { return error; }
     DArray<float>& getWarmStiffness() { return denWarmStiff; }
+    void permuteState(const int* perm, int n) override;
 
 protected:
     // hides BasicSPHSolver::project (different signature), as in the reference

@@ -11,6 +11,8 @@
 class Particles {
 public:
     explicit Particles(const std::vector<float3>& p);
+    struct Uninitialised { unsigned int count; };       // engine extension: `count` zero-filled slots, no upload
+    explicit Particles(Uninitialised u);
 
     Particles(const Particles&) = delete;
     Particles& operator=(const Particles&) = delete;

@@ -12,6 +12,7 @@
 class SPHParticles final : public Particles {
 public:
     explicit SPHParticles(const std::vector<float3>& p);
+    explicit SPHParticles(Uninitialised u);             // engine extension (SPHSystem's persistent-order working set)
 
     SPHParticles(const SPHParticles&) = delete;
     SPHParticles& operator=(const SPHParticles&) = delete;

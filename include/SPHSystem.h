@@ -13,7 +13,7 @@
 #include <memory>
 #include "BaseSolver.h"
 
-namespace sphx { struct GridScratch; struct StepGraph; }
+namespace sphx { struct GridScratch; struct StepGraph; struct PersistState; }
 
 class SPHSystem {
 public:
@@ -76,6 +76,19 @@ public:
     // called inside a SEARCH stage right after the sort, before packing and row construction are enqueued: a slab driver reads
     // its layer boundaries from the fresh cell table there, so that the read-back overlaps the row build
     void setAfterSortHook(std::function<void()> hook) { _afterSort = std::move(hook); }
+    // Persistent neighbour rows (opt-in; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems; C ABI: reserved[3] = 2).
+    // The solver steps a working copy of the fluid arrays that stays in the order of the last row build, the rows carry a skin
+    // and are rebuilt only when a device-side check finds that some particle has moved more than 0.45 skin relative to the
+    // others; getFluids()' arrays, particle2Cell, getSortPerm() and the cell table are brought up to date in the reference's
+    // order (stable sort by the cells of the step's starting positions) at the end of every step() as always.  Results meet the
+    // tolerance contract, not the strict one (the order of a particle's sums follows the rows).  A caller that WRITES the fluid
+    // arrays through raw pointers between steps must call invalidatePersistentOrder() afterwards; the C ABI's setters do.
+    // Returns false when the mode cannot be used (solver without the engine's rows, PBD, slab systems, cellLength <= radius).
+    bool setPersistentRows(bool on);
+    bool persistentRows() const;
+    // make every per-particle array of the solver follow the API order again (host-side readers of solver-internal fields,
+    // snapshots, setters); the next step() re-primes the working copy from the API arrays and rebuilds the rows
+    void invalidatePersistentOrder();
     const DArray<int>& getCellStartFluid() const { return _fluidCellStart; }
     const DArray<int>& getCellStartBoundary() const { return _wallCellStart; }
     BaseSolver* getSolver() const { return _solver.get(); }
@@ -85,6 +98,12 @@ private:
     void computeBoundaryMass();
     void neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart);
     void enqueueStep();   // neighbour search + solver step, no sync
+    bool persistentActive();          // the mode is on AND usable for this solver and grid
+    void persistentPrime();           // working copy := API arrays, identity map, rows to be rebuilt
+    void persistentSearch();          // cells of the API slots, displacement check, stable sort of the slot map, conditional re-sort
+    void persistentExport();          // API arrays := working copy through the slot map
+    std::shared_ptr<SPHParticles> _work;                 // persistent mode: the arrays the solver steps (order of the last row build)
+    std::unique_ptr<sphx::PersistState> _persist;
 
     // who: the two particle sets and the solver plugin (owned; moved in by the constructor)
     std::shared_ptr<SPHParticles> _fluids;

@@ -28,7 +28,7 @@ typedef enum sphx_status {
     SPHX_ERR_STATE = -4        /* call not valid in the current state */
 } sphx_status;
 
-enum { SPHX_ARITH_STRICT = 0, SPHX_ARITH_TOLERANCE = 1 };
+enum { SPHX_ARITH_STRICT = 0, SPHX_ARITH_TOLERANCE = 1, SPHX_ARITH_TOLERANCE_PERSISTENT = 2 };
 /* solver kinds: the three BaseSolver implementations selected in main.cpp:119-130 */
 enum { SPHX_WCSPH = 0, SPHX_DFSPH = 1, SPHX_PBD = 2 };
 
@@ -69,7 +69,13 @@ typedef struct sphx_params {
                                   reserved[3]: arithmetic of the neighbour sweeps, SPHX_ARITH_STRICT (0, default:
                                   every bit equals the IEEE evaluation of the reference's expressions) or
                                   SPHX_ARITH_TOLERANCE (1: hardware rsq/rcp + fused multiply-adds, ~1e-7 per pair term;
-                                  the reference's own binary is built -use_fast_math, src/CMakeLists.txt:43) */
+                                  the reference's own binary is built -use_fast_math, src/CMakeLists.txt:43) or
+                                  SPHX_ARITH_TOLERANCE_PERSISTENT (2: the same arithmetic, and the neighbour rows of WCSPH /
+                                  DFSPH carry a skin and survive from step to step until a device-side check finds that
+                                  some particle has moved more than 0.45 skin relative to the others; the API arrays, cell
+                                  indices and the cell table are still brought up to date in the reference's order by
+                                  every step -- SPHSystem::setPersistentRows in SPHSystem.h; needs cell_length > radius,
+                                  whole-domain systems only; PBD runs as 1) */
 } sphx_params;
 
 /* device-resident fields readable through sphx_get (host copy) / sphx_device_ptr (raw pointer) */
@@ -200,6 +206,9 @@ int  sphx_row_capacity(const sphx_system *sys, int *capacity);
 /* PBD diagnostics: how many times since creation the once-per-step neighbour rows had to be rebuilt inside a step because
  * a particle moved farther than their skin allows (decided and done on the device; always 0 for other solvers)      */
 int  sphx_rows_stale(const sphx_system *sys, int *rebuilds);
+/* persistent rows (reserved[3] = 2): 1/0 whether the mode is in use for this system, row builds and steps since creation
+ * (both 0 when it is not in use: every step builds its rows then)                                                      */
+int  sphx_persistent_stats(const sphx_system *sys, int *in_use, int *row_builds, int *steps);
 /* iteration counts of the last DFSPH step (the values DFSPHSolver.cu:49,65 compute and drop) */
 int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iters);
 
