@@ -21,10 +21,62 @@ DFSPHSolver::DFSPHSolver(int num, float defaultDensityErrorThreshold, float defa
     : BasicSPHSolver(num), alpha((unsigned)num), bufferFloat((unsigned)num), error((unsigned)num),
       denWarmStiff((unsigned)num), scratch((unsigned)num), errorAccum(2u * kErrorSlots * kErrorSlotStride),
       densityErrorThreshold(defaultDensityErrorThreshold), divergenceErrorThreshold(defaultDivergenceErrorThreshold),
-      maxIter(defaultMaxIter)
+      maxIter(defaultMaxIter), loopState(4u)
 {
+    HIP_CALL(hipHostMalloc((void**)&hostIters, 2 * sizeof(int), hipHostMallocDefault));
+    if (hostIters) hostIters[0] = hostIters[1] = 0;
 }
-DFSPHSolver::~DFSPHSolver() noexcept {}
+DFSPHSolver::~DFSPHSolver() noexcept { if (hostIters) (void)hipHostFree(hostIters); }
+
+// ---- adaptive loops decided on the device ------------------------------------------------------------------------------
+// The reference's two solver loops (DFSPHSolver.cu:160-210, :331-363) test a reduced |error| total on the host after every
+// iteration.  Here the total is an exact integer in device memory (D2): a one-block kernel after every error sweep adds the
+// partial sums up, counts the iteration and raises `done` by the reference's own rule; the sweeps of all maxIter possible
+// iterations are enqueued up front and leave at their first instruction once `done` is up (SweepCtx::gate).  No host round
+// trip, same iteration counts, and the whole adaptive step can be captured into a hipGraph.
+namespace {
+enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3 };
+__global__ void __launch_bounds__(kErrorSlots) k_loop_reset(int* __restrict__ st, unsigned long long* __restrict__ accum)
+{
+    accum[(size_t)threadIdx.x * kErrorSlotStride] = 0ull;
+    if (threadIdx.x == 0) { st[kLoopDone] = 0; st[kLoopIter] = 0; }
+}
+__global__ void __launch_bounds__(kErrorSlots) k_loop_decide(int* __restrict__ st, unsigned long long* __restrict__ accum, float threshold,
+                                                             int minIter, int maxIter, int which)
+{
+    if (st[kLoopDone] != 0) return;
+    __shared__ unsigned long long part[kErrorSlots / 64];
+    unsigned long long v = accum[(size_t)threadIdx.x * kErrorSlotStride];
+    accum[(size_t)threadIdx.x * kErrorSlotStride] = 0ull;          // ready for the next error sweep
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long total = 0;
+    for (int w = 0; w < kErrorSlots / 64; ++w) total += part[w];
+    const float totalError = (float)((double)(long long)total * (1.0 / 4294967296.0));      // DFSPHSolver::readErrorTotal
+    const int iter = st[kLoopIter] + 1;
+    st[kLoopIter] = iter;
+    st[which] = iter;
+    if (!((iter < minIter || totalError > threshold) && iter < maxIter)) st[kLoopDone] = 1;
+}
+}  // namespace
+
+bool DFSPHSolver::deviceLoops() const
+{
+    static const bool hostLoop = getenv("SPHX_DFSPH_HOST_LOOP") != nullptr;
+    const SweepCache& c = const_cast<DFSPHSolver*>(this)->cache();
+    return fixedDiv < 0 && fixedDen < 0 && !hostLoop && !c.isSlab && c.fused() && !c.brickWanted && maxIter >= 1;
+}
+bool DFSPHSolver::graphSafe() const { return (fixedDiv >= 0 && fixedDen >= 0) || deviceLoops(); }
+void DFSPHSolver::fetchIterations()
+{
+    if (!itersPending) return;
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    lastDiv = hostIters[0]; lastDen = hostIters[1];
+    itersPending = false;
+}
 
 long long DFSPHSolver::readErrorTotalFixed()
 {
@@ -211,9 +263,25 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         runPhase(ph, fluids, boundaries, cellStartFluid, cellStartBoundary, spaceSize, cellSize, cellLength, radius, dt, rho0,
                  rhoB, visc, G, surfaceTensionIntensity, airPressure, reduce);
     };
+    const bool onDevice = deviceLoops();
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
+    // `iterations` possible iterations of one loop, all enqueued: body(k) launches the sweeps of iteration k
+    auto deviceLoop = [&](float threshold, int minIter, int which, auto&& body) {
+        k_loop_reset<<<1, kErrorSlots, 0, sphx::stream()>>>(loopState.addr(), accum);
+        c.gate = loopState.addr(kLoopDone);
+        c.keepErrorAccum = true;                       // the decision kernel leaves the accumulators zeroed
+        for (int k = 0; k < maxIter; ++k) {
+            body(k);
+            k_loop_decide<<<1, kErrorSlots, 0, sphx::stream()>>>(loopState.addr(), accum, threshold, minIter, maxIter, which);
+        }
+        c.gate = nullptr;
+        c.keepErrorAccum = false;
+    };
     run(SPHX_PH_SEARCH);
     run(SPHX_PH_HEAD);
-    {
+    if (onDevice) {
+        deviceLoop(divergenceErrorThreshold * num * rho0, 1, kLoopDiv, [&](int) { run(SPHX_PH_DIV_CORRECT); run(SPHX_PH_DIV_ERROR, true); });
+    } else {
         const bool adaptive = fixedDiv < 0;
         auto totalError = std::numeric_limits<float>::max();
         int iter = 0;
@@ -234,7 +302,9 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         run(SPHX_PH_WARM_CORRECT);
     }
     run(SPHX_PH_DEN_ERROR_SET);
-    {
+    if (onDevice) {
+        deviceLoop(densityErrorThreshold * num * rho0, 2, kLoopDen, [&](int k) { run(SPHX_PH_DEN_CORRECT); run(SPHX_PH_DEN_ERROR_ACC, k + 1 >= 2); });
+    } else {
         const bool adaptive = fixedDen < 0;
         auto totalError = std::numeric_limits<float>::max();
         int iter = 0;
@@ -248,6 +318,10 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         lastDen = iter;
     }
     run(SPHX_PH_ADVECT);
+    if (onDevice) {          // the counts of this step: device words -> pinned host memory, read on demand (fetchIterations)
+        HIP_CALL(hipMemcpyAsync(hostIters, loopState.addr(kLoopDiv), 2 * sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));
+        itersPending = true;
+    }
 }
 
 // One stage of the fused schedule.  Reference stages: DFSPHSolver.cu:33-72 (order), :160-210 and

@@ -625,6 +625,7 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.rowCell = (skinNow && rowCell) ? rowCell->addr() : nullptr;
     c.buildCut = k.tCut;
     if ((skinRows || persistRows) && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
+    c.gate = gate;
     c.persist = (persistRows && skin > 0.0f && use && rowCell) ? 1 : 0;
     if (c.persist) { c.rowCell = rowCell->addr(); c.tileFmt = nullptr; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;

@@ -496,6 +496,9 @@ struct SweepCtx {
     // contract.  Particles without a row (overflow) walk the cells around the cell their row was built around, in the cell
     // table of the build (csF then points at that copy).
     int persist;
+    // Adaptive solver loops without a host round trip per iteration (DFSPH): the launches of every possible iteration are enqueued
+    // at once; once the device-side test of the |error| total has raised *gate the remaining ones leave at their first instruction.
+    const int* gate;
     int quad;                               // QuadBits: sweeps that run quad-per-particle (walk_row_quad)
     int duo;                                // QuadBits: sweeps that run two lanes per particle (walk_row_duo); quad wins where both are set
     int numTiles;                           // tiles this launch covers
@@ -524,6 +527,7 @@ __device__ __forceinline__ bool tile_outside(const SweepCtx& c, int tile)
 }
 __device__ __forceinline__ int wave_tile(const SweepCtx& c)
 {
+    if (c.gate && *c.gate != 0) return -1;
     const int lt = logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6);
     if (lt >= c.numTiles) return -1;
     if (!c.tileOrder) return lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
@@ -975,6 +979,7 @@ __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, c
 // particles [16 w, 16 w + 16) of the tile.  -1: the block is past the end.
 __device__ __forceinline__ int quad_particle(const SweepCtx& c)
 {
+    if (c.gate && *c.gate != 0) return -1;
     const int lt = logical_block();
     if (lt >= c.numTiles) return -1;
     const int tile = c.tileOrder ? c.tileOrder[lt] : lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
@@ -1115,6 +1120,7 @@ __device__ __forceinline__ void walk_row_duo(const Op& op, const SweepCtx& c, co
 // [32 (w & 1), +32) of tile 2 b + (w >> 1).  -1: the wave is past the end.
 __device__ __forceinline__ int duo_particle(const SweepCtx& c)
 {
+    if (c.gate && *c.gate != 0) return -1;
     const int lt = logical_block() * 2 + (int)(threadIdx.x >> 7);
     if (lt >= c.numTiles) return -1;
     const int tile = c.tileOrder ? c.tileOrder[lt] : lt + (lt < c.tileSplit ? c.tile0 : c.tile1);

@@ -29,7 +29,9 @@ public:
         fixedDiv = divergenceIters;
         fixedDen = densityIters;
     }
-    bool graphSafe() const override { return fixedDiv >= 0 && fixedDen >= 0; }
+    // Fixed iteration counts: no host decision inside the step.  Adaptive control (the reference's default) is graph-safe too
+    // when the termination test runs on the device (whole-domain systems; SPHX_DFSPH_HOST_LOOP=1 restores the host loop)
+    bool graphSafe() const override;
     // one stage of the fused schedule (values of sphx_phase in sphx_c.h, except SEARCH which here
     // means "prepare": pack, neighbour rows, carry the warm stiffness through the sort).
     // `reduce` accumulates the |error| total of the error stages for readErrorTotal().
@@ -38,13 +40,13 @@ public:
                   const DArray<int>& cellStartBoundary, float3 spaceSize, int3 cellSize, float cellLength,
                   float radius, float dt, float rho0, float rhoB, float visc, float3 G,
                   float surfaceTensionIntensity, float airPressure, bool reduce = false);
-    int lastDivergenceIterations() const { return lastDiv; }
-    int lastDensityIterations() const { return lastDen; }
+    int lastDivergenceIterations() { fetchIterations(); return lastDiv; }
+    int lastDensityIterations() { fetchIterations(); return lastDen; }
     // distributed adaptive mode: restrict the |error| total to [lo, hi) and read it as the raw integer
     void setErrorSumRange(int lo, int hi) { sumLo = lo; sumHi = hi; }
     long long readErrorTotalFixed();
     void resetErrorTotal();          // zero the |error| accumulators on the current stream (split error stages then all ADD)
-    void noteIterations(int div, int den) { lastDiv = div; lastDen = den; }
+    void noteIterations(int div, int den) { lastDiv = div; lastDen = den; itersPending = false; }
     const DArray<float>& getAlpha() const { return alpha; }
     const DArray<float>& getStiffness() const { return bufferFloat; }
     const DArray<float>& getError() const { return error; }
@@ -86,4 +88,11 @@ private:
     int fixedDiv = -1, fixedDen = -1;
     bool headDidFirstError = false;   // the fused head sweep already produced the first divergence error
     int lastDiv = 0, lastDen = 0;
+    // device-side adaptive loops: {done, iteration, divergence iterations, density iterations} of the current step on the device,
+    // copied to pinned host memory at the end of every step and read when somebody asks
+    bool deviceLoops() const;
+    void fetchIterations();
+    DArray<int> loopState;
+    int* hostIters = nullptr;
+    bool itersPending = false;
 };
