@@ -3,7 +3,7 @@
 // timing report (what src/main.cpp:73-135 and :300-306 do, minus GLUT/GL).
 //
 //   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--restart-with wcsph|dfsph|pbd]
-//             [--dump file.bin] [--dots file.bin] [--save snap.bin] [--load snap.bin]
+//             [--dump file.bin] [--dots file.bin] [--save snap.bin] [--load snap.bin] [--advect-check file.bin]
 //
 // The scene (constants of main.cpp:54-67, block and shell samplers of :73-117, scaled by nx/24) comes
 // from the library's scene generator (sphx_scene_params / sphx_scene_fill), the same one the tests
@@ -67,7 +67,7 @@ static int write_dump(const std::string& path, int n, const float3* dPos, const 
 int main(int argc, char** argv)
 {
     int solverKind = SPHX_PBD, nx = 24, steps = 100, restartKind = -1;
-    std::string dump, savePath, loadPath, dotsPath;
+    std::string dump, savePath, loadPath, dotsPath, advectPath;
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
         const bool more = a + 1 < argc;
@@ -79,10 +79,34 @@ int main(int argc, char** argv)
         else if (k == "--dots" && more) dotsPath = argv[++a];
         else if (k == "--save" && more) savePath = argv[++a];
         else if (k == "--load" && more) loadPath = argv[++a];
+        else if (k == "--advect-check" && more) advectPath = argv[++a];
     }
     if (sphx_device_count() < 1) {
         fprintf(stderr, "sphx_demo: no HIP device (the engine has no CPU path)\n");
         return 2;
+    }
+
+    if (!advectPath.empty()) {          // Particles::advect on its own (Particles.cu:28-36): n, dt, pos before, vel, pos after
+        const int n = 4099;
+        std::vector<float3> p0((size_t)n), v((size_t)n), p1((size_t)n);
+        unsigned int rng = 2463534242u;
+        auto next = [&]() { rng = rng * 1664525u + 1013904223u; return (float)(rng >> 8) * (1.0f / 16777216.0f); };
+        for (int i = 0; i < n; ++i) {
+            p0[i] = make_float3(next() * 1.7f, next() * 1e-3f, next() * 40.0f - 20.0f);
+            v[i] = make_float3(next() * 6.0f - 3.0f, -next() * 9.8f, (i % 7 == 0) ? 0.0f : next() * 1e-4f);
+        }
+        Particles set(p0);
+        (void)hipMemcpy(set.getVelPtr(), v.data(), sizeof(float3) * n, hipMemcpyHostToDevice);
+        const float dt = 0.002f;
+        set.advect(dt);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(p1.data(), set.getPosPtr(), sizeof(float3) * n, hipMemcpyDeviceToHost);
+        FILE* fp = fopen(advectPath.c_str(), "wb");
+        if (!fp) return 3;
+        fwrite(&n, sizeof(int), 1, fp); fwrite(&dt, sizeof(float), 1, fp);
+        fwrite(p0.data(), sizeof(float3), n, fp); fwrite(v.data(), sizeof(float3), n, fp); fwrite(p1.data(), sizeof(float3), n, fp);
+        fclose(fp);
+        return 0;
     }
 
     if (!loadPath.empty()) {            // continue a saved run

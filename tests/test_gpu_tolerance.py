@@ -322,3 +322,35 @@ def test_persistent_rows_need_slack_in_the_cell_length(sphx, oracle):
     assert not g.persistent_stats()[0]
     assert np.array_equal(g.get(sphx.F_CELL), o.get(oracle.F_CELL))
     assert _rel(g.get(sphx.F_POS), o.get(oracle.F_POS), P.space[0]) <= TOL
+
+
+def test_tolerance_engines_at_config_3_size_against_the_oracle(sphx, oracle):
+    """BASELINE config 3 in full (1,022,208 particles, DFSPH(1,4)), the size at which the quad walks of the corrections and the
+    (y-chunk, x) tile schedule switch on: 10 steps of the plain tolerance engine AND of the persistent-rows engine against ONE
+    run of the strict oracle, element by element at 1e-5 (positions against the domain size, densities against rho0, both also
+    relative to max(|value|, 1 % of the scale)), cell indices, ids and the cell table bit-exact."""
+    P, fluid, boundary = sphx.scene(88)
+    P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    Po = same_params(oracle.Params(), P)
+    engines = []
+    for mode in (1, 2):
+        Q = P.copy(); Q.reserved[3] = mode
+        engines.append(sphx.System(Q, fluid, boundary))
+    o = oracle.System(Po, fluid, boundary)
+    assert engines[0].n == 1022208
+    for step in range(10):
+        o.step()
+        ref = {f: o.get(getattr(oracle, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F", "F_POS", "F_DENSITY")}
+        for mode, g in zip((1, 2), engines):
+            g.step()
+            for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
+                assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, step, f)
+            for f, scale in (("F_POS", P.space[0]), ("F_DENSITY", P.rho0)):
+                a = g.get(getattr(sphx, f)).astype(np.float64); b = ref[f].astype(np.float64)
+                d = np.abs(a - b)
+                assert d.max() / scale <= TOL, (mode, step, f, d.max() / scale)
+                assert (d / np.maximum(np.abs(b), 0.01 * scale)).max() <= TOL, (mode, step, f)
+    assert engines[1].persistent_stats()[0]
+    for g in engines:
+        g.close()
+    o.close()

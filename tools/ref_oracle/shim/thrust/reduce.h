@@ -1,0 +1,1 @@
+#include <thrust/execution_policy.h>
