@@ -11,13 +11,17 @@ A "step" is one SPHSystem::step(): neighbour search + solver step.  Inputs are r
 before the timed region (the scene is uploaded by the constructor).
 
 Prints ONE JSON line (rank 0) with, besides the contract's keys:
-  roofline      dominant kernel (density-error sweep), live hipEvent timing over the timed region: HBM fraction from
-                algorithmic bytes, the FP32-VALU fraction from counted pair evaluations (SURVEY.md §8d asks for both),
-                PMC traffic from profiles/traffic.json when that file was measured on THIS source tree
-  steady_state  post-impact legs (ragged cells, wall contact): the 10 M scene under the reference's adaptive iteration
-                control and the 1 M config 3, >= 100 timed steps each, with neighbours-per-particle statistics
-  configs       BASELINE configs 2, 3, 4 (263k WCSPH, 1M DFSPH, 1M PBD) and the reference scene (20,736 particles)
-  cpu_baseline  the CPU oracle on a bounded sample (>= 1 M particles), rank 0 at N = 1 only
+  value / roofline   the headline leg: --arith tolerance by default (the north star's contract: results within 1e-5 of the reference,
+                     integer cell indices bit-exact; the reference's own binary is built -use_fast_math) -- dominant kernel (density-error
+                     sweep) timed live with hipEvents over the timed region: HBM fraction from algorithmic bytes, FP32-VALU fraction from
+                     counted pair evaluations, PMC traffic from profiles/traffic.json when that file was measured on THIS source tree
+  legs_by_arithmetic the same workload and window under the other contracts (strict = bit-exact IEEE, persistent = tolerance + rows
+                     kept across steps), each with its own live roofline block
+  steady_state       post-impact legs (ragged cells, wall contact): the 10 M scene under the reference's adaptive iteration
+                     control and the 1 M config 3, >= 100 timed steps each, with neighbours-per-particle statistics
+  configs            BASELINE configs 2, 3, 4 (263k WCSPH, 1M DFSPH, 1M PBD) and the reference scene (20,736 particles)
+  cpu_baseline       the CPU oracle: BASELINE config 1 and the reference scene's other two solvers with 1 thread and with all cores
+                     (measured), the headline solver at 1 M on all cores (extrapolated to the bench size, labelled); rank 0 at N = 1 only
 """
 import argparse
 import json
@@ -52,7 +56,7 @@ def step_bytes_per_particle(solver, v, d, k):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nx", type=int, default=190, help="fluid block is nx x 1.5nx x nx (190 -> 10,288,500)")
     ap.add_argument("--solver", default="dfsph", choices=["wcsph", "dfsph", "pbd"])
@@ -68,33 +72,63 @@ def parse():
     ap.add_argument("--slab-transport", default="loopback", choices=["loopback", "rccl"],
                     help="with --force-slab: device-to-device copies, or the installed RCCL (grouped sends to self on the communication stream)")
     ap.add_argument("--no-overlap", action="store_true", help="slab layer: stage-then-exchange instead of edge-first stages")
+    ap.add_argument("--arith", default="tolerance", choices=["strict", "tolerance", "persistent"],
+                    help="arithmetic contract of the HEADLINE leg: tolerance (default: the north star's 1e-5 contract; the reference's own "
+                         "binary is built -use_fast_math), persistent (tolerance + rows kept across steps) or strict (bit-exact IEEE)")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
 def cpu_baseline(args, n_bench):
-    """CPU oracle (kind 'port': this repo's restatement of the reference, OpenMP over particles; the reference
-    itself cannot be built here — nvcc, Thrust and helper_math.h are absent) on a bounded sample of the same
-    workload, scaled linearly in particle count to the bench size."""
+    """CPU oracle (kind 'port': this repo's restatement of the reference, OpenMP over particles; the reference itself
+    cannot be built here -- nvcc, Thrust and helper_math.h are absent) on bounded samples:
+      * BASELINE config 1 as stated (20,736-particle WCSPH dam break, dt = 0.001) and the same scene under the reference's
+        default DFSPH and PBD(20), each with ONE thread (the north star's "serial kernels") and with all cores -- measured,
+        nothing extrapolated (timer position: SPHSystem.cu:131-157, one step() per frame; README.md:6-9 quotes GPU frame times);
+      * the headline solver at 1 M particles on all cores, whose steps/s is EXTRAPOLATED linearly in the particle count to
+        the bench size for `value` (labelled; the measured figure is given beside it)."""
     from oracle import oracle as O
+    cores = O.lib().oracle_max_threads()
+    configs = []
+    for name, solver, dt, serial_steps, parallel_steps in (("wcsph", O.WCSPH, 0.001, 20, 200), ("dfsph", O.DFSPH, 0.002, 6, 60), ("pbd", O.PBD, 0.002, 6, 60)):
+        for threads, steps in ((1, serial_steps), (cores, parallel_steps)):
+            P, fluid, boundary = O.scene(24)
+            P.solver = solver; P.dt = dt
+            s = O.System(P, fluid, boundary, threads=threads)      # constructor step = warm-up
+            if solver == O.PBD:
+                s.step()
+            t0 = time.time()
+            for _ in range(steps):
+                s.step()
+            sec = (time.time() - t0) / steps
+            s.close()
+            configs.append({"workload": "reference scene, 20,736 particles, %s, dt=%g%s" % (
+                                {"wcsph": "WCSPH (BASELINE config 1)", "dfsph": "DFSPH adaptive (reference defaults)", "pbd": "PBD(20)"}[name], dt,
+                                ", free fall" ), "threads": threads, "steps": steps, "ms_per_step": sec * 1e3, "steps_per_s": 1.0 / sec,
+                            "extrapolated": False})
+            note("cpu baseline: reference scene %s, %d thread(s): %.1f ms/step" % (name, threads, sec * 1e3))
     P, fluid, boundary = O.scene(args.cpu_nx)
     P.solver = {"wcsph": O.WCSPH, "dfsph": O.DFSPH, "pbd": O.PBD}[args.solver]
     P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, args.pbd_iters
     note("cpu baseline: oracle nx=%d" % args.cpu_nx)
-    s = O.System(P, fluid, boundary)          # constructor step = warm-up
-    note("cpu baseline: constructor step done")
+    s = O.System(P, fluid, boundary, threads=cores)          # constructor step = warm-up
     t0 = time.time()
     for _ in range(args.cpu_steps):
         s.step()
     dt = (time.time() - t0) / args.cpu_steps
+    s.close()
     n_s = len(fluid)
-    cores = O.lib().oracle_max_threads()
+    configs.append({"workload": "%s dam-break nx=%d, %d particles (the headline solver settings)" % (args.solver, args.cpu_nx, n_s),
+                    "threads": cores, "steps": args.cpu_steps, "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "extrapolated": False})
     steps_per_s_at_bench = (1.0 / dt) * (n_s / float(n_bench))
     return {"value": steps_per_s_at_bench, "unit": "steps/s", "cores": cores, "kind": "port",
-            "note": "port = oracle/sph_oracle.c, this repo's CPU restatement; the reference is not buildable here",
+            "extrapolated": "value = measured %.4f steps/s at %d particles x (%d / %d): linear in the particle count" % (1.0 / dt, n_s, n_s, n_bench),
+            "measured_steps_per_s": 1.0 / dt, "measured_particles": n_s,
+            "note": "port = oracle/sph_oracle.c, this repo's CPU restatement (OpenMP over particles); the reference is not buildable here",
             "sample": "%s dam-break nx=%d (%d particles), %d steps at %.3f s/step on %d OpenMP threads, scaled by "
-                      "particle count to %d particles" % (args.solver, args.cpu_nx, n_s, args.cpu_steps, dt, cores, n_bench)}
+                      "particle count to %d particles" % (args.solver, args.cpu_nx, n_s, args.cpu_steps, dt, cores, n_bench),
+            "configs": configs}
 
 
 def read_traffic(workload_key):
@@ -149,11 +183,22 @@ def neighbour_stats(sim):
             "p99": int(np.searchsorted(cdf, 0.99)), "max": int(longest)}
 
 
-def make_system(sphx, nx, solver, div, den, pbd_iters, tolerance=False):
+ARITH = {"strict": 0, "tolerance": 1, "persistent": 2}
+ARITH_TEXT = {"strict": "strict arithmetic: every bit equals the IEEE evaluation of the reference's expressions in the reference's order (the parity contract "
+                        "of tests/test_gpu_parity.py)",
+              "tolerance": "tolerance arithmetic (sphx_params.reserved[3] = 1): v_rsq/v_rcp + FMA contraction in the neighbour sweeps, quad-per-particle row "
+                           "walks with per-lane partial sums and one DPP reduction per particle; positions and densities within 1e-5 of the oracle, integer "
+                           "fields bit-exact (tests/test_gpu_tolerance.py) -- the north star's contract; the reference's own binary is built -use_fast_math",
+              "persistent": "tolerance arithmetic with persistent neighbour rows (reserved[3] = 2): the solver steps a working copy kept in row-build order, "
+                            "rows carry a skin and are rebuilt when a device-side check finds > 0.45 skin of relative displacement; API arrays exported "
+                            "in the reference's order every step (tests/test_gpu_tolerance.py::test_persistent_rows_*)"}
+
+
+def make_system(sphx, nx, solver, div, den, pbd_iters, tolerance=False, arith=None):
     P, fluid, boundary = sphx.scene(nx)
     P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver]
     P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = div, den, pbd_iters
-    P.reserved[3] = 1 if tolerance else 0
+    P.reserved[3] = ARITH[arith] if arith else (1 if tolerance else 0)
     if solver == "wcsph":
         P.dt = 0.001
     sim = sphx.System(P, fluid, boundary)     # uploads + constructor step (SPHSystem.cu:69-76)
@@ -174,7 +219,7 @@ def settled_leg(sphx, torch, nx, solver, div, den, settle, steps):
     """advance a fresh system past the impact, then time `steps` steps there"""
     sim, P = make_system(sphx, nx, solver, div, den, 4)
     what = "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults: 1e-3 thresholds, <= 20 iterations)"
-    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (nx, sim.n, what, P.dt), "after_steps": 1 + settle}
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, strict arithmetic" % (nx, sim.n, what, P.dt), "after_steps": 1 + settle}
     done, first = 0, None
     while done < settle:              # in slices, so that a run-away state shows up instead of eating the time budget
         k = min(50, settle - done)
@@ -215,7 +260,7 @@ def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup):
         div, den = sim.iters()                  # iteration counts of the last step
         what += ", last step ran (%d,%d) iterations" % (div, den)
     bpp = step_bytes_per_particle(solver, div, den, pbd_iters)
-    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g" % (nx, sim.n, what, P.dt),
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, strict arithmetic" % (nx, sim.n, what, P.dt),
            "particles": sim.n, "steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
            "algorithmic_GBps": bpp * sim.n * sps / 1e9, "hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS}
     sim.close()
@@ -257,91 +302,85 @@ def main():
     sphx.set_device(local_rank)
     torch.cuda.set_device(local_rank)
     solver = args.solver
-    note("building the %s nx=%d scene" % (solver, args.nx))
-    sim, P = make_system(sphx, args.nx, solver, args.div_iters, args.den_iters, args.pbd_iters)
-    n = sim.n
-    note("constructed, %d particles" % n)
-
-    # warm-up (untimed)
-    if args.warmup > 0:
-        sim.step_n(args.warmup)
-    torch.cuda.synchronize()
-
-    # timed region: exactly K steps, launched back to back with one sync at the end; the dominant kernel's
-    # launches are bracketed by hipEvents on the engine stream (live roofline leg).  With the event timer on the
-    # steps are launched eagerly rather than replayed from the captured hipGraph: at 10 M particles launch overhead
-    # is < 1 %, and the number stays the contract's "measured over the timed region".
     span = DOMINANT_SPAN if solver == "dfsph" else ""
-    if span:
-        sphx.kernel_timer(True, span)
-    wall, ms_events = timed_steps(torch, sim, args.steps)
-    note("timed region done: %.2f ms/step" % (wall * 1e3 / args.steps))
-    spans = sphx.kernel_timer_collect() if span else {}
-    sphx.kernel_timer(False)
-    nb_free_fall = neighbour_stats(sim)
-
-    ms_per_step = wall * 1e3 / args.steps
-    steps_per_s = args.steps / wall
     bpp = step_bytes_per_particle(solver, args.div_iters, args.den_iters, args.pbd_iters)
     what = {"dfsph": "DFSPH(%d div + %d density iters, fixed)" % (args.div_iters, args.den_iters),
             "pbd": "PBD(%d Jacobi iters)" % args.pbd_iters, "wcsph": "WCSPH"}[solver]
-    result = {
-        "metric": "simulation steps/sec, DFSPH dam-break" if solver == "dfsph" else "simulation steps/sec, %s dam-break" % solver,
-        "value": steps_per_s, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic, "
-                               "free-fall / early-impact window" % (args.nx, 3 * args.nx // 2, args.nx, n, sim.nb, what, P.dt),
-                   "particles": n, "decomposition": "single device",
-                   "step_algorithmic_bytes_per_particle": bpp,
-                   "step_algorithmic_GBps": bpp * n * steps_per_s / 1e9,
-                   "step_hbm_roofline_frac": bpp * n * steps_per_s / 1e9 / HBM_PEAK_GBPS,
-                   "event_ms_per_step": ms_events / args.steps,
-                   "neighbours_per_particle": nb_free_fall},
-    }
-    if span and span in spans:
-        tot_ms, launches = spans[span]
-        avg_ms = tot_ms / launches
-        achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
-        pmc = read_traffic("%s_nx%d" % (solver, args.nx))         # None unless measured on exactly this source tree
-        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
-        flops = RATE_KERNEL_FLOP_PER_PAIR * nb_free_fall["pairs"] / (avg_ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s')" % span,
-                              "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                              "avg_launch_ms": avg_ms, "launches": launches,
-                              "algorithmic_bytes_per_launch": RATE_KERNEL_BYTES_PER_PARTICLE * n,
-                              "valu": {"pairs_per_launch": nb_free_fall["pairs"], "flop_per_pair_model": RATE_KERNEL_FLOP_PER_PAIR,
-                                       "achieved_TFLOPs": flops, "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
-                                       "valu_issue_frac_pmc": pmc.get("valu_issue_frac") if pmc else None,
-                                       "valu_instr_per_simd_per_clk_pmc": pmc.get("valu_instr_per_simd_per_clk_raw") if pmc else None},
-                              "limiter": limiter_text(pmc)}
-    else:
-        result["roofline"] = None
 
-    sim.close()
-    if not args.no_extra_legs:
-        # the same workload and window under the tolerance arithmetic (hardware rsq / rcp, fused multiply-adds; gated by
-        # tests/test_gpu_tolerance.py: positions and densities within 1e-5 of the oracle).  `value` above is the strict mode.
-        tsim, _ = make_system(sphx, args.nx, solver, args.div_iters, args.den_iters, args.pbd_iters, tolerance=True)
-        tsim.step_n(args.warmup)
+    def headline_leg(arith):
+        """one arithmetic contract on the headline workload: W untimed warm-up steps, then exactly K timed steps launched back
+        to back with one sync at the end; the dominant kernel's launches are bracketed by hipEvents on the engine stream (live
+        roofline leg).  With the event timer on, the steps are launched eagerly rather than replayed from the captured hipGraph:
+        at 10 M particles launch overhead is < 1 %, and the number stays the contract's "measured over the timed region"."""
+        note("building the %s nx=%d scene (%s)" % (solver, args.nx, arith))
+        sim, P = make_system(sphx, args.nx, solver, args.div_iters, args.den_iters, args.pbd_iters, arith=arith)
+        n = sim.n
+        if args.warmup > 0:
+            sim.step_n(args.warmup)
+        torch.cuda.synchronize()
         if span:
             sphx.kernel_timer(True, span)
-        twall, _ = timed_steps(torch, tsim, args.steps)
-        tspans = sphx.kernel_timer_collect() if span else {}
+        wall, ms_events = timed_steps(torch, sim, args.steps)
+        spans = sphx.kernel_timer_collect() if span else {}
         sphx.kernel_timer(False)
-        tsps = args.steps / twall
-        result["tolerance_mode"] = {"arithmetic": "sphx_params.reserved[3] = 1: v_rsq/v_rcp + FMA contraction in the neighbour sweeps; rate, head, viscosity+colour "
-                                                  "and correction sweeps walk their rows quad-per-particle with per-lane partial sums and one DPP "
-                                                  "reduction per particle (summation order is free under the 1e-5 contract)",
-                                    "steps_per_s": tsps, "ms_per_step": twall * 1e3 / args.steps,
-                                    "step_hbm_roofline_frac": bpp * n * tsps / 1e9 / HBM_PEAK_GBPS}
-        if span and span in tspans:
-            t_ms = tspans[span][0] / tspans[span][1]
-            result["tolerance_mode"].update({"dominant_kernel_avg_launch_ms": t_ms,
-                                             "dominant_kernel_hbm_frac": RATE_KERNEL_BYTES_PER_PARTICLE * n / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
-        note("tolerance-mode leg: %.2f ms/step" % (twall * 1e3 / args.steps))
-        tsim.close()
+        note("%s leg: %.2f ms/step" % (arith, wall * 1e3 / args.steps))
+        nb = neighbour_stats(sim)
+        sps = args.steps / wall
+        leg = {"arithmetic": ARITH_TEXT[arith], "steps_per_s": sps, "ms_per_step": wall * 1e3 / args.steps, "event_ms_per_step": ms_events / args.steps,
+               "step_algorithmic_GBps": bpp * n * sps / 1e9, "step_hbm_roofline_frac": bpp * n * sps / 1e9 / HBM_PEAK_GBPS,
+               "particles": n, "boundary_particles": sim.nb, "dt": P.dt, "neighbours_per_particle": nb, "roofline": None}
+        if arith == "persistent":
+            in_use, builds, counted = sim.persistent_stats()
+            leg["persistent_rows"] = {"in_use": in_use, "row_builds": builds, "steps": counted}
+        if span and span in spans:
+            tot_ms, launches = spans[span]
+            avg_ms = tot_ms / launches
+            achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
+            pmc = read_traffic("%s_nx%d%s" % (solver, args.nx, "" if arith == "strict" else "_tol"))    # None unless measured on exactly this source tree
+            flops = RATE_KERNEL_FLOP_PER_PAIR * nb["pairs"] / (avg_ms * 1e-3) / 1e12
+            leg["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE, WARM, %d> (span '%s')" % (0 if arith == "strict" else 1, span),
+                               "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                               "avg_launch_ms": avg_ms, "launches": launches,
+                               "algorithmic_bytes_per_launch": RATE_KERNEL_BYTES_PER_PARTICLE * n,
+                               "valu": {"pairs_per_launch": nb["pairs"], "flop_per_pair_model": RATE_KERNEL_FLOP_PER_PAIR,
+                                        "achieved_TFLOPs": flops, "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
+                                        "valu_issue_frac_pmc": pmc.get("valu_issue_frac") if pmc else None,
+                                        "valu_instr_per_simd_per_clk_pmc": pmc.get("valu_instr_per_simd_per_clk_raw") if pmc else None},
+                               "limiter": limiter_text(pmc)}
+        sim.close()
+        return leg
+
+    head = headline_leg(args.arith)
+    n = head["particles"]
+    result = {
+        "metric": "simulation steps/sec, DFSPH dam-break" if solver == "dfsph" else "simulation steps/sec, %s dam-break" % solver,
+        "value": head["steps_per_s"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, %s arithmetic, free-fall / early-impact window"
+                               % (args.nx, 3 * args.nx // 2, args.nx, n, head["boundary_particles"], what, head["dt"], args.arith),
+                   "arithmetic": head["arithmetic"],
+                   "particles": n, "decomposition": "single device",
+                   "step_algorithmic_bytes_per_particle": bpp,
+                   "step_algorithmic_GBps": head["step_algorithmic_GBps"],
+                   "step_hbm_roofline_frac": head["step_hbm_roofline_frac"],
+                   "event_ms_per_step": head["event_ms_per_step"],
+                   "neighbours_per_particle": head["neighbours_per_particle"]},
+        "roofline": head["roofline"],
+    }
+    if "persistent_rows" in head:
+        result["config"]["persistent_rows"] = head["persistent_rows"]
+
+    if not args.no_extra_legs:
+        # the same workload and window under the other arithmetic contracts, each with its own live roofline leg
+        result["legs_by_arithmetic"] = {args.arith: {k: head[k] for k in ("steps_per_s", "ms_per_step", "step_hbm_roofline_frac")}}
+        for other in ("strict", "tolerance", "persistent"):
+            if other != args.arith:
+                leg = headline_leg(other)
+                result["legs_by_arithmetic"][other] = {k: leg[k] for k in ("arithmetic", "steps_per_s", "ms_per_step", "step_hbm_roofline_frac", "roofline") if k in leg}
+                if "persistent_rows" in leg:
+                    result["legs_by_arithmetic"][other]["persistent_rows"] = leg["persistent_rows"]
         # Post-impact legs (ragged cells, wall contact, 40+ neighbours).  At 10 M particles the column hits the floor
         # around step 200; with the FIXED (1,4) iteration counts of config 5 the under-converged solve does not survive
         # that impact (densities and velocities run away within ~50 steps: tools/settle_probe.py, DESIGN.md), so the

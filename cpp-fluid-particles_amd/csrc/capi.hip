@@ -69,6 +69,13 @@ int sphx_set_device(int ordinal)
 
 int sphx_sizeof_params(void) { return (int)sizeof(sphx_params); }
 
+int sphx_device_pci_id(int ordinal, char* out, int capacity)
+{
+    if (!out || capacity < 16) return fail(SPHX_ERR_INVALID, "sphx_device_pci_id: bad argument");
+    if (hipDeviceGetPCIBusId(out, capacity, ordinal) != hipSuccess) { (void)hipGetLastError(); return fail(SPHX_ERR_HIP, "sphx_device_pci_id: hipDeviceGetPCIBusId failed"); }
+    return SPHX_OK;
+}
+
 // ------------------------------------------------------------------------------------ scene
 // Constants of main.cpp:54-67; block and shell samplers of main.cpp:73-117; scaling rule of
 // BASELINE.md §4 (s = nx/24; nx = 24 reproduces the reference scene bit-for-bit).

@@ -39,6 +39,8 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional: what the bench line reports about the communicator
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 
     bool load(std::string& why)
     {
@@ -62,6 +64,8 @@ struct RcclApi {
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        CommCount = (decltype(CommCount))sym("ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))sym("ncclCommUserRank");
         if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !AllReduce || !GroupStart || !GroupEnd) {
             why = "librccl lacks an expected symbol";
             return false;
@@ -89,12 +93,23 @@ struct Transport {
     virtual void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) = 0;
     virtual void wait() = 0;
     virtual long long allreduce_sum(long long localSum) = 0;   // blocking; every process calls it
+    // what the bench line reports: 0 loopback / 1 RCCL, ranks and own rank of the communicator as the LIBRARY reports them
+    // (-1: the library has no ncclCommCount), payload bytes posted so far, exchanges (grouped send/recv rounds) and all-reduces
+    virtual void describe(int& kind, int& ranks, int& rank) const { kind = 0; ranks = 1; rank = 0; }
+    long long bytesSent = 0, bytesReceived = 0, exchanges = 0, allreduces = 0;
+    void account(const std::vector<Msg>& sends, const std::vector<Msg>& recvs)
+    {
+        for (const Msg& m : sends) bytesSent += (long long)m.bytes;
+        for (const Msg& m : recvs) bytesReceived += (long long)m.bytes;
+        ++exchanges;
+    }
 };
 
 // all slabs in this process: a message is one device-to-device copy on the engine stream
 struct LoopbackTransport final : Transport {
     void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool) override
     {
+        account(sends, recvs);
         std::vector<char> used(sends.size(), 0);
         for (const Msg& r : recvs) {
             size_t k = 0;
@@ -164,8 +179,15 @@ struct RcclTransport final : Transport {
         if (commStream) (void)hipStreamDestroy(commStream);
         comm = nullptr; dScalar = nullptr; hScalar = nullptr; ready = done = nullptr; commStream = nullptr;
     }
+    void describe(int& kind, int& ranks, int& rank) const override
+    {
+        kind = 1; ranks = -1; rank = -1;
+        if (g_rccl.CommCount && g_rccl.CommCount(comm, &ranks) != ncclSuccess) ranks = -1;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(comm, &rank) != ncclSuccess) rank = -1;
+    }
     void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) override
     {
+        account(sends, recvs);
         if (pending) wait();
         hip_ok(hipEventRecord(ready, sphx::stream()), "event record");
         hip_ok(hipStreamWaitEvent(commStream, ready, 0), "stream wait");
@@ -199,6 +221,7 @@ struct RcclTransport final : Transport {
     }
     long long allreduce_sum(long long v) override
     {
+        ++allreduces;
         wait();
         hScalar[0] = v;
         hip_ok(hipMemcpyAsync(dScalar, hScalar, sizeof(long long), hipMemcpyHostToDevice, sphx::stream()), "scalar upload");
@@ -1073,6 +1096,18 @@ int sphx_slab_system(const sphx_slab_group* g, int index, sphx_system** sys)
 {
     if (!g || !sys || index < 0 || index >= (int)g->slabs.size()) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_system: bad argument");
     *sys = g->slabs[index]->sys;
+    return SPHX_OK;
+}
+
+int sphx_slab_comm_info(const sphx_slab_group* g, int* transport_kind, int* comm_ranks, int* comm_rank, long long counters4[4])
+{
+    if (!g || !g->transport) return slab_fail(SPHX_ERR_INVALID, "sphx_slab_comm_info: bad argument");
+    int kind = 0, ranks = 0, rank = 0;
+    g->transport->describe(kind, ranks, rank);
+    if (transport_kind) *transport_kind = kind;
+    if (comm_ranks) *comm_ranks = ranks;
+    if (comm_rank) *comm_rank = rank;
+    if (counters4) { counters4[0] = g->transport->bytesSent; counters4[1] = g->transport->bytesReceived; counters4[2] = g->transport->exchanges; counters4[3] = g->transport->allreduces; }
     return SPHX_OK;
 }
 

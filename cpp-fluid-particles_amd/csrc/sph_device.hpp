@@ -436,25 +436,10 @@ constexpr unsigned int kStreamSlotMask = 0x07ffffffu;
 //                       the 4 neighbours of a chunk are consecutive accepted candidates, i.e. (almost) adjacent
 //                       records, so the quad's gathers share cache lines (walk_row_quad).
 constexpr int kRowChunk = 4;
-// Row traffic: every entry is read once per sweep and the row storage of a 10 M scene is 1.3-2 GB, far beyond the 256 MB Infinity
-// Cache: streaming it with the non-temporal hint keeps the gathered records resident instead (-3 % per sweep at 10.3 M particles,
-// +14..19 % at 1 M where the rows themselves fit the cache: profiles/r04_ubench_tiles.txt).  A build-time switch of the library
-// (the kernels would otherwise need a second instantiation each); off by default.
-#ifndef SPHX_NT_ROWS
-#define SPHX_NT_ROWS 0
-#endif
-typedef unsigned int row_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned int row_load(const unsigned int* p) { return SPHX_NT_ROWS ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ uint4 row_load4(const unsigned int* p)
-{
-    if (SPHX_NT_ROWS) { const row_u4 v = __builtin_nontemporal_load(reinterpret_cast<const row_u4*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
-    return *reinterpret_cast<const uint4*>(p);
-}
-__device__ __forceinline__ void row_store4(unsigned int* p, const uint4 v)
-{
-    if (SPHX_NT_ROWS) { row_u4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<row_u4*>(p)); }
-    else *reinterpret_cast<uint4*>(p) = v;
-}
+// (Non-temporal row loads / stores were measured and dropped: -3 % per sweep in the micro-benchmark at 10.3 M particles, +14..19 % at
+// 1 M, nothing in the engine's sweeps and a 2x slower row builder -- profiles/r04_ubench_tiles.txt, DESIGN.md section 5.  Routing the row
+// loads through a helper function also cost the strict rate kernel 16 %: the compiler then waits for each row load before issuing
+// the next one.  Keep them as plain indexed loads through the __restrict__ pointer.)
 __device__ __forceinline__ size_t row_base_offset(int i, int cap) { return ((size_t)(i >> 6) * (size_t)cap) * 64u + (size_t)(i & 63) * kRowChunk; }
 __device__ __forceinline__ size_t row_entry_offset(int k) { return (size_t)(k >> 2) * 256u + (unsigned)(k & 3); }
 
@@ -594,8 +579,11 @@ __device__ __forceinline__ void walk_cells(const SweepCtx& c, const float3 pi, V
 template <bool WANT_BOUNDARY, class Visit>
 __device__ __forceinline__ void walk_cells_fallback(const SweepCtx& c, const int i, const float3 pi, Visit&& visit)
 {
+    // (persistent rows exist under the tolerance arithmetic only: in the strict instantiations of the quad kernels, where
+    // assume_arith pins k.tol to 0, this branch disappears -- its extra live registers made the compiler serialise the row
+    // loads of the strict rate kernel, +16 % on the dominant launch: ISA diff in r04)
     int3 c0;
-    if (c.persist) {
+    if (c.k.tol != 0 && c.persist) {
         const int id = c.rowCell[i];
         c0 = make_int3(id / (c.g.gz * c.g.gy), (id / c.g.gz) % c.g.gy, id % c.g.gz);
         if (id >= c.g.C) c0.x = -4;          // built out of the grid (sentinel bucket): every cell of the walk is skipped
@@ -700,7 +688,7 @@ __device__ __forceinline__ void walk_row(const Op& op, const SweepCtx& c, const 
     for (; t + kAhead <= cnt; t += kAhead) {
         unsigned int e[kAhead];
         if constexpr (kAhead == kRowChunk) {      // t is a multiple of 4: one 16-byte load
-            const uint4 ch = row_load4(row + (size_t)(t >> 2) * 256u);
+            const uint4 ch = *reinterpret_cast<const uint4*>(row + (size_t)(t >> 2) * 256u);
             e[0] = ch.x; e[1] = ch.y; e[2] = ch.z; e[3] = ch.w;
         } else {
 #pragma unroll
@@ -758,12 +746,12 @@ __device__ __forceinline__ void sweep(const Op& op, const SweepCtx& c, float4* l
                                       const int i, const bool valid, const float3 pi, Body& body)
 {
     const int lane = threadIdx.x & 63;
-    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool skin = c.stale != nullptr || (c.k.tol != 0 && c.persist != 0);
     const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);    // stale skin rows: direct walks (launch-uniform)
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow && !c.persist) {     // (normally never fails: the position update asks for a rebuild on a crossing)
+    if (c.stale != nullptr && useRow) {     // (normally never fails: the position update asks for a rebuild on a crossing)
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -896,7 +884,7 @@ __device__ __forceinline__ void quad_chunks(const Op& op, const SweepCtx& c, con
         // unconditional load (chunks past this row's end hold stale entries), then: past the end -> record 0,
         // evaluated and dropped
         ok[u] = 4 * (s + u) + g < cnt;
-        const unsigned int raw = row_load(rowq + (size_t)(s + u) * 256u);
+        const unsigned int raw = rowq[(size_t)(s + u) * 256u];
         e[u] = ok[u] ? raw : 0u;
     }
     float4 pj[U];
@@ -991,12 +979,12 @@ __device__ __forceinline__ int quad_particle(const SweepCtx& c)
 template <bool WANT_BOUNDARY, class Op, class Body>
 __device__ __forceinline__ void sweep_quad(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
 {
-    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool skin = c.stale != nullptr || (c.k.tol != 0 && c.persist != 0);
     const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow && !c.persist) {
+    if (c.stale != nullptr && useRow) {
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -1131,12 +1119,12 @@ __device__ __forceinline__ int duo_particle(const SweepCtx& c)
 template <bool WANT_BOUNDARY, class Op, class Body>
 __device__ __forceinline__ void sweep_duo(const Op& op, const SweepCtx& c, const int i, const bool valid, const float3 pi, Body& body)
 {
-    const bool skin = c.stale != nullptr || c.persist != 0;
+    const bool skin = c.stale != nullptr || (c.k.tol != 0 && c.persist != 0);
     const bool rows = c.nbr != nullptr && !(c.stale != nullptr && *c.stale != 0);
     const bool allPlain = !fast_paths_enabled(c.k);
     const int cnt = (rows && valid) ? c.nbrCount[i] : 0;
     bool useRow = rows && valid && cnt <= c.cap;
-    if (skin && useRow && !c.persist) {
+    if (c.stale != nullptr && useRow) {
         const int3 cNow = cell_of(pi, c.g);
         useRow = cell_id(cNow.x, cNow.y, cNow.z, c.g) == c.rowCell[i];
     }
@@ -1186,7 +1174,7 @@ __device__ __forceinline__ void put_entry(const SweepCtx& c, unsigned int* stage
     if (SPHX_BUILD_REGSTAGE && !stage) {
         const int w = cnt & 3;
         pend.x = w == 0 ? e : pend.x; pend.y = w == 1 ? e : pend.y; pend.z = w == 2 ? e : pend.z; pend.w = w == 3 ? e : pend.w;
-        if (w == 3 && cnt < c.cap) row_store4(row + (size_t)(cnt >> 2) * 256u, pend);
+        if (w == 3 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
         return;
     }
     if (stage && cnt < kRowStage) stage[cnt * 64 + lane] = e;
@@ -1289,7 +1277,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     }
     if (valid) nbrCount[i] = cnt;
     if (valid && cnt > c.cap && c.overflowMax) atomicMax(c.overflowMax, cnt);     // (rare: the host enlarges the rows, SweepCache::tuneRowCapacity)
-    if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) row_store4(row + (size_t)(cnt >> 2) * 256u, pend);
+    if (SPHX_BUILD_REGSTAGE && !stage && valid && (cnt & 3) != 0 && cnt < c.cap) *reinterpret_cast<uint4*>(row + (size_t)(cnt >> 2) * 256u) = pend;
     if (stage) {                                  // one coalesced 1 KB store per chunk index (slots past a row's end hold
         wave_lds_fence();                         // stale stage contents: readers never look past nbrCount)
         int top = valid ? min(min(cnt, c.cap), kRowStage) : 0;

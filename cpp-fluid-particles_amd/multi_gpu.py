@@ -55,7 +55,7 @@ def run_slab_bench(args, rank, world, local_rank):
         group.step(args.warmup)
     # live roofline leg (rank 0's slab): hipEvents around every launch of the dominant kernel on the engine stream
     span = "density_error"
-    if rank == 0 and P.solver == sphx.DFSPH:
+    if P.solver == sphx.DFSPH:
         sphx.kernel_timer(True, span)
 
     def barrier():
@@ -63,14 +63,21 @@ def run_slab_bench(args, rank, world, local_rank):
         if world > 1:
             dist.barrier()
 
+    comm0 = group.comm_info()
+    if world > 1 and comm0["transport"] == "rccl" and comm0["ranks"] != world:
+        # (-1 = the library does not export ncclCommCount; anything else must be the launcher's world size)
+        if comm0["ranks"] != -1:
+            raise SystemExit("rank %d: the RCCL communicator reports %d ranks, the launcher %d" % (rank, comm0["ranks"], world))
+    wait0 = group.wait_seconds()
     barrier()
     t0 = time.perf_counter()
     group.step(args.steps)
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    wall_local = time.perf_counter() - t0
     barrier()
+    wall = wall_local
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64)
+        w = torch.tensor([wall_local], dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     if P.solver == sphx.DFSPH:
@@ -82,23 +89,11 @@ def run_slab_bench(args, rank, world, local_rank):
         bpp, what = 300 + 104 * P.pbd_iters + 72, "PBD(%d Jacobi iters)" % P.pbd_iters
     steps_per_s = args.steps / wall
     infos = [group.info(i) for i in range(slabs_here)]
-    result = {
-        "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s,
-        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic"
-                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt),
-                   "particles": n_total,
-                   "decomposition": "%d x-slabs; this process: columns %s, owned/held particles %s; transport %s; %s"
-                                    % (world if world > 1 else slabs_here, [(a, b) for a, b, _, _ in infos], [(o, h) for _, _, o, h in infos],
-                                       transport, "stage-then-exchange" if flags else "edge-first stages, halo overlapped with interior sweeps"),
-                   "host_wait_seconds_rank0": group.wait_seconds(),
-                   "step_algorithmic_bytes_per_particle": bpp,
-                   "step_algorithmic_GBps": bpp * n_total * steps_per_s / 1e9,
-                   "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
-        "roofline": None,
-    }
-    if rank == 0 and P.solver == sphx.DFSPH:
+    comm1 = group.comm_info()
+
+    # this rank's own record: what it ran on, what it owned, how long IT took, what it sent -- and its own roofline leg
+    roof = None
+    if P.solver == sphx.DFSPH:
         spans = sphx.kernel_timer_collect()
         sphx.kernel_timer(False)
         if span in spans and spans[span][1] > 0:
@@ -110,10 +105,47 @@ def run_slab_bench(args, rank, world, local_rank):
             owned = sum(o for _, _, o, _ in infos) / float(slabs_here)
             per_launch = 44.0 * owned                                   # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s'), rank 0's slab, owned particles" % span,
-                                  "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                                  "traffic": None, "avg_launch_ms": avg_ms, "launches": logical,
-                                  "algorithmic_bytes_per_launch": per_launch}
+            roof = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE> (span '%s'), this rank's slab(s), owned particles" % span,
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": logical, "algorithmic_bytes_per_launch": per_launch}
+    mine = {"rank": rank, "local_rank": local_rank, "device_pci_id": sphx.device_pci_id(local_rank),
+            "device_name": torch.cuda.get_device_name(local_rank),
+            "slabs": [{"columns": [a, b], "owned": o, "held": h} for a, b, o, h in infos],
+            "ms_per_step": wall_local * 1e3 / args.steps, "host_wait_seconds": group.wait_seconds() - wait0,
+            "rccl": {"transport": comm1["transport"], "comm_ranks": comm1["ranks"], "comm_rank": comm1["rank"]},
+            "halo_bytes_sent_per_step": (comm1["bytes_sent"] - comm0["bytes_sent"]) / float(args.steps),
+            "halo_bytes_received_per_step": (comm1["bytes_received"] - comm0["bytes_received"]) / float(args.steps),
+            "exchanges_per_step": (comm1["exchanges"] - comm0["exchanges"]) / float(args.steps),
+            "allreduces_per_step": (comm1["allreduces"] - comm0["allreduces"]) / float(args.steps),
+            "roofline": roof}
+    per_rank = [mine]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+    ms = [r["ms_per_step"] for r in per_rank]
+    owned_all = [sum(sl["owned"] for sl in r["slabs"]) for r in per_rank]
+    result = {
+        "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s,
+        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic"
+                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt),
+                   "particles": n_total,
+                   "decomposition": "%d x-slabs; transport %s; %s" % (world if world > 1 else slabs_here, transport,
+                                    "stage-then-exchange" if flags else "edge-first stages, halo overlapped with interior sweeps"),
+                   "step_algorithmic_bytes_per_particle": bpp,
+                   "step_algorithmic_GBps": bpp * n_total * steps_per_s / 1e9,
+                   "step_hbm_roofline_frac_of_job": bpp * n_total * steps_per_s / 1e9 / (8000.0 * world)},
+        # self-verification of a multi-process run: what RCCL itself says about the communicator, which physical device every
+        # rank used, and every rank's own clock, ownership, traffic and roofline leg
+        "rccl": {"ranks": comm1["ranks"], "transport": comm1["transport"], "world_size_launcher": world,
+                 "distinct_devices": len({r["device_pci_id"] for r in per_rank}) if world > 1 else 1},
+        "ranks": per_rank,
+        "rank_ms_per_step": {"min": min(ms), "max": max(ms)},
+        "owned_particles": {"min": min(owned_all), "max": max(owned_all), "total": sum(owned_all)},
+        "roofline": per_rank[0]["roofline"],
+    }
     group.close()
     if world > 1:
         dist.barrier()

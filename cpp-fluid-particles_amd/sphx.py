@@ -33,7 +33,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
-    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
+    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -276,7 +276,15 @@ def sample_triangles(tri, spacing):
 SLAB_NO_OVERLAP, SLAB_SWEEP_GHOSTS = 1, 2
 SLAB_EXPORTS = ["sphx_slab_rccl_unique_id", "sphx_slab_create", "sphx_slab_destroy", "sphx_slab_step", "sphx_slab_info",
                 "sphx_slab_gather", "sphx_slab_iters", "sphx_slab_system", "sphx_slab_wait_seconds", "sphx_slab_set_rebalance",
-                "sphx_slab_plan_cuts", "sphx_slab_plan_capacity", "sphx_slab_cut_rule"]
+                "sphx_slab_plan_cuts", "sphx_slab_plan_capacity", "sphx_slab_cut_rule", "sphx_slab_comm_info"]
+
+
+def device_pci_id(ordinal):
+    """PCI bus id of HIP device `ordinal` (hipDeviceGetPCIBusId), e.g. '0000:05:00.0'"""
+    buf = C.create_string_buffer(64)
+    lib().sphx_device_pci_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    _check(lib().sphx_device_pci_id(int(ordinal), buf, 64))
+    return buf.value.decode()
 
 
 def slab_plan_cuts(params, fluid, world):
@@ -370,6 +378,16 @@ class SlabGroup:
         a, b = C.c_int(), C.c_int()
         _check(lib().sphx_slab_iters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def comm_info(self):
+        """the transport as it reports itself: kind, ranks and own rank of the communicator (ncclCommCount / ncclCommUserRank),
+        payload bytes sent / received, exchanges and all-reduces posted by this process"""
+        kind, ranks, rank = C.c_int(), C.c_int(), C.c_int()
+        ctr = (C.c_longlong * 4)()
+        lib().sphx_slab_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+        _check(lib().sphx_slab_comm_info(self._h, C.byref(kind), C.byref(ranks), C.byref(rank), ctr))
+        return {"transport": "rccl" if kind.value == 1 else "loopback", "ranks": ranks.value, "rank": rank.value,
+                "bytes_sent": int(ctr[0]), "bytes_received": int(ctr[1]), "exchanges": int(ctr[2]), "allreduces": int(ctr[3])}
 
     def wait_seconds(self):
         v = C.c_double()

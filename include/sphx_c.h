@@ -114,6 +114,8 @@ const char *sphx_last_error(void);
 int  sphx_device_count(void);                         /* hipGetDeviceCount; 0 when no GPU */
 int  sphx_set_device(int ordinal);                    /* hipSetDevice (one process per GPU) */
 int  sphx_sizeof_params(void);
+/* PCI bus id of HIP device `ordinal` ("0000:05:00.0"): lets a multi-process run state which physical device each rank used */
+int  sphx_device_pci_id(int ordinal, char *out, int capacity);
 
 /* scene of main.cpp:54-117, scaled by nx/24 as BASELINE.md §4 prescribes (nx=24: the reference
  * scene).  Two-call protocol: counts first, then fill caller-owned host buffers.              */

@@ -84,6 +84,11 @@ int sphx_slab_gather(sphx_slab_group *g, int index, int capacity, int *ids, floa
 int sphx_slab_iters(const sphx_slab_group *g, int *divergence_iters, int *density_iters);
 /* the engine system of local slab `index` (for sphx_kernel_timer / sphx_device_ptr); owned by the group */
 int sphx_slab_system(const sphx_slab_group *g, int index, sphx_system **sys);
+/* The transport as it reports itself (bench.py --gpus N puts this into its line so that a scaling run can be checked):
+ * transport_kind 0 = loopback copies, 1 = RCCL; comm_ranks / comm_rank = ncclCommCount / ncclCommUserRank of the
+ * communicator THIS process joined (-1: the library does not export them); counters4 = payload bytes sent, payload bytes
+ * received, grouped send/recv rounds and all-reduces posted by this process since creation.                             */
+int sphx_slab_comm_info(const sphx_slab_group *g, int *transport_kind, int *comm_ranks, int *comm_rank, long long counters4[4]);
 /* seconds this process spent in host-side waits for exchanges since creation (diagnostic) */
 int sphx_slab_wait_seconds(const sphx_slab_group *g, double *seconds);
 

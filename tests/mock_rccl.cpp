@@ -312,6 +312,8 @@ int ncclAllReduce(const void* in, void* out, size_t count, int type, int op, Com
     return 0;
 }
 
+int ncclCommCount(const Comm* c, int* count) { if (!c || !count) return fail("ncclCommCount: bad argument"); *count = c->world; return 0; }
+int ncclCommUserRank(const Comm* c, int* rank) { if (!c || !rank) return fail("ncclCommUserRank: bad argument"); *rank = c->rank; return 0; }
 const char* ncclGetErrorString(int r) { return r == 0 ? "no error" : "mock_rccl error (see stderr)"; }
 
 }  // extern "C"

@@ -40,4 +40,7 @@ def test_sweep_kernels_have_no_spills_and_uniform_base_gathers():
             mix = out[i + 1]
             assert "main loop" in mix
             assert re.search(r"gathers uniform-base 8, per-lane-base 0", mix), mix      # 4 chunks x (position + velocity)
+            assert "issued together" in mix, mix      # (r04: one extra live register made the compiler wait after every row load: +16 %)
+        if "k_rate_quad<true, 2, 1>" in name:         # ... and its tolerance twin
+            assert "issued together" in out[i + 1], out[i + 1]
     assert seen_rate

@@ -243,6 +243,19 @@ def test_bench_launch_line_two_ranks(tmp_path):
     assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1000.0) < 1.0
     assert r["config"]["particles"] == 40 * 60 * 40 and "2 x-slabs" in r["config"]["decomposition"]
     assert r["roofline"] and r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
+    # the line verifies itself: the communicator as the RCCL library reports it, every rank's device, clock, ownership,
+    # traffic and roofline leg
+    assert r["rccl"] == {"ranks": 2, "transport": "rccl", "world_size_launcher": 2, "distinct_devices": 1}      # (one-GPU box: both ranks on device 0)
+    assert [q["rank"] for q in r["ranks"]] == [0, 1] and [q["rccl"]["comm_rank"] for q in r["ranks"]] == [0, 1]
+    for q in r["ranks"]:
+        assert q["rccl"]["comm_ranks"] == 2 and q["rccl"]["transport"] == "rccl"
+        assert len(q["device_pci_id"]) >= 7 and q["device_name"]
+        assert q["ms_per_step"] > 0 and q["host_wait_seconds"] >= 0
+        assert q["halo_bytes_sent_per_step"] > 0 and q["halo_bytes_received_per_step"] > 0 and q["exchanges_per_step"] >= 10
+        assert q["roofline"] and 0 < q["roofline"]["frac"] < 1
+    assert r["ranks"][0]["halo_bytes_sent_per_step"] == r["ranks"][1]["halo_bytes_received_per_step"]
+    assert sum(sl["owned"] for q in r["ranks"] for sl in q["slabs"]) == r["owned_particles"]["total"] == 40 * 60 * 40
+    assert r["rank_ms_per_step"]["max"] <= r["ms_per_step"] * 1.001 and r["rank_ms_per_step"]["min"] > 0
 
 
 @pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("pbd", False), ("dfsph", True)])

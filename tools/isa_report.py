@@ -44,7 +44,20 @@ def loop_mix(body):
     if not best:
         return None
     mix = {"total": len(best), "valu": 0, "valu_pk": 0, "valu_trans": 0, "salu": 0, "branch": 0, "vmem_row": 0,
-           "gather_saddr": 0, "gather_vaddr": 0, "waitcnt": 0, "lds": 0}
+           "gather_saddr": 0, "gather_vaddr": 0, "waitcnt": 0, "lds": 0, "row_loads_split": 0}
+    # the row loads of a trip must be in flight TOGETHER: a "load, wait, load, wait" sequence (what the compiler falls back to
+    # when the kernel is one VGPR over its budget; r04: +16 % on the dominant launch) shows as waits between the row loads
+    seen_row, pending_wait = 0, False
+    for l in best:
+        op = l.split()[0]
+        if op.startswith("global_load") and op.endswith("dword") and "off" in l:
+            if seen_row and pending_wait:
+                mix["row_loads_split"] += 1
+            seen_row += 1; pending_wait = False
+        elif op == "s_waitcnt" and "vmcnt" in l and seen_row:
+            pending_wait = True
+        elif op.startswith("global_load"):
+            break                                    # the gathers begin: the row loads of this trip are over
     for l in best:
         op = l.split()[0]
         if op.startswith("s_cbranch") or op.startswith("s_branch"):
@@ -98,9 +111,10 @@ def report(unit):
             m = loop_mix(body)
             if m:
                 print("      main loop (4 row entries per trip): %d instr | VALU %d (packed %d, transcendental %d) | SALU %d | "
-                      "branches %d | waitcnt %d | row loads %d | gathers uniform-base %d, per-lane-base %d | LDS %d"
+                      "branches %d | waitcnt %d | row loads %d (%s) | gathers uniform-base %d, per-lane-base %d | LDS %d"
                       % (m["total"], m["valu"], m["valu_pk"], m["valu_trans"], m["salu"], m["branch"], m["waitcnt"],
-                         m["vmem_row"], m["gather_saddr"], m["gather_vaddr"], m["lds"]))
+                         m["vmem_row"], "issued together" if m["row_loads_split"] == 0 else "SERIALISED by %d waits" % m["row_loads_split"],
+                         m["gather_saddr"], m["gather_vaddr"], m["lds"]))
     print()
 
 

@@ -8,10 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, key = sys.argv[1], sys.argv[2]
 src = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % tag)))["k_rate_density"]
 entry = {
-    "kernel": "k_rate_quad<true,2> (computeDensityError_CUDA, quad-per-particle walk), one launch at 10,288,500 particles",
+    "kernel": "k_rate_quad<true,2,%d> (computeDensityError_CUDA, quad-per-particle walk, %s arithmetic), one launch at 10,288,500 particles"
+              % ((1, "tolerance") if key.endswith("_tol") else (0, "strict")),
     "hbm_bytes_per_launch": src["hbm_bytes_fetch_x2"],
     "fetch_size_raw_bytes": src["FETCH_SIZE"], "write_size_bytes": src["WRITE_SIZE"],
-    "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes); separate --pmc passes",
+    "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes; calibrated for THIS path's "
+                  "access widths -- 16-byte and 4-byte streams, the quad walk's row read, 16-byte gathers -- in profiles/r04_ubench_tiles.txt: all x2); "
+                  "WRITE_SIZE exact for full records, a 4-byte update inside a 16-byte record is tallied as its whole 64-byte line; separate --pmc passes",
     "valu_issue_frac": src.get("valu_issue_frac"),
     "valu_instr_per_simd_per_clk_raw": src.get("valu_instr_per_simd_per_clk_raw"),
     "valu_note": "SQ_INSTS_VALU x 2.3 clk / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); 2.3 clk per wave64 fp32 instruction calibrated in "
@@ -26,5 +29,11 @@ entry = {
     "source": "profiles/%s_rocprofv3_dfsph10m_summary.txt (tools/profile_gpu.sh %s)" % (tag, tag),
 }
 path = os.path.join(ROOT, "profiles", "traffic.json")
-json.dump({key: entry}, open(path, "w"), indent=1)
+try:
+    table = json.load(open(path))
+except Exception:
+    table = {}
+table = {k: v for k, v in table.items() if v.get("source_hash") == entry["source_hash"]}     # entries of other source trees are stale
+table[key] = entry
+json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(entry, indent=1))

@@ -67,7 +67,7 @@ for sub in ("valu", "cache"):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for r in csv.DictReader(open(cc)):
         k = short(r["Kernel_Name"])
-        if "k_rate" in k or "OpCorrect" in k or "k_build_list" in k or "k_dfsph_head" in k:
+        if "k_rate" in k or "k_run_op" in k or "k_build_list" in k or "k_dfsph_head" in k:
             a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
     print("\n== %s pass, per-dispatch averages" % sub)
     for k, d in acc.items():
