@@ -169,7 +169,7 @@ int DFSPHSolver::correctDivergenceError(std::shared_ptr<SPHParticles>& fluids, c
             ScopedKernel t("divergence_correct");
             launch_op(correct, num);
         }
-        {
+        if (adaptive || iter + 1 < fixedDiv) {      // (fixed counts: the sweep behind the last correction has no reader, see step())
             ScopedKernel t("divergence_error");
             launch_rate<false, 0>(rate, num, adaptive);
         }
@@ -287,7 +287,10 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         int iter = 0;
         while (adaptive ? ((iter < 1 || totalError > divergenceErrorThreshold * num * rho0) && iter < maxIter) : (iter < fixedDiv)) {
             run(SPHX_PH_DIV_CORRECT);
-            run(SPHX_PH_DIV_ERROR, adaptive);
+            // The error sweep behind a correction feeds the NEXT correction and the termination test (DFSPHSolver.cu:347-361).
+            // With fixed counts nothing reads the one behind the last correction: error / stiffness (and posf.w) are rewritten by
+            // the density solve before anybody looks at them, so every field of the finished step is unchanged without it.
+            if (adaptive || iter + 1 < fixedDiv) run(SPHX_PH_DIV_ERROR, adaptive);
             ++iter;
             if (adaptive) totalError = readErrorTotal();
         }

@@ -646,7 +646,8 @@ struct sphx_slab_group {
         if (!adaptive) {
             for (; itDiv < v; ++itDiv) {
                 sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
-                sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA, SPHX_F_POSF});
+                // (fixed counts: the error sweep behind the LAST correction -- and its halo -- has no reader, DFSPHSolver::step)
+                if (itDiv + 1 < v) sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA, SPHX_F_POSF});
             }
         } else {       // DFSPHSolver.cu:347-361
             const float limit = global.dfsph_divergence_thr * (float)nGlobal * global.rho0;
