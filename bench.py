@@ -11,12 +11,13 @@ A "step" is one SPHSystem::step(): neighbour search + solver step.  Inputs are r
 before the timed region (the scene is uploaded by the constructor).
 
 Prints ONE JSON line (rank 0) with, besides the contract's keys:
-  value / roofline   the headline leg: --arith tolerance by default (the north star's contract: results within 1e-5 of the reference,
-                     integer cell indices bit-exact; the reference's own binary is built -use_fast_math) -- dominant kernel (density-error
+  value / roofline   the headline leg: --arith persistent by default (the north star's contract: results within 1e-5 of the reference,
+                     integer cell indices bit-exact; the reference's own binary is built -use_fast_math; neighbour rows kept across steps
+                     while a device-side check allows) -- dominant kernel (density-error
                      sweep) timed live with hipEvents over the timed region: HBM fraction from algorithmic bytes, FP32-VALU fraction from
                      counted pair evaluations, PMC traffic from profiles/traffic.json when that file was measured on THIS source tree
-  legs_by_arithmetic the same workload and window under the other contracts (strict = bit-exact IEEE, persistent = tolerance + rows
-                     kept across steps), each with its own live roofline block
+  legs_by_arithmetic the same workload and window under the other contracts (strict = bit-exact IEEE, tolerance = the same arithmetic as
+                     the headline with rows rebuilt every step), each with its own live roofline block
   steady_state       post-impact legs (ragged cells, wall contact): the 10 M scene under the reference's adaptive iteration
                      control and the 1 M config 3, >= 100 timed steps each, with neighbours-per-particle statistics
   configs            BASELINE configs 2, 3, 4 (263k WCSPH, 1M DFSPH, 1M PBD) and the reference scene (20,736 particles)
@@ -74,9 +75,10 @@ def parse():
     ap.add_argument("--slab-transport", default="loopback", choices=["loopback", "rccl"],
                     help="with --force-slab: device-to-device copies, or the installed RCCL (grouped sends to self on the communication stream)")
     ap.add_argument("--no-overlap", action="store_true", help="slab layer: stage-then-exchange instead of edge-first stages")
-    ap.add_argument("--arith", default="tolerance", choices=["strict", "tolerance", "persistent"],
-                    help="arithmetic contract of the HEADLINE leg: tolerance (default: the north star's 1e-5 contract; the reference's own "
-                         "binary is built -use_fast_math), persistent (tolerance + rows kept across steps) or strict (bit-exact IEEE)")
+    ap.add_argument("--arith", default="persistent", choices=["strict", "tolerance", "persistent"],
+                    help="arithmetic contract of the HEADLINE leg: persistent (default: the north star's 1e-5 contract -- the reference's own "
+                         "binary is built -use_fast_math -- with neighbour rows kept across steps), tolerance (the same arithmetic, rows rebuilt "
+                         "every step) or strict (bit-exact IEEE, the parity contract)")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()

@@ -354,3 +354,31 @@ def test_tolerance_engines_at_config_3_size_against_the_oracle(sphx, oracle):
     for g in engines:
         g.close()
     o.close()
+
+
+def test_tolerance_engines_at_headline_size_against_the_strict_engine(sphx):
+    """the headline workload itself (BASELINE config 5's 10,288,500 particles on one device, DFSPH(1,4)): 12 steps of the
+    tolerance engine and of the persistent-rows engine (bench.py's default leg) against the STRICT engine, which is
+    oracle-identical at the sizes the oracle reaches: ids, cell indices and the cell table equal, positions within 1e-5 of the
+    domain size, densities within 1e-5 of rho0, element by element; the persistent mode must have kept rows across steps"""
+    P, fluid, boundary = sphx.scene(190)
+    P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    runs = {}
+    for mode in (0, 1, 2):
+        Q = P.copy(); Q.reserved[3] = mode
+        runs[mode] = sphx.System(Q, fluid, boundary)
+    assert runs[0].n == 10288500
+    for batch in range(3):
+        for g in runs.values():
+            g.step_n(4)
+        ref = {f: runs[0].get(getattr(sphx, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F", "F_POS", "F_DENSITY")}
+        for mode in (1, 2):
+            g = runs[mode]
+            for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
+                assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, batch, f)
+            assert _rel(g.get(sphx.F_POS), ref["F_POS"], P.space[0]) <= TOL, (mode, batch)
+            assert _rel(g.get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0) <= TOL, (mode, batch)
+    in_use, builds, steps = runs[2].persistent_stats()
+    assert in_use and steps == 12 and builds < steps, (in_use, builds, steps)
+    for g in runs.values():
+        g.close()

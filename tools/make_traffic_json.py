@@ -26,7 +26,8 @@ entry = {
     "l2_hit_rate": src["TCC_HIT_sum"] / (src["TCC_HIT_sum"] + src["TCC_MISS_sum"]) if "TCC_HIT_sum" in src else None,
     "avg_launch_us_rocprof": src.get("avg_launch_us_rocprof"),
     "source_hash": src["source_hash"],
-    "source": "profiles/%s_rocprofv3_dfsph10m_summary.txt (tools/profile_gpu.sh %s)" % (tag, tag),
+    "source": "profiles/%s_rocprofv3_dfsph10m_%s_summary.txt (tools/profile_gpu.sh %s --arith %s)"
+              % (tag.replace("strict", ""), "strict" if tag.endswith("strict") else "headline", tag, "strict" if tag.endswith("strict") else "persistent"),
 }
 path = os.path.join(ROOT, "profiles", "traffic.json")
 try:
