@@ -111,6 +111,7 @@ struct SweepCache {
     int rangeOrderMin = 3000000;            // particles a range must hold to keep the tile schedule (SPHX_RANGE_ORDER_MIN; tests lower it)
     int rangeLo2 = -1, rangeHi2 = -1;       // a second range behind the first, swept by the SAME launches (the two edge layers of a slab)
     bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
+    bool strictRateInTol = true;             // tolerance mode, >= 4 M particles: rate sweeps on the strict quad kernel (SweepCache::ctx)
     const int* gate = nullptr;               // device word that switches the following sweeps off (SweepCtx::gate)
     // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps
     // re-test every pair against the true support, `staleFlag` (device) is raised by the position update when a

@@ -484,7 +484,18 @@ SweepCache::SweepCache(int num)
     if (const char* e = getenv("SPHX_DUO_MASK")) { duoMask = atoi(e); duoMaskLarge = 0; }   // ... and which with two lanes per particle
     if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
     if (const char* e = getenv("SPHX_BRICK")) brickWanted = atoi(e) != 0;      // compact-brick LDS stage under the tolerance arithmetic
+    if (brickWanted) {      //  the stage needs ~74 KB of dynamic LDS per block: parts with 64 KB (gfx942) cannot run it
+        int dev = 0, ldsMax = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+            (size_t)ldsMax < (size_t)(kBrickSlots + 1) * 2 * sizeof(float4) + 4096) {
+            (void)hipGetLastError();
+            fprintf(stderr, "sphx: SPHX_BRICK=1 ignored: this device offers %d bytes of LDS per block, the compact-brick stage needs %zu\n", ldsMax,
+                    (size_t)(kBrickSlots + 1) * 2 * sizeof(float4) + 4096);
+            brickWanted = false; brickFailed = true;
+        }
+    }
     if (const char* e = getenv("SPHX_BRICK_MIN")) brickMin = atoi(e);
+    if (const char* e = getenv("SPHX_TOL_STRICT_RATE")) strictRateInTol = atoi(e) != 0;      // A/B measurements
 }
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)
@@ -626,6 +637,12 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.buildCut = k.tCut;
     if ((skinRows || persistRows) && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.gate = gate;
+    // From 4 M particles on the rate sweeps of a tolerance-mode step take the STRICT quad kernel (bit-exact results are inside any
+    // tolerance): it is cut for 8 waves per SIMD where the tolerance walk needs 6, and once the sweep waits for the vector memory
+    // path that occupancy is worth more than the tolerance walk's fewer instructions (r04, 10.3 M: 0.787 vs 0.840 ms per launch;
+    // at 1 M the tolerance kernel wins, 0.053 vs 0.071 ms).  Not with persistent rows: their strict walk would re-derive the
+    // plain-operator predicate per pair.
+    c.plainBits = (tolerance && !(persistRows && skin > 0.0f) && !(skinRows && skin > 0.0f) && n >= 4000000 && strictRateInTol) ? 1 : 0;
     c.persist = (persistRows && skin > 0.0f && use && rowCell) ? 1 : 0;
     if (c.persist) { c.rowCell = rowCell->addr(); c.tileFmt = nullptr; }
     c.massUniform = allowPacked ? massUniform.addr() : nullptr;
@@ -651,7 +668,9 @@ void SweepCache::tuneRowCapacity(int stepsSinceLastCall)
 {
     if ((!capAuto && !listIsBrick) || !nbr) return;
     capCheckSteps += stepsSinceLastCall;
-    if (capCheckSteps < 8) return;
+    // (the opt-in brick schedule reports a brick it could not stage through a device flag and SKIPS that brick meanwhile: look at
+    // the flag at every call -- after every step() and every 16 steps of a stepN batch -- not every 8+ steps: ADVICE r03)
+    if (capCheckSteps < 8 && !listIsBrick) return;
     capCheckSteps = 0;
     int words[3] = {0, 0, 0};
     HIP_CALL(hipMemcpyAsync(words, rowOverflow.addr(), 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));

@@ -484,6 +484,7 @@ struct SweepCtx {
     // Adaptive solver loops without a host round trip per iteration (DFSPH): the launches of every possible iteration are enqueued
     // at once; once the device-side test of the |error| total has raised *gate the remaining ones leave at their first instruction.
     const int* gate;
+    int plainBits;                          // tolerance launches: row entries carry the plain-operator flag anyway (a sweep may take the strict kernel)
     int quad;                               // QuadBits: sweeps that run quad-per-particle (walk_row_quad)
     int duo;                                // QuadBits: sweeps that run two lanes per particle (walk_row_duo); quad wins where both are set
     int numTiles;                           // tiles this launch covers
@@ -1201,7 +1202,7 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
     // the plain-operator flag of an entry is read by the strict walks only (the tolerance arithmetic has no exact fast paths to
     // guard): launch-uniform
-    const bool wantPlain = c.k.tol == 0;
+    const bool wantPlain = c.k.tol == 0 || c.plainBits != 0;
     WaveRanges w; w.start = w.len = w.off = 0; w.ok = false;
     if (streamed) w = wave_ranges(c, (i >> 6) << 6);
 #pragma unroll 1

@@ -752,7 +752,12 @@ inline void launch_rate_kernel(const OpRate& o, int n)
     }
     if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     else if (o.c.nbr && (o.c.quad & kQuadRate)) {
-        if (o.c.k.tol) k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+        if (o.c.k.tol && o.c.plainBits && !o.c.brick) {      // tolerance mode at size: the strict kernel is the faster one (SweepCache::ctx)
+            OpRate s = o;
+            s.c.k.tol = 0;
+            k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(s.c), kWideBlock, 0, stream()>>>(s, n);
+        }
+        else if (o.c.k.tol) k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
         else k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
     }
     else if (o.c.nbr && (o.c.duo & kQuadRate)) k_rate_duo<DENSITY_MODE, WARM><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
