@@ -374,7 +374,7 @@ struct sphx_slab_group {
     double waitSeconds = 0.0;
     std::vector<Msg> sends, recvs;
     bool failed = false;        // a step threw: posted messages were dropped, slabs may be half-updated -> only destroy is allowed
-    hipStream_t edgeStream = nullptr;                     // DFSPH edge layers + their halo, beside the interior (SPHX_SLAB_EDGE_STREAM=0: off)
+    hipStream_t edgeStream = nullptr;                     // DFSPH / WCSPH edge layers + their halo, beside the interior (SPHX_SLAB_EDGE_STREAM=0: off)
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
 
     ~sphx_slab_group()
@@ -585,9 +585,9 @@ struct sphx_slab_group {
             postHalo(halo, false);
             return;
         }
-        if (edgeStream && global.solver == SPHX_DFSPH) {
-            // DFSPH: the edge layers and the interior of a stage are independent (both read the previous stage's output, each writes
-            // its own particles), so the edges -- one small launch -- and the halo they feed run on a stream of their own BESIDE the
+        if (edgeStream && global.solver != SPHX_PBD) {
+            // DFSPH and (r04) WCSPH: the edge layers and the interior of a stage are independent (both read the previous stage's output
+            // -- neighbour velocities through the vel4 mirror of the stage before --, each writes its own particles), so the edges -- one small launch -- and the halo they feed run on a stream of their own BESIDE the
             // interior instead of in front of it.  fork: the edge stream starts where the engine stream stands (halo of the previous
             // stage arrived, previous interior done); join: the engine stream's next work waits for the edges and, with the loopback
             // transport, for the halo copies behind them.  An error stage zeroes its accumulators before the fork; both parts add.
