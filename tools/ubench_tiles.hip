@@ -106,6 +106,61 @@ __global__ void __launch_bounds__(256) k_q4(Consts c, const float4* __restrict__
     if (valid && g == 0) st_out<NTOUT>(out + i, e);
 }
 
+// ---- Q4C: the quad walk on COMPACT rows: 16-bit entries = offsets into one of three windows of the particle (one per dx layer: the
+// candidates of a layer lie within two z-columns of each other in memory), window bases and the two split points per particle in a
+// 16-byte meta record.  Half the row stream; the price is the decode (two compares, two selects, one add per entry) and the meta load.
+template <bool TWO>
+__global__ void __launch_bounds__(256) k_q4c(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                             const unsigned short* __restrict__ rows16, const uint4* __restrict__ meta,
+                                             float* __restrict__ out, int n, int numTiles, int cap)
+{
+    const int tile = logical_block();
+    if (tile >= numTiles) return;
+    const int g = threadIdx.x & 3;
+    const int ip = tile * 64 + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+    const bool valid = ip < n;
+    const int i = valid ? ip : n - 1;
+    const float4 self = posm[i];
+    const float4 sv = vel4[i];
+    const uint4 m = meta[i];
+    const int cnt = valid ? (int)(m.w & 1023u) : 0, s1 = (int)((m.w >> 10) & 1023u), s2 = (int)((m.w >> 20) & 1023u);
+    const unsigned short* rowq = rows16 + row_base_offset(i, cap) + g;
+    int steps = (cnt + 3) >> 2;
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    float e = 0.0f;
+    auto chunks = [&](auto UC, int s) {
+        constexpr int U = decltype(UC)::value;
+        unsigned int idx[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 4 * (s + u) + g;
+            ok[u] = k < cnt;
+            const unsigned int off = rowq[(size_t)(s + u) * 256u];
+            const unsigned int base = k >= s2 ? m.z : (k >= s1 ? m.y : m.x);
+            idx[u] = ok[u] ? base + off : 0u;
+        }
+        float4 pj[U], vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float dx = self.x - pj[u].x, dy = self.y - pj[u].y, dz = self.z - pj[u].z;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            e += pair_tol_d(c, dx, dy, dz, r2, sv.x - vj[u].x, sv.y - vj[u].y, sv.z - vj[u].z, ok[u] ? pj[u].w : 0.0f);
+        }
+    };
+    int s = 0;
+    for (; s + 4 <= steps; s += 4) chunks(std::integral_constant<int, 4>{}, s);
+    for (; s < steps; ++s) chunks(std::integral_constant<int, 1>{}, s);
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xB1, 0xf, 0xf, true));
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x4E, 0xf, 0xf, true));
+    if (valid && g == 0) out[i] = e;
+}
+
 // ---- shared: the candidate runs of one cell (9 (dx,dy) columns, each the contiguous particles of cells z-1..z+1) ---------------------
 struct CellRuns { int vd, vp, total; };
 // candidate t of run k is particle t + o_k for p_k <= t < p_(k+1).  Lane k (< 9) holds p_k in vp and o_k - o_(k-1) in vd (o_0 in lane 0);
@@ -641,6 +696,48 @@ int main(int argc, char** argv)
             }
         }
         CK(hipFree(dPos2)); CK(hipFree(dVel2));
+    }
+
+    if (strchr(modes, 'k')) {      // COMPACT rows: 16-bit window offsets + a 16-byte meta record per particle
+        std::vector<unsigned int> ra(rowWords);
+        CK(hipMemcpy(ra.data(), dRowsA, 4 * rowWords, hipMemcpyDeviceToHost));
+        std::vector<unsigned short> r16(rowWords, 0);
+        std::vector<uint4> meta(n);
+        long long overflow = 0;
+        for (int i = 0; i < n; ++i) {
+            const int cc = scell[i], cz = cc % gz, cy = (cc / gz) % gy, cx = cc / (gz * gy);
+            unsigned int base[3]; int split[2] = {0, 0};
+            for (int d = 0; d < 3; ++d) {
+                const int X = std::min(std::max(cx + d - 1, 0), gx - 1), Y = std::max(cy - 1, 0), Z = std::max(cz - 1, 0);
+                base[d] = (unsigned)cs[(X * gy + Y) * gz + Z];
+            }
+            const int m = std::min(ca[i], kCap);
+            const size_t rb = ((size_t)(i >> 6) * kCap) * 64u + (size_t)(i & 63) * 4u;
+            int k = 0;
+            for (; k < m; ++k) {
+                const unsigned int j = ra[rb + (size_t)(k >> 2) * 256u + (k & 3)] & kIndexMask;
+                const int jc = scell[j], jx = jc / (gz * gy);
+                const int d = jx - cx + 1;
+                if (d >= 1 && split[0] == 0 && k > 0 && false) {}
+                const unsigned int off = j - base[d];
+                if (off > 65535u) ++overflow;
+                r16[rb + (size_t)(k >> 2) * 256u + (k & 3)] = (unsigned short)off;
+                if (d == 0) { split[0] = k + 1; split[1] = k + 1; }
+                else if (d == 1) split[1] = k + 1;
+            }
+            meta[i] = make_uint4(base[0], base[1], base[2], (unsigned)m | ((unsigned)split[0] << 10) | ((unsigned)split[1] << 20));
+        }
+        printf("compact rows: %lld offsets beyond 16 bits\n", overflow);
+        unsigned short* dR16; uint4* dMeta;
+        CK(hipMalloc(&dR16, 2 * rowWords)); CK(hipMalloc(&dMeta, sizeof(uint4) * (size_t)n));
+        CK(hipMemcpy(dR16, r16.data(), 2 * rowWords, hipMemcpyHostToDevice)); CK(hipMemcpy(dMeta, meta.data(), sizeof(uint4) * (size_t)n, hipMemcpyHostToDevice));
+        for (int two = 1; two >= 0; --two) {
+            char nm[96]; snprintf(nm, sizeof(nm), "Q4C compact 16-bit rows + 16 B meta tol %s", two ? "2f" : "1f");
+            run(nm, two, [&] {
+                if (two) hipLaunchKernelGGL((k_q4c<true>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dR16, dMeta, dOut, n, numTiles, kCap);
+                else hipLaunchKernelGGL((k_q4c<false>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dR16, dMeta, dOut, n, numTiles, kCap); });
+        }
+        CK(hipFree(dR16)); CK(hipFree(dMeta));
     }
 
     if (strchr(modes, 'c')) {      // calibration dispatches (run once each; read FETCH_SIZE / WRITE_SIZE per dispatch from rocprofv3 --pmc)
