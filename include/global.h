@@ -37,7 +37,9 @@ void report_hip_error(hipError_t e, const char* file, int line);
         hipError_t sphx_e_ = (x);                                           \
         if (sphx_e_ != hipSuccess) ::sphx::report_hip_error(sphx_e_, __FILE__, __LINE__); \
     } while (0)
-// source compatibility with drivers written against the reference headers
+// API surface, not a compatibility layer: `CUDA_CALL` is the NAME the reference's header gives this macro (global.h:23) and a
+// driver written against it uses.  It is the only CUDA-named symbol of the product and expands to the HIP macro above; there is
+// no second code path behind it, and nothing in the engine uses it.
 #define CUDA_CALL(x) HIP_CALL(x)
 #define CHECK_KERNEL() HIP_CALL(hipGetLastError())
 
