@@ -13,7 +13,8 @@ for tag in sys.argv[1:] or ["r04"]:
     out = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     per = defaultdict(dict)
     for sub in ("fetch", "write", "valu", "cache"):
-        for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        # (gpurun_out/ accumulates over calls: only the newest file of a pass belongs to the last collection)
+        for f in sorted(glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
@@ -23,7 +24,7 @@ for tag in sys.argv[1:] or ["r04"]:
                 for c, (t, n) in d.items():
                     per[k][c] = t / n
     us = {}
-    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             us[short(r["Name"])] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
     print("== %s: counters per launch at 10,288,500 particles (VALU issue = SQ_INSTS_VALU x 2.3 clk / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); HBM = FETCH_SIZE x 2 + WRITE_SIZE)" % tag)
