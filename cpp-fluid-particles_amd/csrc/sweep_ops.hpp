@@ -41,8 +41,15 @@ template <int TOLK> __device__ __forceinline__ void assume_arith(const SweepCtx&
     if constexpr (TOLK == 0) __builtin_assume(c.k.tol == 0);
     if constexpr (TOLK == 1) __builtin_assume(c.k.tol != 0);
 }
+// (occupancy of the tolerance quad walks: experiments with -DSPHX_RUNOP_TOL_WAVES / -DSPHX_HEAD_TOL_WAVES)
+#ifndef SPHX_RUNOP_TOL_WAVES
+#define SPHX_RUNOP_TOL_WAVES SPHX_MINWAVES
+#endif
+#ifndef SPHX_HEAD_TOL_WAVES
+#define SPHX_HEAD_TOL_WAVES SPHX_MINWAVES
+#endif
 template <class Op, bool STREAM, int MODE = 0, int TOLK = -1>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_run_op(const Op op, int n)
+__global__ void __launch_bounds__(kWideBlock, (MODE == 1 && TOLK == 1) ? SPHX_RUNOP_TOL_WAVES : SPHX_MINWAVES) k_run_op(const Op op, int n)
 {
     (void)n;
     assume_arith<TOLK>(op.c);
@@ -581,7 +588,7 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head(const 
     if (WITH_RATE && o.out.accum) accumulate_error(fixed, o.out.accum);
 }
 template <bool WITH_RATE, int MODE, int TOLK = -1>
-__global__ void __launch_bounds__(kWideBlock, SPHX_MINWAVES) k_dfsph_head_group(const OpDfsphHeadT<WITH_RATE> o, int n)
+__global__ void __launch_bounds__(kWideBlock, (MODE == 1 && TOLK == 1) ? SPHX_HEAD_TOL_WAVES : SPHX_MINWAVES) k_dfsph_head_group(const OpDfsphHeadT<WITH_RATE> o, int n)
 {
     assume_arith<TOLK>(o.c);
     const int i = MODE == 1 ? quad_particle(o.c) : duo_particle(o.c);

@@ -161,6 +161,64 @@ __global__ void __launch_bounds__(256) k_q4c(Consts c, const float4* __restrict_
     if (valid && g == 0) out[i] = e;
 }
 
+// ---- Q4P: the quad walk with ONE gather per pair for the two-field sweep: position and velocity packed into a single 16-byte record.
+// Position: per axis (cell mod 4) : 19..20-bit fraction of the cell length (21 + 21 + 22 bits) -- differences of two records wrap to the
+// signed distance as long as the cells differ by at most one, which every row entry guarantees; at 10 M particles fp32 positions
+// themselves resolve only 2.4e-5 of a cell.  Velocity: three 21-bit signed fixed-point components on a common scale (here 8 m/s range).
+// Costs ~25 more VALU instructions per pair for the unpacking; saves one of the two gather instructions.
+struct QScale { float posStep21, posStep22, velStep; };
+__device__ __forceinline__ int wrap21(int d) { return (d << 11) >> 11; }
+__device__ __forceinline__ int wrap22(int d) { return (d << 10) >> 10; }
+__global__ void __launch_bounds__(256) k_q4p(Consts c, QScale qs, const uint4* __restrict__ qpv, const float4* __restrict__ posm,
+                                             const unsigned int* __restrict__ rows, const int* __restrict__ counts,
+                                             float* __restrict__ out, int n, int numTiles, int cap)
+{
+    const int tile = logical_block();
+    if (tile >= numTiles) return;
+    const int g = threadIdx.x & 3;
+    const int ip = tile * 64 + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+    const bool valid = ip < n;
+    const int i = valid ? ip : n - 1;
+    const uint4 own = qpv[i];
+    const int ox = (int)(own.x & 0x1fffffu), oy = (int)(((own.x >> 21) | (own.y << 11)) & 0x1fffffu), oz = (int)(own.y >> 10);
+    const int ovx = (int)(own.z & 0x1fffffu), ovy = (int)(((own.z >> 21) | (own.w << 11)) & 0x1fffffu), ovz = (int)(own.w >> 10);
+    const float m0 = posm[0].w;
+    const int cnt = valid ? min(counts[i], cap) : 0;
+    const unsigned int* rowq = rows + row_base_offset(i, cap) + g;
+    int steps = (cnt + 3) >> 2;
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    float e = 0.0f;
+    auto chunks = [&](auto UC, int s) {
+        constexpr int U = decltype(UC)::value;
+        unsigned int idx[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = 4 * (s + u) + g < cnt;
+            const unsigned int raw = rowq[(size_t)(s + u) * 256u];
+            idx[u] = ok[u] ? raw : 0u;
+        }
+        uint4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qpv) + ((size_t)(idx[u] & kIndexMask) << 4));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jx = (int)(r[u].x & 0x1fffffu), jy = (int)(((r[u].x >> 21) | (r[u].y << 11)) & 0x1fffffu), jz = (int)(r[u].y >> 10);
+            const int jvx = (int)(r[u].z & 0x1fffffu), jvy = (int)(((r[u].z >> 21) | (r[u].w << 11)) & 0x1fffffu), jvz = (int)(r[u].w >> 10);
+            const float dx = (float)wrap21(ox - jx) * qs.posStep21, dy = (float)wrap21(oy - jy) * qs.posStep21, dz = (float)wrap22(oz - jz) * qs.posStep22;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float dvx = (float)wrap21(ovx - jvx), dvy = (float)wrap21(ovy - jvy), dvz = (float)wrap22(ovz - jvz) * 0.5f;
+            e += pair_tol_d(c, dx, dy, dz, r2, dvx, dvy, dvz, ok[u] ? m0 * qs.velStep : 0.0f);
+        }
+    };
+    int s = 0;
+    for (; s + 4 <= steps; s += 4) chunks(std::integral_constant<int, 4>{}, s);
+    for (; s < steps; ++s) chunks(std::integral_constant<int, 1>{}, s);
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xB1, 0xf, 0xf, true));
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x4E, 0xf, 0xf, true));
+    if (valid && g == 0) out[i] = e;
+}
+
 // ---- shared: the candidate runs of one cell (9 (dx,dy) columns, each the contiguous particles of cells z-1..z+1) ---------------------
 struct CellRuns { int vd, vp, total; };
 // candidate t of run k is particle t + o_k for p_k <= t < p_(k+1).  Lane k (< 9) holds p_k in vp and o_k - o_(k-1) in vd (o_0 in lane 0);
@@ -738,6 +796,32 @@ int main(int argc, char** argv)
                 else hipLaunchKernelGGL((k_q4c<false>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dR16, dMeta, dOut, n, numTiles, kCap); });
         }
         CK(hipFree(dR16)); CK(hipFree(dMeta));
+    }
+
+    if (strchr(modes, 'p')) {      // PACKED record: quantised position + velocity in one 16-byte gather
+        std::vector<uint4> q(n + 1);
+        const float vRange = 8.0f;                               // |v| < 8 m/s on a 21-bit signed grid (22 bits for z)
+        QScale qs; qs.posStep21 = cellLength / 524288.0f; qs.posStep22 = cellLength / 1048576.0f; qs.velStep = vRange / 1048576.0f;
+        for (int k = 0; k <= n; ++k) {
+            auto qp = [&](float x, int fracBits) {
+                const double t = (double)x / (double)cellLength; const long long cellI = (long long)floor(t);
+                long long f = (long long)floor((t - (double)cellI) * (double)(1 << fracBits)); if (f < 0) f = 0; if (f >= (1 << fracBits)) f = (1 << fracBits) - 1;
+                return (unsigned long long)(((cellI & 3) << fracBits) | f);
+            };
+            auto qv = [&](float v, int bits) {
+                const double step = (double)vRange / 1048576.0 * (bits == 22 ? 0.5 : 1.0);
+                long long t = llround((double)v / step); const long long lim = (1LL << (bits - 1)) - 1; t = std::max(-lim, std::min(lim, t));
+                return (unsigned long long)(t & ((1LL << bits) - 1));
+            };
+            const unsigned long long P64 = qp(posm[k].x, 19) | (qp(posm[k].y, 19) << 21) | (qp(posm[k].z, 20) << 42);
+            const unsigned long long V64 = qv(vel4[k].x, 21) | (qv(vel4[k].y, 21) << 21) | (qv(vel4[k].z, 22) << 42);
+            q[k] = make_uint4((unsigned)P64, (unsigned)(P64 >> 32), (unsigned)V64, (unsigned)(V64 >> 32));
+        }
+        uint4* dQ; CK(hipMalloc(&dQ, sizeof(uint4) * (size_t)(n + 1)));
+        CK(hipMemcpy(dQ, q.data(), sizeof(uint4) * (size_t)(n + 1), hipMemcpyHostToDevice));
+        run("Q4P packed 16-byte (quantised pos + vel) record tol 2f", 1, [&] {
+            hipLaunchKernelGGL(k_q4p, dim3(gridQ), dim3(256), 0, st, c, qs, dQ, dPos, dRowsA, dCntA, dOut, n, numTiles, kCap); });
+        CK(hipFree(dQ));
     }
 
     if (strchr(modes, 'c')) {      // calibration dispatches (run once each; read FETCH_SIZE / WRITE_SIZE per dispatch from rocprofv3 --pmc)
