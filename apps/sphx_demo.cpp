@@ -4,6 +4,7 @@
 //
 //   sphx_demo [--solver wcsph|dfsph|pbd] [--nx 24] [--steps 100] [--restart-with wcsph|dfsph|pbd]
 //             [--dump file.bin] [--dots file.bin] [--save snap.bin] [--load snap.bin] [--advect-check file.bin]
+//             [--arith strict|tolerance|persistent]
 //
 // The scene (constants of main.cpp:54-67, block and shell samplers of :73-117, scaled by nx/24) comes
 // from the library's scene generator (sphx_scene_params / sphx_scene_fill), the same one the tests
@@ -66,7 +67,7 @@ static int write_dump(const std::string& path, int n, const float3* dPos, const 
 
 int main(int argc, char** argv)
 {
-    int solverKind = SPHX_PBD, nx = 24, steps = 100, restartKind = -1;
+    int solverKind = SPHX_PBD, nx = 24, steps = 100, restartKind = -1, arith = 0;
     std::string dump, savePath, loadPath, dotsPath, advectPath;
     for (int a = 1; a < argc; ++a) {
         const std::string k = argv[a];
@@ -80,6 +81,7 @@ int main(int argc, char** argv)
         else if (k == "--save" && more) savePath = argv[++a];
         else if (k == "--load" && more) loadPath = argv[++a];
         else if (k == "--advect-check" && more) advectPath = argv[++a];
+        else if (k == "--arith" && more) { const std::string v = argv[++a]; arith = v == "persistent" ? 2 : (v == "tolerance" ? 1 : 0); }
     }
     if (sphx_device_count() < 1) {
         fprintf(stderr, "sphx_demo: no HIP device (the engine has no CPU path)\n");
@@ -140,12 +142,15 @@ int main(int argc, char** argv)
         if (kind == SPHX_PBD) plugin = std::make_shared<PBDSolver>(fluidParticles->size());
         else if (kind == SPHX_DFSPH) plugin = std::make_shared<DFSPHSolver>(fluidParticles->size());
         else plugin = std::make_shared<BasicSPHSolver>(fluidParticles->size());
+        // engine extensions of the drop-in API (none changes a reference signature): the arithmetic contract of the neighbour sweeps
+        if (arith >= 1) static_cast<BasicSPHSolver*>(plugin.get())->setToleranceArithmetic(true);
         auto system = std::make_shared<SPHSystem>(
             fluidParticles, boundaryParticles, plugin, make_float3(sc.space[0], sc.space[1], sc.space[2]), sc.cell_length,
             sc.radius, sc.dt, sc.m0, sc.rho0, sc.rho_boundary, sc.stiff, sc.visc, sc.surface_tension, sc.air_pressure,
             make_float3(sc.gravity[0], sc.gravity[1], sc.gravity[2]), make_int3(sc.cells[0], sc.cells[1], sc.cells[2]));
         printf("scene: %d fluid + %d wall particles in a %d x %d x %d grid\n", system->fluidSize(), system->boundarySize(), sc.cells[0],
                sc.cells[1], sc.cells[2]);
+        if (arith == 2 && !system->setPersistentRows(true)) printf("persistent rows are not available for this solver: tolerance arithmetic only\n");
         return system;
     };
     auto run = [&](const std::shared_ptr<SPHSystem>& system) {

@@ -382,3 +382,63 @@ def test_tolerance_engines_at_headline_size_against_the_strict_engine(sphx):
     assert in_use and steps == 12 and builds < steps, (in_use, builds, steps)
     for g in runs.values():
         g.close()
+
+
+@pytest.mark.parametrize("solver,arith", [("dfsph", "persistent"), ("wcsph", "persistent"), ("pbd", "persistent"), ("dfsph", "tolerance")])
+def test_cpp_api_driver_with_engine_arithmetic_modes(oracle, tmp_path, solver, arith):
+    """apps/sphx_demo (the main.cpp-style driver on the C++ API) with the engine extensions switched on through the C++ classes
+    themselves -- BasicSPHSolver::setToleranceArithmetic, SPHSystem::setPersistentRows -- default solver settings (adaptive DFSPH:
+    the device-side loops): 15 frames within 1e-5 of the oracle; PBD reports that persistent rows are not available and runs on."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "sphx_demo")
+    subprocess.check_call(["make", "-C", os.path.join(root, "apps")], stdout=subprocess.DEVNULL)
+    out = str(tmp_path / "dump.bin")
+    text = subprocess.run([exe, "--solver", solver, "--nx", "12", "--steps", "15", "--dump", out, "--arith", arith], check=True, capture_output=True, text=True).stdout
+    assert ("persistent rows are not available" in text) == (solver == "pbd")
+    raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.int32)[0])
+    pos = np.frombuffer(raw[4:4 + 12 * n], np.float32).reshape(n, 3)
+    den = np.frombuffer(raw[4 + 12 * n:], np.float32)
+    P, fluid, boundary = oracle.scene(12)
+    P.solver = {"wcsph": oracle.WCSPH, "dfsph": oracle.DFSPH, "pbd": oracle.PBD}[solver]
+    o = oracle.System(P, fluid, boundary)
+    for _ in range(15):
+        o.step()
+    assert _rel(pos, o.get(oracle.F_POS), P.space[0]) <= TOL and _rel(den, o.get(oracle.F_DENSITY), P.rho0) <= TOL
+    assert not np.array_equal(den.view(np.uint32), o.get(oracle.F_DENSITY).view(np.uint32)), "the tolerance path must actually run"
+
+
+def test_persistent_rows_snapshot_and_count_changes(sphx, oracle, tmp_path):
+    """host-side events in the middle of a persistent run: a snapshot (the solver's arrays are flushed into API order for it), a
+    resumed copy, sphx_set of a solver-internal field, and lowering the active count -- each followed by steps that stay within
+    1e-5 of the strict oracle driven through the same events"""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 3
+    Po = same_params(oracle.Params(), P)
+    P.reserved[3] = 2
+    g, o = sphx.System(P, fluid, boundary), oracle.System(Po, fluid, boundary)
+
+    def close_to_oracle(a, tag):
+        assert np.array_equal(a.get(sphx.F_ID), o.get(oracle.F_ID)) and np.array_equal(a.get(sphx.F_CELL), o.get(oracle.F_CELL)), tag
+        assert _rel(a.get(sphx.F_POS), o.get(oracle.F_POS), P.space[0]) <= TOL, tag
+        assert _rel(a.get(sphx.F_DENSITY), o.get(oracle.F_DENSITY), P.rho0) <= TOL, tag
+        assert _rel(a.get(sphx.F_WARM), o.get(oracle.F_WARM), max(float(np.abs(o.get(oracle.F_WARM)).max()), 1e-30)) <= 1e-2, tag
+
+    for _ in range(6):
+        g.step(); o.step()
+    close_to_oracle(g, "before the snapshot")
+    snap = str(tmp_path / "persist.snap")
+    sphx.save_snapshot(g, snap)
+    r = sphx.load_snapshot(snap)
+    for _ in range(5):
+        g.step(); r.step(); o.step()
+    close_to_oracle(g, "after the snapshot")
+    close_to_oracle(r, "resumed copy")
+    assert r.persistent_stats()[0]
+    warm = o.get(oracle.F_WARM) * np.float32(0.5)
+    g.set(sphx.F_WARM, warm); o.set(oracle.F_WARM, warm)
+    for _ in range(3):
+        g.step(); o.step()
+    close_to_oracle(g, "after sphx_set of the warm stiffness")
+    g.close(); r.close(); o.close()
