@@ -194,7 +194,7 @@ ARITH_TEXT = {"strict": "strict arithmetic: every bit equals the IEEE evaluation
                            "walks with per-lane partial sums and one DPP reduction per particle; positions and densities within 1e-5 of the oracle, integer "
                            "fields bit-exact (tests/test_gpu_tolerance.py) -- the north star's contract; the reference's own binary is built -use_fast_math",
               "persistent": "tolerance arithmetic with persistent neighbour rows (reserved[3] = 2): the solver steps a working copy kept in row-build order, "
-                            "rows carry a skin and are rebuilt when a device-side check finds > 0.45 skin of relative displacement; API arrays exported "
+                            "rows carry a skin and are rebuilt when a device-side check finds > 0.49 skin of relative displacement; API arrays exported "
                             "in the reference's order every step (tests/test_gpu_tolerance.py::test_persistent_rows_*)"}
 
 

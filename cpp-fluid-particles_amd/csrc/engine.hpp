@@ -125,6 +125,9 @@ struct SweepCache {
     DArray<int> staleFlag;                   // two flags: [activeFlag] is raised by the coming position updates; [2] counts rebuilds
     int activeFlag = 0;
     float staleLimit2() const { return (0.45f * skin) * (0.45f * skin); }
+    // persistent rows: a pair's separation changes by at most the sum of the two displacements (relative to the common drift), so
+    // 0.49 skin each keeps every pair within R now inside the R + skin of the build; against the static boundary: 0.98 skin in full
+    float persistLimit2() const { return (0.49f * skin) * (0.49f * skin); }
     // Persistent rows (SPHSystem's persistent mode; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems): the solver steps
     // arrays that keep the order of the last row build; rows carry a skin no larger than the slack of the cell length
     // (cellLength - R, so that the 27-cell candidate walk still sees every pair within R + skin) and are rebuilt only when the

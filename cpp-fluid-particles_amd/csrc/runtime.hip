@@ -724,7 +724,7 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     if (persistRows && skin > 0.0f) {
         // Persistent rows: the same launches every step -- copy of the cell table, then the builder -- and every wave of them
         // leaves at once unless the grid pass of this step raised persistFlags[0] (SPHSystem::persistentSearch: some particle
-        // moved more than 0.45 skin relative to the others since the build, or the host asked).  Graph-replayable.
+        // moved more than 0.49 skin relative to the others since the build, or the host asked).  Graph-replayable.
         const unsigned long long entries = (unsigned long long)((std::max(capN, n) + 63) / 64) * 64ull * (unsigned long long)cap;
         if ((unsigned long long)capN + (unsigned long long)nbCap > (unsigned long long)kIndexMask) { persistRows = false; flags |= kFlagNoList; ++generation; return; }
         if (!nbr || nbr->entries < entries) { nbr.reset(); nbr.reset(new RowStore(entries)); ++generation; requestRebuild(); }

@@ -475,7 +475,7 @@ struct SweepCtx {
     float buildCut;                         // squared cutoff the row builder accepts candidates with
     // Persistent rows (tolerance arithmetic, WCSPH / DFSPH; SPHSystem's persistent mode): the particle arrays keep the order of
     // the last row build across steps (the API arrays are exported in the reference's order separately), rows were built with
-    // the skin, every pair re-tests its CURRENT distance.  A row stays valid while no particle has moved more than 0.45 skin
+    // the skin, every pair re-tests its CURRENT distance.  A row stays valid while no particle has moved more than 0.45 skin (PBD skin rows; 0.49 skin for persistent rows)
     // RELATIVE to the others since the build (checked on the device at the start of every step), whatever cells the particles
     // are in by now: the neighbour set of the reference is {r <= R}, and the order of a particle's sum is free under this
     // contract.  Particles without a row (overflow) walk the cells around the cell their row was built around, in the cell

@@ -596,7 +596,7 @@ __global__ void k_persist_count(int* __restrict__ flags) { if (flags[0] != 0) fl
 // own displacement as c a block of fluid in free fall has d - c = 0 to rounding).
 // Boundary particles do not move, so against THEM a fluid particle's displacement counts in full (no common drift to take out):
 // a particle that is within reach of the boundary now -- one of the 27 cells around its cell holds boundary particles, nearWall --
-// asks for a rebuild once it has moved 0.9 skin in absolute terms.
+// asks for a rebuild once it has moved 0.98 skin in absolute terms.
 __global__ void k_near_wall(int* __restrict__ nearWall, const int* __restrict__ csB, GridDesc g)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -770,7 +770,7 @@ void SPHSystem::persistentSearch()
         ScopedKernel t("grid_cell_count");
         k_persist_cells<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), P, _work->getPosPtr(),
                                                          static_cast<const float4*>(pv.posBuild), _persist->nearWall->addr(), g, num, num / 2,
-                                                         pv.limit2, 4.0f * pv.limit2, pv.flags);      // 4 x (0.45 skin)^2 = (0.9 skin)^2
+                                                         pv.limit2, 4.0f * pv.limit2, pv.flags);      // 4 x (0.49 skin)^2 = (0.98 skin)^2
     }
     {
         ScopedKernel t("grid_scan");

@@ -61,7 +61,7 @@ BasicSPHSolver::PersistentView BasicSPHSolver::preparePersistent(int3 cellSize, 
         ++c.generation;
         c.requestRebuild();
     }
-    return PersistentView{c.persistRows, c.persistFlags.addr(), c.persistRows ? (const void*)c.posBuild->addr() : nullptr, c.staleLimit2()};
+    return PersistentView{c.persistRows, c.persistFlags.addr(), c.persistRows ? (const void*)c.posBuild->addr() : nullptr, c.persistLimit2()};
 }
 const int* BasicSPHSolver::enginePersistFlags() const { return _cache->persistRows ? _cache->persistFlags.addr() : nullptr; }
 void BasicSPHSolver::requestRowRebuild() { if (_cache->persistRows) _cache->requestRebuild(); }

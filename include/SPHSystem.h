@@ -78,7 +78,7 @@ public:
     void setAfterSortHook(std::function<void()> hook) { _afterSort = std::move(hook); }
     // Persistent neighbour rows (opt-in; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems; C ABI: reserved[3] = 2).
     // The solver steps a working copy of the fluid arrays that stays in the order of the last row build, the rows carry a skin
-    // and are rebuilt only when a device-side check finds that some particle has moved more than 0.45 skin relative to the
+    // and are rebuilt only when a device-side check finds that some particle has moved more than 0.49 skin relative to the
     // others; getFluids()' arrays, particle2Cell, getSortPerm() and the cell table are brought up to date in the reference's
     // order (stable sort by the cells of the step's starting positions) at the end of every step() as always.  Results meet the
     // tolerance contract, not the strict one (the order of a particle's sums follows the rows).  A caller that WRITES the fluid

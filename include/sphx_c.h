@@ -72,7 +72,7 @@ typedef struct sphx_params {
                                   the reference's own binary is built -use_fast_math, src/CMakeLists.txt:43) or
                                   SPHX_ARITH_TOLERANCE_PERSISTENT (2: the same arithmetic, and the neighbour rows of WCSPH /
                                   DFSPH carry a skin and survive from step to step until a device-side check finds that
-                                  some particle has moved more than 0.45 skin relative to the others; the API arrays, cell
+                                  some particle has moved more than 0.49 skin relative to the others; the API arrays, cell
                                   indices and the cell table are still brought up to date in the reference's order by
                                   every step -- SPHSystem::setPersistentRows in SPHSystem.h; needs cell_length > radius,
                                   whole-domain systems only; PBD runs as 1) */
