@@ -18,7 +18,7 @@
 //           (run under rocprofv3 --pmc; MI355X_MICROARCH.md: only wide coalesced reads are calibrated there)
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I cpp-fluid-particles_amd/csrc -I include tools/ubench_tiles.hip -o tools/ubench_tiles
-//   ./ubench_tiles [nx=88] [reps=20] [modes: any of q a b B c]
+//   ./ubench_tiles [nx=88] [reps=20] [modes: any of q a b B o k p h c]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -104,6 +104,79 @@ __global__ void __launch_bounds__(256) k_q4(Consts c, const float4* __restrict__
     e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xB1, 0xf, 0xf, true));
     e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x4E, 0xf, 0xf, true));
     if (valid && g == 0) st_out<NTOUT>(out + i, e);
+}
+
+// ---- Q4H: HALF rows with pair symmetry (second half): a row keeps only the neighbours j > i; the pair's scalar goes to i
+// (register) and to j (global float atomic, fire and forget).  Half the gathers and half the pair arithmetic; the price is one 4-byte
+// atomic per pair through the same texture-address path, sums whose order differs from run to run, and -- in the engine -- a second
+// elementwise pass for the per-particle epilogue (the sums are complete only when the whole launch has finished).
+// SCAT: 0 = walk only (no scatter: wrong sums, the floor), 1 = one atomic per pair, 2 = atomics only for pairs leaving the 64-particle tile,
+//       in-tile pairs through LDS atomics and one global atomic per particle at the end
+template <bool TWO, int SCAT>
+__global__ void __launch_bounds__(256) k_q4h(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                             const unsigned int* __restrict__ rows, const int* __restrict__ counts,
+                                             float* __restrict__ out, int n, int numTiles, int cap)
+{
+    __shared__ float tileSum[64];
+    const int tile = logical_block();
+    if (tile >= numTiles) return;
+    if (SCAT == 2) { if (threadIdx.x < 64) tileSum[threadIdx.x] = 0.0f; __syncthreads(); }
+    const int g = threadIdx.x & 3;
+    const int ip = tile * 64 + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+    const bool valid = ip < n;
+    const int i = valid ? ip : n - 1;
+    const float4 self = posm[i];
+    const float4 sv = vel4[i];
+    const int cnt = valid ? min(counts[i], cap) : 0;
+    const unsigned int* rowq = rows + row_base_offset(i, cap) + g;
+    int steps = (cnt + 3) >> 2;
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+    float e = 0.0f;
+    auto chunks = [&](auto UC, int s) {
+        constexpr int U = decltype(UC)::value;
+        unsigned int idx[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = 4 * (s + u) + g < cnt;
+            const unsigned int raw = rowq[(size_t)(s + u) * 256u];
+            idx[u] = ok[u] ? raw : 0u;
+        }
+        float4 pj[U], vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pj[u] = gather16(posm, idx[u] << 4);
+            vj[u] = TWO ? gather16(vel4, idx[u] << 4) : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float dx = self.x - pj[u].x, dy = self.y - pj[u].y, dz = self.z - pj[u].z;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            // the pair's scalar without the mass: m_j s to i, m_i s to j
+            const float t = pair_tol_d(c, dx, dy, dz, r2, sv.x - vj[u].x, sv.y - vj[u].y, sv.z - vj[u].z, 1.0f);
+            e += ok[u] ? pj[u].w * t : 0.0f;
+            if (SCAT == 1) { if (ok[u]) unsafeAtomicAdd(out + idx[u], self.w * t); }
+            if (SCAT == 2) {
+                if (ok[u]) {
+                    const unsigned int local = idx[u] - (unsigned)(tile * 64);
+                    if (local < 64u) atomicAdd(&tileSum[local], self.w * t);       // ds_add_f32
+                    else unsafeAtomicAdd(out + idx[u], self.w * t);
+                }
+            }
+        }
+    };
+    int s = 0;
+    for (; s + 4 <= steps; s += 4) chunks(std::integral_constant<int, 4>{}, s);
+    for (; s < steps; ++s) chunks(std::integral_constant<int, 1>{}, s);
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xB1, 0xf, 0xf, true));
+    e += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x4E, 0xf, 0xf, true));
+    if (SCAT == 2) {
+        if (valid && g == 0) atomicAdd(&tileSum[ip - tile * 64], e);
+        __syncthreads();
+        if (threadIdx.x < 64 && tile * 64 + (int)threadIdx.x < n) unsafeAtomicAdd(out + tile * 64 + threadIdx.x, tileSum[threadIdx.x]);
+    } else if (valid && g == 0) {
+        if (SCAT == 0) out[i] = e; else unsafeAtomicAdd(out + i, e);
+    }
 }
 
 // ---- Q4C: the quad walk on COMPACT rows: 16-bit entries = offsets into one of three windows of the particle (one per dx layer: the
@@ -754,6 +827,43 @@ int main(int argc, char** argv)
             }
         }
         CK(hipFree(dPos2)); CK(hipFree(dVel2));
+    }
+
+    if (strchr(modes, 'h')) {      // HALF rows (j > i) with pair symmetry: scalar to i in registers, to j by float atomics
+        std::vector<unsigned int> ra(rowWords), rh(rowWords, 0u);
+        CK(hipMemcpy(ra.data(), dRowsA, 4 * rowWords, hipMemcpyDeviceToHost));
+        std::vector<int> ch(n);
+        long long halfPairs = 0, inTile = 0; int longest = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t rb = ((size_t)(i >> 6) * kCap) * 64u + (size_t)(i & 63) * 4u;
+            int m = 0;
+            for (int k = 0; k < std::min(ca[i], kCap); ++k) {
+                const unsigned int j = ra[rb + (size_t)(k >> 2) * 256u + (k & 3)] & kIndexMask;
+                if ((int)j <= i) continue;
+                rh[rb + (size_t)(m >> 2) * 256u + (m & 3)] = j; ++m;
+                inTile += (int)(j >> 6) == (i >> 6);
+            }
+            ch[i] = m; halfPairs += m; longest = std::max(longest, m);
+        }
+        printf("half rows: %lld pairs (%.1f per particle), longest %d, %.1f %% of them inside the 64-particle tile\n", halfPairs, (double)halfPairs / n, longest, 100.0 * inTile / halfPairs);
+        CK(hipMemcpy(dRowsB, rh.data(), 4 * rowWords, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dCntB, ch.data(), 4 * (size_t)n, hipMemcpyHostToDevice));
+        for (int two = 1; two >= 0; --two) for (int scat = 0; scat < 3; ++scat) {
+            char nm[128];
+            snprintf(nm, sizeof(nm), "Q4H half rows, %s tol %s", scat == 0 ? "NO scatter (floor, wrong sums)" : (scat == 1 ? "global atomic per pair" : "LDS in tile + global atomics"), two ? "2f" : "1f");
+            // every launch starts from zeroed sums: the memset is part of the cost
+            auto launch = [&] {
+                if (scat) CK(hipMemsetAsync(dOut, 0, 4 * (size_t)n, st));
+#define LQH(T, S) hipLaunchKernelGGL((k_q4h<T, S>), dim3(gridQ), dim3(256), 0, st, c, dPos, dVel, dRowsB, dCntB, dOut, n, numTiles, kCap)
+                if (two) { if (scat == 0) LQH(true, 0); else if (scat == 1) LQH(true, 1); else LQH(true, 2); }
+                else { if (scat == 0) LQH(false, 0); else if (scat == 1) LQH(false, 1); else LQH(false, 2); }
+            };
+            const float ms = timeit(launch);
+            CK(hipMemcpy(got.data(), dOut, 4 * (size_t)n, hipMemcpyDeviceToHost));
+            double maxAbs = 0, scaleV = 0;
+            if (!ref[two].empty()) for (int i = 0; i < n; ++i) { maxAbs = std::max(maxAbs, fabs((double)got[i] - ref[two][i])); scaleV = std::max(scaleV, fabs((double)ref[two][i])); }
+            printf("%-72s %8.3f ms   %7.1f Gpair/s (full pairs)   [max |diff| %.2e of %.2e]\n", nm, ms, pairs / ms * 1e-6, maxAbs, scaleV);
+        }
     }
 
     if (strchr(modes, 'k')) {      // COMPACT rows: 16-bit window offsets + a 16-byte meta record per particle
