@@ -21,7 +21,7 @@ DFSPHSolver::DFSPHSolver(int num, float defaultDensityErrorThreshold, float defa
     : BasicSPHSolver(num), alpha((unsigned)num), bufferFloat((unsigned)num), error((unsigned)num),
       denWarmStiff((unsigned)num), scratch((unsigned)num), errorAccum(2u * kErrorSlots * kErrorSlotStride),
       densityErrorThreshold(defaultDensityErrorThreshold), divergenceErrorThreshold(defaultDivergenceErrorThreshold),
-      maxIter(defaultMaxIter), loopState(4u)
+      maxIter(defaultMaxIter), loopState((unsigned)kLoopWords)
 {
     HIP_CALL(hipHostMalloc((void**)&hostIters, 2 * sizeof(int), hipHostMallocDefault));
     if (hostIters) hostIters[0] = hostIters[1] = 0;
@@ -35,11 +35,10 @@ DFSPHSolver::~DFSPHSolver() noexcept { if (hostIters) (void)hipHostFree(hostIter
 // iterations are enqueued up front and leave at their first instruction once `done` is up (SweepCtx::gate).  No host round
 // trip, same iteration counts, and the whole adaptive step can be captured into a hipGraph.
 namespace {
-enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3 };
 __global__ void __launch_bounds__(kErrorSlots) k_loop_reset(int* __restrict__ st, unsigned long long* __restrict__ accum)
 {
     accum[(size_t)threadIdx.x * kErrorSlotStride] = 0ull;
-    if (threadIdx.x == 0) { st[kLoopDone] = 0; st[kLoopIter] = 0; }
+    if (threadIdx.x == 0) { st[kLoopDone] = 0; st[kLoopIter] = 0; st[kLoopBarrier] = 0; }
 }
 __global__ void __launch_bounds__(kErrorSlots) k_loop_decide(int* __restrict__ st, unsigned long long* __restrict__ accum, float threshold,
                                                              int minIter, int maxIter, int which)
@@ -72,10 +71,11 @@ bool DFSPHSolver::deviceLoops() const
 bool DFSPHSolver::graphSafe() const { return (fixedDiv >= 0 && fixedDen >= 0) || deviceLoops(); }
 void DFSPHSolver::fetchIterations()
 {
+    // (a replayed step graph updates the pinned words without passing through step(): while the device decides the loops the counts
+    // are always taken from there)
     if (!itersPending) return;
     HIP_CALL(hipStreamSynchronize(sphx::stream()));
     lastDiv = hostIters[0]; lastDen = hostIters[1];
-    itersPending = false;
 }
 
 long long DFSPHSolver::readErrorTotalFixed()
@@ -242,6 +242,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
     const int num = (int)fluids->size();
     if (!c.fused()) {
+        itersPending = false;
         computeDensityAlpha(fluids, boundaries, cellStartFluid, cellStartBoundary, cellSize, cellLength, radius);
         lastDiv = correctDivergenceError(fluids, boundaries, cellStartFluid, cellStartBoundary, rho0, cellSize, cellLength,
                                          radius, dt, divergenceErrorThreshold, maxIter);
@@ -264,6 +265,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
                  rhoB, visc, G, surfaceTensionIntensity, airPressure, reduce);
     };
     const bool onDevice = deviceLoops();
+    if (onDevice && getenv("SPHX_DFSPH_WINDOW")) adaptWindows();
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
     // `iterations` possible iterations of one loop, all enqueued: body(k) launches the sweeps of iteration k
     auto deviceLoop = [&](float threshold, int minIter, int which, auto&& body) {
@@ -271,6 +273,12 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         c.gate = loopState.addr(kLoopDone);
         c.keepErrorAccum = true;                       // the decision kernel leaves the accumulators zeroed
         for (int k = 0; k < maxIter; ++k) {
+            // The iterations the last steps needed (+ 2) are ordinary launches; whatever is left of the loop is ONE persistent launch
+            // (where the configuration has one).  A loop that has terminated then costs a few launches that leave at once, not 3 per
+            // possible iteration; one that runs longer than predicted is finished by the tail (slower per iteration: its grid barriers
+            // cost more than kernel boundaries do -- profiles/r04_dfsph_loop_tail.txt -- so the window follows the counts, adaptWindows).
+            if (k == std::max(minIter, which == kLoopDen ? windowDen : windowDiv) &&
+                runLoopTail(which == kLoopDen, fluids, cellStartFluid, cellStartBoundary, dt, rho0, threshold, minIter, which)) break;
             body(k);
             k_loop_decide<<<1, kErrorSlots, 0, sphx::stream()>>>(loopState.addr(), accum, threshold, minIter, maxIter, which);
         }
@@ -323,8 +331,64 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     run(SPHX_PH_ADVECT);
     if (onDevice) {          // the counts of this step: device words -> pinned host memory, read on demand (fetchIterations)
         HIP_CALL(hipMemcpyAsync(hostIters, loopState.addr(kLoopDiv), 2 * sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));
-        itersPending = true;
     }
+    itersPending = onDevice;
+}
+
+// A loop that outruns its window is finished by the tail at 2-3 times the cost per iteration (4 waves per SIMD, grid barriers):
+// on a large scene that is milliseconds per step until the window has followed (1,022,208 particles, the impact: 25 steps at
+// 6.2 ms instead of 3.5 with 16 steps between two looks, profiles/r04_dfsph_loop_tail.txt), so there the counts are looked at
+// every 4 steps -- one stream synchronisation per 4 steps of >= 1 ms.  Small scenes keep the batches long.
+int DFSPHSolver::tuneInterval() const
+{
+    return (deviceLoops() && alpha.length() >= 100000u) ? 4 : 16;
+}
+void DFSPHSolver::tune(int stepsSinceLastCall)
+{
+    BasicSPHSolver::tune(stepsSinceLastCall);
+    if (deviceLoops()) { fetchIterations(); adaptWindows(); }
+}
+// grow at once (to twice the need, so that a rising count does not re-capture every few steps), shrink only when far too wide
+void DFSPHSolver::adaptWindows()
+{
+    // SPHX_DFSPH_WINDOW=k: fixed windows (tests: 0 leaves every iteration beyond the reference's minimum to the tail kernel)
+    if (const char* e = getenv("SPHX_DFSPH_WINDOW")) {
+        const int w = std::max(0, atoi(e));
+        if (w != windowDiv || w != windowDen) { windowDiv = windowDen = w; ++cache().generation; }
+        return;
+    }
+    auto adapt = [&](int& window, int seen, int minIter) {
+        const int want = std::min(maxIter, std::max(minIter, seen) + 2);
+        int next = window;
+        if (seen + 1 > window) next = std::min(maxIter, std::max(want, 2 * window));
+        else if (want + 6 < window) next = want;
+        if (next == window) return;
+        window = next;
+        ++cache().generation;          // a captured step holds the old number of launches
+    };
+    adapt(windowDiv, lastDiv, 1);
+    adapt(windowDen, lastDen, 2);
+}
+
+bool DFSPHSolver::runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
+                              const DArray<int>& cellStartBoundary, float dt, float rho0, float threshold, int minIter, int which)
+{
+    if (getenv("SPHX_DFSPH_NO_TAIL") != nullptr) return false;
+    SweepCache& c = cache();
+    const int num = (int)fluids->size();
+    const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
+    const LoopTail tail{loopState.addr(), accum, threshold, minIter, maxIter, which};
+    ScopedKernel t(densityLoop ? "density_loop_tail" : "divergence_loop_tail");
+    if (densityLoop)
+        return launch_dfsph_loop_tail<true, 2>(OpCorrect<true>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true},
+                                               OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                                                      RateOut{error.addr(), bufferFloat.addr(), denWarmStiff.addr(), accum, dt, rho0, c.posfw(), sumLo, sumHi}},
+                                               tail, num);
+    return launch_dfsph_loop_tail<false, 0>(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true},
+                                            OpRate{ctx, fluids->getVelPtr(), fluids->getDensityPtr(), alpha.addr(),
+                                                   RateOut{error.addr(), bufferFloat.addr(), nullptr, accum, dt, rho0, c.posfw(), sumLo, sumHi}},
+                                            tail, num);
 }
 
 // One stage of the fused schedule.  Reference stages: DFSPHSolver.cu:33-72 (order), :160-210 and

@@ -511,14 +511,17 @@ __device__ __forceinline__ bool tile_outside(const SweepCtx& c, int tile)
     const int a = tile * kTile, b = a + kTile;
     return (b <= c.lo || a >= c.hi) && (b <= c.lo2 || a >= c.hi2);
 }
-__device__ __forceinline__ int wave_tile(const SweepCtx& c)
+__device__ __forceinline__ int wave_tile_of(const SweepCtx& c, const int lt)      // lt: the launch-order tile number of this wave
 {
-    if (c.gate && *c.gate != 0) return -1;
-    const int lt = logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6);
     if (lt >= c.numTiles) return -1;
     if (!c.tileOrder) return lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
     const int tile = c.tileOrder[lt];
     return tile_outside(c, tile) ? -1 : tile;
+}
+__device__ __forceinline__ int wave_tile(const SweepCtx& c)
+{
+    if (c.gate && *c.gate != 0) return -1;
+    return wave_tile_of(c, logical_block() * (kWideBlock / kTile) + (int)(threadIdx.x >> 6));
 }
 __device__ __forceinline__ bool in_range(const SweepCtx& c, int i) { return (i >= c.lo && i < c.hi) || (i >= c.lo2 && i < c.hi2); }
 
@@ -966,10 +969,9 @@ __device__ __forceinline__ void walk_row_quad(const Op& op, const SweepCtx& c, c
 
 // The particle of this lane's quad in a quad-per-particle launch: one block of 4 waves per tile, wave w takes the
 // particles [16 w, 16 w + 16) of the tile.  -1: the block is past the end.
-__device__ __forceinline__ int quad_particle(const SweepCtx& c)
+// (lt: the launch-order tile number; a persistent block of the DFSPH loop tail walks several of them)
+__device__ __forceinline__ int quad_particle_of(const SweepCtx& c, const int lt)
 {
-    if (c.gate && *c.gate != 0) return -1;
-    const int lt = logical_block();
     if (lt >= c.numTiles) return -1;
     const int tile = c.tileOrder ? c.tileOrder[lt] : lt + (lt < c.tileSplit ? c.tile0 : c.tile1);
     if (c.tileOrder && tile_outside(c, tile)) return -1;
@@ -977,6 +979,11 @@ __device__ __forceinline__ int quad_particle(const SweepCtx& c)
     // was measured and removed: the quads of a wave then gather around non-adjacent particles, 61.1 -> 64.5 ms per post-impact
     // step at 10.3 M, +1 % strict and +6 % tolerance in free fall.)
     return tile * kTile + (int)(threadIdx.x >> 6) * 16 + (int)((threadIdx.x & 63) >> 2);
+}
+__device__ __forceinline__ int quad_particle(const SweepCtx& c)
+{
+    if (c.gate && *c.gate != 0) return -1;
+    return quad_particle_of(c, logical_block());
 }
 
 // sweep() for a quad-per-particle launch (rows in global memory only; no LDS-streamed tiles)

@@ -819,6 +819,133 @@ struct OpCorrect {
     }
 };
 
+// ---- the tail of an adaptive DFSPH solver loop as ONE launch (r04) --------------------------------------------------------
+// The device-decided loops (dfsph.hip) enqueue the launches of every possible iteration and gate them off once the loop has
+// terminated; at 20 possible iterations that left ~100 launches per step that leave at their first instruction (1.5 us each on
+// the reference scene: 0.16 of its 0.38 ms per step).  Here the first iteration(s) stay ordinary launches; every further
+// iteration runs inside one persistent kernel: correction sweep, grid barrier, error sweep (its |error| terms go to the
+// exact integer accumulators), grid barrier, then EVERY block forms the total from the same accumulators and applies the
+// reference's rule (DFSPHSolver.cu:187-208, :347-361) -- the same decision everywhere, no third barrier.  The sweeps are the
+// bodies of k_run_op<OpCorrect, quad> and k_rate_quad, so every per-particle sum is the one the separate launches form.
+// The blocks spin on a counter in device memory: the grid never exceeds what the device holds at once (launch_dfsph_loop_tail).
+struct LoopTail {
+    int* st;                          // DFSPHSolver::loopState: done flag, iterations so far, divergence count, density count, barrier word
+    unsigned long long* accum;        // kErrorSlots partial totals (zero on entry; cumulative inside the tail)
+    float threshold; int minIter, maxIter, which;
+};
+enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3, kLoopBarrier = 4, kLoopWords = 8 };
+__device__ __forceinline__ void grid_barrier(unsigned int* word, unsigned int& target)
+{
+    __syncthreads();
+#ifndef SPHX_TAIL_FENCE
+#define SPHX_TAIL_FENCE 3          // experiments: bit 0 release fence, bit 1 acquire fence (anything but 3 computes wrong results)
+#endif
+#ifndef SPHX_TAIL_SLEEP
+#define SPHX_TAIL_SLEEP 2
+#endif
+    if (threadIdx.x == 0) {
+        target += gridDim.x;
+        if (SPHX_TAIL_FENCE & 1) __threadfence();              // release: what this block wrote (agent scope: L2 write-back across XCDs)
+        atomicAdd(word, 1u);
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(SPHX_TAIL_SLEEP);
+        if (SPHX_TAIL_FENCE & 2) __threadfence();              // acquire: drop what the caches hold of the other blocks' arrays
+    }
+    __syncthreads();
+}
+// CM: the correction sweep's launch shape, 0 lane per particle (a block takes four tiles), 1 quad per particle (one tile)
+template <bool DENSITY_MODE, int WARM, int CM, int TOLC, int TOLR>
+__global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<DENSITY_MODE> corr, const OpRate rate, const LoopTail t)
+{
+    static_assert(kErrorSlots == kWideBlock, "one accumulator per thread of a block");
+    if (t.st[kLoopDone] != 0) return;                          // (written by the launch before this one: the same for every block)
+    __shared__ unsigned long long part[kWideBlock / 64];
+    unsigned int* const word = reinterpret_cast<unsigned int*>(t.st + kLoopBarrier);
+    unsigned int target = 0;
+    int iter = t.st[kLoopIter];
+    unsigned long long before = 0;
+    for (;;) {
+        if constexpr (CM == 1) {
+            for (int lt = (int)blockIdx.x; lt < corr.c.numTiles; lt += (int)gridDim.x) {
+                assume_arith<TOLC>(corr.c);
+                const int i = quad_particle_of(corr.c, lt);
+                if (i >= 0) corr.template operator()<1>(i, in_range(corr.c, i), nullptr, nullptr);
+            }
+        } else {
+            for (int lt = (int)blockIdx.x * (kWideBlock / kTile) + (int)(threadIdx.x >> 6); lt < corr.c.numTiles; lt += (int)gridDim.x * (kWideBlock / kTile)) {
+                const int tile = wave_tile_of(corr.c, lt);
+                if (tile < 0) continue;
+                const int i = tile * kTile + (int)(threadIdx.x & 63);
+                corr(i, in_range(corr.c, i), nullptr, nullptr);
+            }
+        }
+        grid_barrier(word, target);
+        for (int lt = (int)blockIdx.x; lt < rate.c.numTiles; lt += (int)gridDim.x) {
+            assume_arith<TOLR>(rate.c);
+            const int i = quad_particle_of(rate.c, lt);
+            if (i < 0) continue;
+            const bool valid = in_range(rate.c, i);
+            long long fixed = 0;
+            const float3 own = valid ? rate.vel[i] : v3(0, 0, 0);
+            OpRate::Body b{rate, own.x, own.y, own.z, 0.0f};
+            sweep_quad<true>(rate, rate.c, i, valid, own_pos(rate.c, i, valid), b);
+            if (stores_results<1>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(rate.out, i, b.e, rate.density[i], rate.alpha[i]);
+            accumulate_error(fixed, rate.out.accum);
+        }
+        grid_barrier(word, target);
+        unsigned long long v = t.accum[(size_t)threadIdx.x * kErrorSlotStride];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        unsigned long long sum = 0;
+        for (int w = 0; w < kWideBlock / 64; ++w) sum += part[w];
+        const unsigned long long total = sum - before;         // the accumulators are not zeroed between iterations here
+        before = sum;
+        ++iter;
+        const float totalError = (float)((double)(long long)total * (1.0 / 4294967296.0));      // DFSPHSolver::readErrorTotal
+        if (!((iter < t.minIter || totalError > t.threshold) && iter < t.maxIter)) break;
+        // (part[] is rewritten only behind the next two barriers)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t.st[kLoopIter] = iter; t.st[t.which] = iter; t.st[kLoopDone] = 1; }
+}
+template <bool DENSITY_MODE, int WARM, int CM, int TOLC, int TOLR>
+inline bool launch_tail_kernel(const OpCorrect<DENSITY_MODE>& corr, const OpRate& rate, const LoopTail& t)
+{
+    static thread_local int perCU = -1, cus = 0;               // blocks of THIS kernel a compute unit holds at once
+    if (perCU < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        HIP_CALL(hipGetDevice(&dev)); HIP_CALL(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount;
+        HIP_CALL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR>, kWideBlock, 0));
+    }
+    if (perCU < 1 || cus < 1) return false;
+    const int grid = std::min(corr.c.numTiles, perCU * cus);   // (the rate sweep takes one tile per block; a lane-walk correction four)
+    k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR><<<grid, kWideBlock, 0, stream()>>>(corr, rate, t);
+    return true;
+}
+// false: this configuration has no tail kernel (the caller enqueues gated launches instead)
+template <bool DENSITY_MODE, int WARM>
+inline bool launch_dfsph_loop_tail(const OpCorrect<DENSITY_MODE>& corrIn, const OpRate& rateIn, const LoopTail& t, int n)
+{
+    const SweepCtx& c = corrIn.c;
+    if (n <= 0 || c.numTiles <= 0 || !c.nbr || c.tileFmt || c.brick || !(c.quad & kQuadRate)) return false;
+    const bool quadCorrect = (c.quad & kQuadCorrect) != 0;
+    if (!quadCorrect && (c.duo & kQuadCorrect)) return false;  // (launch_op: the two-lane walk has no tail form)
+    OpCorrect<DENSITY_MODE> corr = corrIn;
+    OpRate rate = rateIn;
+    corr.c.gate = nullptr; rate.c.gate = nullptr;
+    const bool tolC = c.k.tol != 0;
+    const bool tolR = tolC && !c.plainBits;                    // (launch_rate_kernel: the strict walk serves the rate sweeps of large tolerance runs)
+    if (tolC && !tolR) rate.c.k.tol = 0;
+    if (!quadCorrect) {                                        // (lane walks decide their arithmetic at run time: k_run_op<Op, false, 0, -1>)
+        if (tolR) return launch_tail_kernel<DENSITY_MODE, WARM, 0, -1, 1>(corr, rate, t);
+        return launch_tail_kernel<DENSITY_MODE, WARM, 0, -1, 0>(corr, rate, t);
+    }
+    if (tolC && tolR) return launch_tail_kernel<DENSITY_MODE, WARM, 1, 1, 1>(corr, rate, t);
+    if (tolC) return launch_tail_kernel<DENSITY_MODE, WARM, 1, 1, 0>(corr, rate, t);
+    return launch_tail_kernel<DENSITY_MODE, WARM, 1, 0, 0>(corr, rate, t);
+}
+
 // =================================================================================== PBD
 // computeDensityLambda_CUDA, PBDSolver.cu:127-168.  `rb` is (float)(bool)rho0;
 // dividing by 1.0f is the identity, so the division is only performed when rb != 1.

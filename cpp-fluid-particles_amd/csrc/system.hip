@@ -890,28 +890,34 @@ float SPHSystem::stepN(int n)
         _graph->capturedCount = _fluids->size();
         _graph->capturedGeneration = _solver->graphGeneration();
         _solver->prepareForCapture();
+        const bool say = getenv("SPHX_GRAPH_DEBUG") != nullptr;       // which stage of a capture failed (the step then runs eagerly)
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
-            try { enqueueStep(); } catch (...) { ok = false; }
+            try { enqueueStep(); } catch (const char* msg) { ok = false; if (say) std::cout << "sphx: capture: enqueue threw: " << msg << "\n"; }
+            catch (...) { ok = false; if (say) std::cout << "sphx: capture: enqueue threw\n"; }
             hipGraph_t gph = nullptr;
-            if (hipStreamEndCapture(st, &gph) != hipSuccess) ok = false;
-            if (ok && gph && hipGraphInstantiate(&_graph->exec, gph, nullptr, nullptr, 0) == hipSuccess) {
+            const hipError_t ended = hipStreamEndCapture(st, &gph);
+            if (ended != hipSuccess) { ok = false; if (say) std::cout << "sphx: capture: end of capture: " << hipGetErrorString(ended) << "\n"; }
+            const hipError_t made = (ok && gph) ? hipGraphInstantiate(&_graph->exec, gph, nullptr, nullptr, 0) : hipErrorUnknown;
+            if (made == hipSuccess) {
                 _graph->graph = gph;
+                if (say) std::cout << "sphx: capture: step graph instantiated\n";
             } else {
+                if (say && ok) std::cout << "sphx: capture: instantiate: " << hipGetErrorString(made) << "\n";
                 if (gph) (void)hipGraphDestroy(gph);
                 _graph->exec = nullptr;
                 (void)hipGetLastError();
             }
-        }
+        } else if (say) std::cout << "sphx: capture: could not begin\n";
     };
     hipEvent_t start, stop;
     HIP_CALL(hipEventCreate(&start));
     HIP_CALL(hipEventCreate(&stop));
     HIP_CALL(hipEventRecord(start, st));
-    // The batch runs in chunks of 16 steps with the solver's host-side tuning hook between them (one 4-byte read-back: row
+    // The batch runs in chunks of (normally) 16 steps with the solver's host-side tuning hook between them (one 4-byte read-back: row
     // capacity, PBD skin controller): a long batch that runs into denser states must not wait for its end to get longer rows.
     // The hook may invalidate the capture (regrown rows); the next chunk then re-captures.
-    constexpr int kChunk = 16;
+    const int kChunk = std::max(1, _solver->tuneInterval());
     for (int done = 0; done < n;) {
         ensureGraph();
         const int chunk = std::min(n - done, kChunk);

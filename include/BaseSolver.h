@@ -32,6 +32,8 @@ public:
     // called between steps (never inside a captured graph) with the number of steps run since the last call: a place
     // for host-side adaptation from device-side statistics; may change graphGeneration()
     virtual void tune(int stepsSinceLastCall) { (void)stepsSinceLastCall; }
+    // how many steps of a batch (SPHSystem::stepN) may be enqueued between two calls of tune()
+    virtual int tuneInterval() const { return 16; }
 
 protected:
     virtual void advect(std::shared_ptr<SPHParticles>& fluids, float dt, float3 spaceSize) = 0;

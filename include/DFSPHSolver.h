@@ -53,6 +53,8 @@ public:
     DArray<float>& getWarmStiffness() { return denWarmStiff; }
     void permuteState(const int* perm, int n) override;
 
+    void tune(int stepsSinceLastCall) override;      // engine: row capacity (BasicSPHSolver) + the windows of the device-decided loops
+    int tuneInterval() const override;               // device-decided loops on large scenes: the windows follow the counts every 4 steps
 protected:
     // hides BasicSPHSolver::project (different signature), as in the reference
     virtual int project(std::shared_ptr<SPHParticles>& fluids,
@@ -88,10 +90,18 @@ private:
     int fixedDiv = -1, fixedDen = -1;
     bool headDidFirstError = false;   // the fused head sweep already produced the first divergence error
     int lastDiv = 0, lastDen = 0;
-    // device-side adaptive loops: {done, iteration, divergence iterations, density iterations} of the current step on the device,
+    // device-side adaptive loops: {done, iteration, divergence iterations, density iterations, grid-barrier word} of the current step on the device,
     // copied to pinned host memory at the end of every step and read when somebody asks
     bool deviceLoops() const;
     void fetchIterations();
+    // iterations beyond the first one(s) of a device-decided loop in ONE persistent launch (sweep_ops.hpp, k_dfsph_loop_tail);
+    // false: not available in this configuration, the caller enqueues gated launches
+    // how many iterations of each loop are enqueued as ordinary (gated) launches before the tail: the count of the last steps + 2.
+    // A prediction only -- the tail runs whatever is left, so the results do not depend on it; a change re-captures the step graph.
+    int windowDiv = 3, windowDen = 4;
+    void adaptWindows();
+    bool runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
+                     const DArray<int>& cellStartBoundary, float dt, float rho0, float threshold, int minIter, int which);
     DArray<int> loopState;
     int* hostIters = nullptr;
     bool itersPending = false;

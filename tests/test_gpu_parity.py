@@ -904,6 +904,34 @@ def test_trajectory_bit_exact_through_landing(sphx, oracle, solver, dt, first, l
         assert gs.get(sphx.F_PRESSURE).max() > 0, "Tait pressures must be active"
 
 
+@pytest.mark.parametrize("mode", ["tail_only", "gated_only", "windows"])
+def test_adaptive_loops_tail_and_gated_launches_bit_exact(sphx, oracle, monkeypatch, mode):
+    """adaptive DFSPH through the landing (counts 1 -> 20) with every iteration beyond the reference's minimum inside the persistent
+    tail launch (SPHX_DFSPH_WINDOW=0), with gated launches only (SPHX_DFSPH_NO_TAIL=1) and with the default adaptive windows:
+    every field bit-identical to the oracle, same iteration counts (DFSPHSolver.cu:187-208, :347-361); the counts read after a
+    replayed batch are those of its last step"""
+    if mode == "tail_only":
+        monkeypatch.setenv("SPHX_DFSPH_WINDOW", "0")
+    if mode == "gated_only":
+        monkeypatch.setenv("SPHX_DFSPH_NO_TAIL", "1")
+    gs, os_, _ = make_pair(sphx, oracle, 24, 1)
+    names = FIELDS_COMMON + FIELDS_DFSPH
+    its = []
+    for s in range(1, 91):
+        gs.step(); os_.step()
+        assert gs.iters() == os_.iters(), (mode, s)
+        its.append(gs.iters())
+        if s % 15 == 0:
+            compare(sphx, oracle, gs, os_, names, "%s step %d" % (mode, s))
+    assert max(i[0] for i in its) == 20 and min(i[0] for i in its) == 1
+    P, f, b = sphx.scene(24); P.solver = sphx.DFSPH
+    batch = sphx.System(P, f, b)
+    batch.step_n(90)
+    assert batch.iters() == its[-1], "counts after a replayed batch"
+    assert np.array_equal(batch.get(sphx.F_POS).view(np.uint32), gs.get(sphx.F_POS).view(np.uint32))
+    batch.close()
+
+
 def test_adaptive_row_capacity_grows_and_stays_exact(sphx, oracle):
     """rows start at 48 entries per particle; a state denser than the lattice (two interleaved jittered lattices, ~60 neighbours)
     overflows them: the overflowing particles walk the cells directly (same bits), the builder reports the longest row, the
