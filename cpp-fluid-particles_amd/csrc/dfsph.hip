@@ -266,6 +266,9 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     };
     const bool onDevice = deviceLoops();
     if (onDevice && getenv("SPHX_DFSPH_WINDOW")) adaptWindows();
+    // fixed counts with at least one divergence correction: the gravity kick rides in the last correction's store
+    const bool kickFused = !onDevice && fixedDiv >= 1 && !c.isSlab && num > 0 && getenv("SPHX_NO_KICK_FUSION") == nullptr;
+    kickDv = make_float3(dt * G.x, dt * G.y, dt * G.z);
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
     // `iterations` possible iterations of one loop, all enqueued: body(k) launches the sweeps of iteration k
     auto deviceLoop = [&](float threshold, int minIter, int which, auto&& body) {
@@ -294,7 +297,9 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         auto totalError = std::numeric_limits<float>::max();
         int iter = 0;
         while (adaptive ? ((iter < 1 || totalError > divergenceErrorThreshold * num * rho0) && iter < maxIter) : (iter < fixedDiv)) {
+            kickInCorrect = kickFused && iter + 1 == fixedDiv;      // (no error sweep reads the velocities behind the last correction)
             run(SPHX_PH_DIV_CORRECT);
+            kickInCorrect = false;
             // The error sweep behind a correction feeds the NEXT correction and the termination test (DFSPHSolver.cu:347-361).
             // With fixed counts nothing reads the one behind the last correction: error / stiffness (and posf.w) are rewritten by
             // the density solve before anybody looks at them, so every field of the finished step is unchanged without it.
@@ -304,7 +309,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         }
         lastDiv = iter;
     }
-    run(SPHX_PH_FORCE);
+    if (!kickFused) run(SPHX_PH_FORCE);
     run(SPHX_PH_VISC_COLOR);
     if (surface) {
         run(SPHX_PH_SURFACE_WARM);     // one row walk for the surface sweep and the warm-start correction
@@ -436,7 +441,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     }
     case SPHX_PH_DIV_CORRECT: {
         ScopedKernel t("divergence_correct");
-        launch_op(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true}, num);
+        launch_op(OpCorrect<false>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true, kickInCorrect, kickDv.x, kickDv.y, kickDv.z}, num);
         break;
     }
     case SPHX_PH_DIV_ERROR: {

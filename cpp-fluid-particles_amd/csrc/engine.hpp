@@ -71,6 +71,7 @@ struct SweepCache {
     DArray<int> tileKey;                     // bucket of each tile while the schedule is built
     std::unique_ptr<DArray<int>> tileBuckets; // histogram / cursors of the (y-chunk, x) buckets
     bool orderValid = false;
+    int orderBuiltTiles = -1;                // tile count of the schedule the array holds (a complete permutation of that many tiles)
     std::unique_ptr<RowStore> nbr;           // allocated on first use
     // Unified neighbour space: posm, posf, vel4 and cg4 hold [capN fluid slots | nbCap boundary slots].
     // A row entry carries ONE index into it, so a sweep gathers with a uniform base pointer and a

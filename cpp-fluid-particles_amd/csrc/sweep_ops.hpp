@@ -779,6 +779,9 @@ struct OpCorrect {
     const float* kappa; float3* vel;
     float dt;
     bool packedScalar;      // posf.w currently holds THIS kappa array for every fluid particle
+    // fixed iteration counts, whole-domain steps: the gravity kick of BasicSPHSolver::force (vel += dt G, BasicSPHSolver.cu:227-235) that
+    // follows the LAST divergence correction is applied by that correction's store -- the same two rounded additions, one pass less
+    bool addKick = false; float kx = 0.0f, ky = 0.0f, kz = 0.0f;
     using Field = float;    // neighbour stiffness
     __device__ __forceinline__ Field stage(bool isB, int j) const { return fluid_only(kappa, isB, j); }
     struct Body {
@@ -813,7 +816,8 @@ struct OpCorrect {
         Body b{*this, valid ? kappa[i] : 0.0f, v3(0, 0, 0)};
         sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!stores_results<QUAD>(valid)) return;
-        const float3 vn = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
+        float3 vn = add3(vel[i], DIVIDE_BY_DT ? div3s(b.a, dt) : b.a);
+        if (addKick) vn = add3(vn, v3(kx, ky, kz));
         vel[i] = vn;
         c.vel4[i] = f4(vn);
     }

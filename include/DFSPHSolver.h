@@ -99,6 +99,9 @@ private:
     // how many iterations of each loop are enqueued as ordinary (gated) launches before the tail: the count of the last steps + 2.
     // A prediction only -- the tail runs whatever is left, so the results do not depend on it; a change re-captures the step graph.
     int windowDiv = 3, windowDen = 4;
+    // fixed counts: the coming divergence correction is the last one of the step and also applies the gravity kick (OpCorrect::addKick)
+    bool kickInCorrect = false;
+    float3 kickDv = {0.0f, 0.0f, 0.0f};
     void adaptWindows();
     bool runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
                      const DArray<int>& cellStartBoundary, float dt, float rho0, float threshold, int minIter, int which);
