@@ -442,3 +442,28 @@ def test_persistent_rows_snapshot_and_count_changes(sphx, oracle, tmp_path):
         g.step(); o.step()
     close_to_oracle(g, "after sphx_set of the warm stiffness")
     g.close(); r.close(); o.close()
+
+@pytest.mark.parametrize("arith", [1, 2])
+def test_adaptive_loop_tail_equals_gated_launches_in_tolerance_arithmetic(sphx, monkeypatch, arith):
+    """adaptive DFSPH under the tolerance arithmetic (rows every step / persistent rows): every iteration beyond the reference's minimum
+    inside the persistent tail launch (SPHX_DFSPH_WINDOW=0) against gated launches only (SPHX_DFSPH_NO_TAIL=1) -- the sweeps are the same
+    code, so states and iteration counts must agree bit for bit, through the landing of the reference scene (counts 1 -> 20)"""
+    def run(tail):
+        if tail:
+            monkeypatch.delenv("SPHX_DFSPH_NO_TAIL", raising=False); monkeypatch.setenv("SPHX_DFSPH_WINDOW", "0")
+        else:
+            monkeypatch.delenv("SPHX_DFSPH_WINDOW", raising=False); monkeypatch.setenv("SPHX_DFSPH_NO_TAIL", "1")
+        P, f, b = sphx.scene(24)
+        P.solver = sphx.DFSPH; P.reserved[3] = arith
+        s = sphx.System(P, f, b)
+        its = []
+        for k in range(90):
+            s.step(); its.append(s.iters())
+        out = (s.get(sphx.F_POS).copy(), s.get(sphx.F_VEL).copy(), s.get(sphx.F_DENSITY).copy(), s.get(sphx.F_CELL).copy(), its)
+        s.close()
+        return out
+    a, b = run(True), run(False)
+    assert a[4] == b[4], "iteration counts"
+    assert max(i[0] for i in a[4]) >= 15 and min(i[0] for i in a[4]) == 1, "the loops must have run long and short"
+    for x, y, name in zip(a[:4], b[:4], ("pos", "vel", "density", "cell")):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), name
