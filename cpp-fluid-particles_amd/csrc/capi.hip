@@ -336,9 +336,11 @@ int sphx_persistent_stats(const sphx_system* h, int* in_use, int* row_builds, in
 int sphx_iters(const sphx_system* h, int* div, int* den)
 {
     if (!h) return fail(SPHX_ERR_INVALID, "null system");
-    if (div) *div = h->dfsph ? h->dfsph->lastDivergenceIterations() : 0;
-    if (den) *den = h->dfsph ? h->dfsph->lastDensityIterations() : 0;
-    return SPHX_OK;
+    return guarded("sphx_iters", [&] {       // (reading the counts of device-decided loops also reports a failed loop-tail launch)
+        if (div) *div = h->dfsph ? h->dfsph->lastDivergenceIterations() : 0;
+        if (den) *den = h->dfsph ? h->dfsph->lastDensityIterations() : 0;
+        return (int)SPHX_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------ fields

@@ -23,8 +23,8 @@ DFSPHSolver::DFSPHSolver(int num, float defaultDensityErrorThreshold, float defa
       densityErrorThreshold(defaultDensityErrorThreshold), divergenceErrorThreshold(defaultDivergenceErrorThreshold),
       maxIter(defaultMaxIter), loopState((unsigned)kLoopWords)
 {
-    HIP_CALL(hipHostMalloc((void**)&hostIters, 2 * sizeof(int), hipHostMallocDefault));
-    if (hostIters) hostIters[0] = hostIters[1] = 0;
+    HIP_CALL(hipHostMalloc((void**)&hostIters, 3 * sizeof(int), hipHostMallocDefault));
+    if (hostIters) hostIters[0] = hostIters[1] = hostIters[2] = 0;
 }
 DFSPHSolver::~DFSPHSolver() noexcept { if (hostIters) (void)hipHostFree(hostIters); }
 
@@ -76,6 +76,13 @@ void DFSPHSolver::fetchIterations()
     if (!itersPending) return;
     HIP_CALL(hipStreamSynchronize(sphx::stream()));
     lastDiv = hostIters[0]; lastDen = hostIters[1];
+    if (hostIters[2] != 0) {       // k_dfsph_loop_tail: a grid barrier timed out -- the step that reported it is NOT valid
+        hostIters[2] = 0;
+        tailFailed = true;
+        ++cache().generation;
+        HIP_CALL(hipMemsetAsync(loopState.addr(kLoopFault), 0, sizeof(int), sphx::stream()));
+        throw "DFSPHSolver: the loop tail's grid barrier timed out (its blocks were not resident at once); the last step is invalid, the solver continues with gated launches";
+    }
 }
 
 long long DFSPHSolver::readErrorTotalFixed()
@@ -335,7 +342,7 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     }
     run(SPHX_PH_ADVECT);
     if (onDevice) {          // the counts of this step: device words -> pinned host memory, read on demand (fetchIterations)
-        HIP_CALL(hipMemcpyAsync(hostIters, loopState.addr(kLoopDiv), 2 * sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));
+        HIP_CALL(hipMemcpyAsync(hostIters, loopState.addr(kLoopDiv), 3 * sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));      // counts + the tail's fault word
     }
     itersPending = onDevice;
 }
@@ -378,7 +385,7 @@ void DFSPHSolver::adaptWindows()
 bool DFSPHSolver::runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
                               const DArray<int>& cellStartBoundary, float dt, float rho0, float threshold, int minIter, int which)
 {
-    if (getenv("SPHX_DFSPH_NO_TAIL") != nullptr) return false;
+    if (tailFailed || getenv("SPHX_DFSPH_NO_TAIL") != nullptr) return false;
     SweepCache& c = cache();
     const int num = (int)fluids->size();
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);

@@ -833,13 +833,18 @@ struct OpCorrect {
 // bodies of k_run_op<OpCorrect, quad> and k_rate_quad, so every per-particle sum is the one the separate launches form.
 // The blocks spin on a counter in device memory: the grid never exceeds what the device holds at once (launch_dfsph_loop_tail).
 struct LoopTail {
-    int* st;                          // DFSPHSolver::loopState: done flag, iterations so far, divergence count, density count, barrier word
+    int* st;                          // DFSPHSolver::loopState: done flag, iterations so far, divergence count, density count, fault, barrier word
     unsigned long long* accum;        // kErrorSlots partial totals (zero on entry; cumulative inside the tail)
     float threshold; int minIter, maxIter, which;
 };
-enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3, kLoopBarrier = 4, kLoopWords = 8 };
-__device__ __forceinline__ void grid_barrier(unsigned int* word, unsigned int& target)
+enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3, kLoopFault = 4, kLoopBarrier = 5, kLoopWords = 8 };
+// false: the other blocks did not arrive within seconds (the grid was not resident at once after all -- a profiler or a partition
+// the occupancy query does not know of): the block raises st[kLoopFault] and leaves; the host reports it with the iteration counts
+// (DFSPHSolver::fetchIterations) and goes back to gated launches.  A hang here would take the whole device with it.
+__device__ __forceinline__ bool grid_barrier(unsigned int* word, unsigned int& target, int* fault)
 {
+    __shared__ int gaveUp;
+    if (threadIdx.x == 0) gaveUp = 0;
     __syncthreads();
 #ifndef SPHX_TAIL_FENCE
 #define SPHX_TAIL_FENCE 3          // experiments: bit 0 release fence, bit 1 acquire fence (anything but 3 computes wrong results)
@@ -851,10 +856,15 @@ __device__ __forceinline__ void grid_barrier(unsigned int* word, unsigned int& t
         target += gridDim.x;
         if (SPHX_TAIL_FENCE & 1) __threadfence();              // release: what this block wrote (agent scope: L2 write-back across XCDs)
         atomicAdd(word, 1u);
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(SPHX_TAIL_SLEEP);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(SPHX_TAIL_SLEEP);
+            if (++spins > (1u << 24)) { gaveUp = 1; *fault = 1; __threadfence(); break; }       // 2^24 x (uncached load + 128 clocks): seconds; a legitimate wait is a few ms
+        }
         if (SPHX_TAIL_FENCE & 2) __threadfence();              // acquire: drop what the caches hold of the other blocks' arrays
     }
     __syncthreads();
+    return gaveUp == 0;
 }
 // CM: the correction sweep's launch shape, 0 lane per particle (a block takes four tiles), 1 quad per particle (one tile)
 template <bool DENSITY_MODE, int WARM, int CM, int TOLC, int TOLR>
@@ -862,6 +872,7 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
 {
     static_assert(kErrorSlots == kWideBlock, "one accumulator per thread of a block");
     if (t.st[kLoopDone] != 0) return;                          // (written by the launch before this one: the same for every block)
+    if (__hip_atomic_load(t.st + kLoopFault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // a block that started late: the launch has failed already
     __shared__ unsigned long long part[kWideBlock / 64];
     unsigned int* const word = reinterpret_cast<unsigned int*>(t.st + kLoopBarrier);
     unsigned int target = 0;
@@ -882,7 +893,7 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
                 corr(i, in_range(corr.c, i), nullptr, nullptr);
             }
         }
-        grid_barrier(word, target);
+        if (!grid_barrier(word, target, t.st + kLoopFault)) return;
         for (int lt = (int)blockIdx.x; lt < rate.c.numTiles; lt += (int)gridDim.x) {
             assume_arith<TOLR>(rate.c);
             const int i = quad_particle_of(rate.c, lt);
@@ -895,7 +906,7 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
             if (stores_results<1>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(rate.out, i, b.e, rate.density[i], rate.alpha[i]);
             accumulate_error(fixed, rate.out.accum);
         }
-        grid_barrier(word, target);
+        if (!grid_barrier(word, target, t.st + kLoopFault)) return;
         unsigned long long v = t.accum[(size_t)threadIdx.x * kErrorSlotStride];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -923,7 +934,10 @@ inline bool launch_tail_kernel(const OpCorrect<DENSITY_MODE>& corr, const OpRate
         HIP_CALL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR>, kWideBlock, 0));
     }
     if (perCU < 1 || cus < 1) return false;
-    const int grid = std::min(corr.c.numTiles, perCU * cus);   // (the rate sweep takes one tile per block; a lane-walk correction four)
+    int grid = std::min(corr.c.numTiles, perCU * cus);         // (the rate sweep takes one tile per block; a lane-walk correction four)
+#ifdef SPHX_TEST_HOOKS
+    if (getenv("SPHX_DFSPH_TAIL_OVERSUBSCRIBE")) grid = std::max(corr.c.numTiles, 16 * perCU * cus);      // more blocks than fit: the barrier must time out and report
+#endif
     k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR><<<grid, kWideBlock, 0, stream()>>>(corr, rate, t);
     return true;
 }

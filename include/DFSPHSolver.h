@@ -100,6 +100,7 @@ private:
     // A prediction only -- the tail runs whatever is left, so the results do not depend on it; a change re-captures the step graph.
     int windowDiv = 3, windowDen = 4;
     // fixed counts: the coming divergence correction is the last one of the step and also applies the gravity kick (OpCorrect::addKick)
+    bool tailFailed = false;         // a grid barrier of the tail timed out once: gated launches from then on
     bool kickInCorrect = false;
     float3 kickDv = {0.0f, 0.0f, 0.0f};
     void adaptWindows();

@@ -101,8 +101,9 @@ def test_fault_hooks_live_in_the_test_build_only():
     product = os.path.join(ROOT, "cpp-fluid-particles_amd", "libsphx.so")
     hooks = os.path.join(ROOT, "tests", "libsphx_hooks.so")
     assert os.path.exists(product) and os.path.exists(hooks), "built by __graft_entry__.build()"
-    assert b"SPHX_SLAB_FAULT" not in open(product, "rb").read()
-    assert b"SPHX_SLAB_FAULT" in open(hooks, "rb").read()
+    for hook in (b"SPHX_SLAB_FAULT", b"SPHX_DFSPH_TAIL_OVERSUBSCRIBE"):
+        assert hook not in open(product, "rb").read(), hook
+        assert hook in open(hooks, "rb").read(), hook
 
 
 def test_obstacle_samplers(sphx):

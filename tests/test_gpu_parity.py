@@ -4,10 +4,14 @@ Bar: bit-exact for integer outputs (cell ids, cell starts, permutation/ids) AND 
 field — the engine keeps the reference's IEEE operation order, so equality is exact, not 1e-5.
 The stated north-star tolerance (1e-5 relative) is asserted as well where a looser check is the
 right statement (full-size properties)."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import assert_bit_equal, same_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -930,6 +934,37 @@ def test_adaptive_loops_tail_and_gated_launches_bit_exact(sphx, oracle, monkeypa
     assert batch.iters() == its[-1], "counts after a replayed batch"
     assert np.array_equal(batch.get(sphx.F_POS).view(np.uint32), gs.get(sphx.F_POS).view(np.uint32))
     batch.close()
+
+
+def test_loop_tail_that_cannot_be_resident_reports_a_fault_instead_of_hanging(tmp_path):
+    """the persistent tail launch spins on a grid barrier: launched with more blocks than the device holds at once (test build of the
+    library, SPHX_DFSPH_TAIL_OVERSUBSCRIBE) the barrier must time out, the step must be reported invalid through the C ABI, and the
+    solver must carry on with gated launches -- a hang here would take the device with it"""
+    import subprocess, sys, textwrap
+    hooks = os.path.join(ROOT, "tests", "libsphx_hooks.so")
+    assert os.path.exists(hooks), "tests/libsphx_hooks.so is built by __graft_entry__.build() (make -C tests)"
+    script = tmp_path / "oversubscribed.py"
+    script.write_text(textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, os.path.join(%r, "cpp-fluid-particles_amd"))
+        import sphx
+        P, f, b = sphx.scene(24); P.solver = sphx.DFSPH          # the reference scene: the loops run long once the column lands (~step 60)
+        s = sphx.System(P, f, b)
+        failed, after = 0, 0
+        for k in range(120):
+            try:
+                s.step()
+                if failed: after += 1
+            except RuntimeError as e:
+                failed += 1; print("step", k, "reported:", e, flush=True)
+            if after >= 10: break
+        assert failed == 1 and after == 10, (failed, after)
+        assert max(s.iters()) > 2, s.iters()                     # gated launches carry on
+        print("OK", flush=True)
+    """ % ROOT))
+    env = dict(os.environ, SPHX_LIB=hooks, SPHX_DFSPH_TAIL_OVERSUBSCRIBE="1", SPHX_DFSPH_WINDOW="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout and "grid barrier timed out" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_adaptive_row_capacity_grows_and_stays_exact(sphx, oracle):
