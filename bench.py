@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0) with, besides the contract's keys:
                      counted pair evaluations, PMC traffic from profiles/traffic.json when that file was measured on THIS source tree
   legs_by_arithmetic the same workload and window under the other contracts (strict = bit-exact IEEE, tolerance = the same arithmetic as
                      the headline with rows rebuilt every step), each with its own live roofline block
+  reference_default_iterations   the same scene and window under the reference's own adaptive iteration control (strict and headline arithmetic)
   steady_state       post-impact legs (ragged cells, wall contact): the 10 M scene under the reference's adaptive iteration
                      control and the 1 M config 3, >= 100 timed steps each, with neighbours-per-particle statistics
   configs            BASELINE configs 2, 3, 4 (263k WCSPH, 1M DFSPH, 1M PBD) and the reference scene (20,736 particles)
@@ -387,6 +388,20 @@ def main():
                 result["legs_by_arithmetic"][other] = {k: leg[k] for k in ("arithmetic", "steps_per_s", "ms_per_step", "step_hbm_roofline_frac", "roofline") if k in leg}
                 if "persistent_rows" in leg:
                     result["legs_by_arithmetic"][other]["persistent_rows"] = leg["persistent_rows"]
+        # The reference's DEFAULT iteration control on the same scene and window (adaptive loops, thresholds 1e-3, at most 20 iterations --
+        # main.cpp's DFSPHSolver; 1 divergence + 2 density iterations in free fall): loops decided on the device, the iterations beyond a
+        # window in one persistent launch (profiles/r04_dfsph_loop_tail.txt).  Graph replay, W + K steps like the headline.
+        if solver == "dfsph":
+            result["reference_default_iterations"] = {}
+            for arith in ("strict", "persistent"):
+                sim, P = make_system(sphx, args.nx, solver, -1, -1, args.pbd_iters, arith=arith)
+                if args.warmup > 0:
+                    sim.step_n(args.warmup)
+                wall, _ = timed_steps(torch, sim, args.steps)
+                result["reference_default_iterations"][arith] = {"steps_per_s": args.steps / wall, "ms_per_step": wall * 1e3 / args.steps,
+                                                                 "iterations_last_step": list(sim.iters()), "steps": args.steps, "warmup": args.warmup}
+                note("adaptive DFSPH (%s): %.2f ms/step, iterations %s" % (arith, wall * 1e3 / args.steps, sim.iters()))
+                sim.close()
         # Post-impact legs (ragged cells, wall contact, 40+ neighbours).  At 10 M particles the column hits the floor
         # around step 200; with the FIXED (1,4) iteration counts of config 5 the under-converged solve does not survive
         # that impact (densities and velocities run away within ~50 steps: tools/settle_probe.py), so the
