@@ -363,6 +363,17 @@ struct Slab {
 }  // namespace
 
 // ================================================================================ the group
+#ifdef SPHX_TEST_HOOKS
+// test build only: SPHX_SLAB_TRACE=1 prints where the host side of every rank is (the last line of a rank that hangs says where)
+static void slab_trace(int rank, int step, const char* what, long long arg = 0)
+{
+    static const bool on = std::getenv("SPHX_SLAB_TRACE") != nullptr;
+    if (on) { std::fprintf(stderr, "[slab rank %d step %d] %s %lld\n", rank, step, what, arg); std::fflush(stderr); }
+}
+#define SLAB_TRACE(what, arg) slab_trace(slabs[0]->rank, slabs[0]->stepsDone, what, (long long)(arg))
+#else
+#define SLAB_TRACE(what, arg) ((void)0)
+#endif
 struct sphx_slab_group {
     std::vector<std::unique_ptr<Slab>> slabs;
     std::unique_ptr<Transport> transport;
@@ -389,7 +400,14 @@ struct sphx_slab_group {
         if (e && std::strcmp(e, "0") == 0) return;
         int least = 0, greatest = 0;
         hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
-        hip_ok(hipStreamCreateWithPriority(&edgeStream, hipStreamNonBlocking, greatest), "edge stream");
+        // A DEFAULT-priority stream (r04).  Until r04 this was the highest priority the device has; with 8 processes sharing the one
+        // test GPU (tests/test_gpu_slab.py, 8 ranks, transfers completing late) a rank then now and then computed different bits or died
+        // of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in its first step -- 4 of 30 runs, in the r03 sources as well; 0 of 24 with this
+        // stream at default priority, 0 of 12 without it (profiles/r04_slab_edge_stream_priority.txt).  The edge kernels are enqueued
+        // before the interior of their stage, so they start first anyway.  SPHX_EDGE_PRIORITY=high restores the old stream.
+        const char* pr = std::getenv("SPHX_EDGE_PRIORITY");
+        if (pr && std::strcmp(pr, "high") == 0) hip_ok(hipStreamCreateWithPriority(&edgeStream, hipStreamNonBlocking, greatest), "edge stream");
+        else hip_ok(hipStreamCreateWithFlags(&edgeStream, hipStreamNonBlocking), "edge stream");
         hip_ok(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "event");
         hip_ok(hipEventCreateWithFlags(&joinEvent, hipEventDisableTiming), "event");
     }
@@ -462,13 +480,16 @@ struct sphx_slab_group {
             if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.counts.p + 0, 24}); recvs.push_back({s.rank - 1, s.rank, s.counts.p + 6, 24}); }
             if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.counts.p + 3, 24}); recvs.push_back({s.rank + 1, s.rank, s.counts.p + 9, 24}); }
         }
+        SLAB_TRACE("size exchange: posting", sends.size());
         transport->exchange(sends, recvs, false);
+        SLAB_TRACE("size exchange: posted", 0);
         for (auto& sp : slabs) {
             Slab& s = *sp;
             hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 13 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
             hip_ok(hipMemcpyAsync(s.hInts + 6, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
         }
         sync("particle exchange (sizes)");
+        SLAB_TRACE("size exchange: synchronised", 0);
         // Rank-local failures are only known now (the violation flag, and the capacity check needs the neighbours' sizes),
         // but the neighbours are about to post receives for THIS rank's payload: a rank that simply returned an error here
         // would leave them waiting in ncclRecv.  So every rank contributes its failure code to one all-reduce and all of
@@ -488,6 +509,7 @@ struct sphx_slab_group {
         }
 #endif
         const long long anyBad = world > (int)slabs.size() ? transport->allreduce_sum(bad) : bad;
+        SLAB_TRACE("failure word reduced", anyBad);
         if (anyBad) {
             const char* here = bad ? "this process" : "another rank";
             if (anyBad & ((1LL << 20) - 1)) die(std::string("slab: a particle crossed more than one cell column in one step (") + here + ")");
@@ -529,7 +551,9 @@ struct sphx_slab_group {
     void updateLayers()
     {
         const auto t0 = std::chrono::steady_clock::now();
+        SLAB_TRACE("waiting for the layer offsets", 0);
         for (auto& sp : slabs) hip_ok(hipEventSynchronize(sp->layersReady), "layer offsets");
+        SLAB_TRACE("layer offsets here", 0);
         waitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (auto& sp : slabs) {
             Slab& s = *sp;
@@ -565,6 +589,7 @@ struct sphx_slab_group {
 
     void runAll(int phase)
     {
+        SLAB_TRACE("stage (all held particles)", phase);
         transport->wait();
         for (auto& sp : slabs) sp->sys->system->phase(phase);
     }
@@ -574,6 +599,7 @@ struct sphx_slab_group {
     // reduce: the stage accumulates the exact |error| total of the owned particles (adaptive DFSPH).
     void sweepStage(int phase, const std::vector<int>& halo, bool reduce = false)
     {
+        SLAB_TRACE("stage", phase);
         transport->wait();                      // the edges read ghost values written by the previous stage's halo
         const bool sweepGhosts = !overlap() && (flags & SPHX_SLAB_SWEEP_GHOSTS);
         if (!overlap()) {

@@ -39,7 +39,8 @@ namespace {
 
 constexpr int kMaxRanks = 8;
 constexpr size_t kChunk = 1u << 20;            // bytes of one mailbox
-constexpr double kTimeoutSeconds = 60.0;       // a protocol deadlock becomes an error, not a hung box
+// a protocol deadlock becomes an error, not a hung box (SPHX_MOCK_RCCL_TIMEOUT_S: diagnostics)
+const double kTimeoutSeconds = [] { const char* e = std::getenv("SPHX_MOCK_RCCL_TIMEOUT_S"); return e ? std::atof(e) : 60.0; }();
 
 struct Box {                                   // one direction of one pair: single producer, single consumer
     std::atomic<uint64_t> written, consumed;   // chunk counters
@@ -165,13 +166,14 @@ __global__ void k_mock_delay(long long ticks)
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
-struct Deferred { std::vector<Op> ops; hipEvent_t done; std::vector<char*> pinned; int status; };
+struct Deferred { std::vector<Op> ops; hipEvent_t done; std::vector<char*> pinned; int status; int sleepUs; };
 std::vector<Deferred*> g_inflight;         // groups whose stream work may still be running (single host thread per process)
 std::atomic<int> g_deferredError{0};
 
 void deferred_callback(void* p)
 {
     Deferred* d = (Deferred*)p;
+    if (d->sleepUs > 0) usleep((useconds_t)d->sleepUs);
     d->status = move_messages(d->ops);
     if (d->status) g_deferredError.store(d->status);
 }
@@ -210,7 +212,13 @@ int run_group()
     if (d->ops.empty()) { delete d; return 0; }
     hipStream_t st = d->ops[0].stream;
     for (const Op& o : d->ops) if (o.stream != st) { delete d; return fail("deferred mode expects one stream per group"); }
-    hipLaunchKernelGGL(k_mock_delay, dim3(1), dim3(1), 0, st, (long long)defer_us() * 100);     // wall_clock64: 100 MHz
+    // the delay: a spin kernel on the stream (SPHX_MOCK_RCCL_SPIN_KERNEL=1, the r03 form) or -- default -- a sleep at the start of the
+    // stream-ordered host callback below.  Either way the transfers complete that long after ncclGroupEnd returned, in stream order.
+    // (r04: with 8 processes on the one test GPU a process now and then died of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in its first step in
+    // deferred mode only; the long-running one-thread spin kernel being pre-empted was the one thing the immediate mode does not have.)
+    static const bool spinKernel = [] { const char* e = std::getenv("SPHX_MOCK_RCCL_SPIN_KERNEL"); return e && std::atoi(e) != 0; }();
+    if (spinKernel) hipLaunchKernelGGL(k_mock_delay, dim3(1), dim3(1), 0, st, (long long)defer_us() * 100);     // wall_clock64: 100 MHz
+    d->sleepUs = spinKernel ? 0 : defer_us();
     for (Op& o : d->ops) {
         if (hipHostMalloc((void**)&o.host, o.bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned staging allocation failed");
         d->pinned.push_back(o.host);

@@ -15,6 +15,9 @@ import sphx
 
 def main():
     rank, world, nx, steps, seed = (int(a) for a in sys.argv[1:6])
+    if os.environ.get("SPHX_TEST_WATCHDOG_S"):           # diagnostics: where is this rank after that many seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SPHX_TEST_WATCHDOG_S"]), exit=True)
     solver, adaptive, rebalance, outdir = sys.argv[6], sys.argv[7] == "1", sys.argv[8] == "1", sys.argv[9]
     sphx.set_device(0)
     P, fluid, boundary = sphx.scene(nx)

@@ -185,7 +185,7 @@ def _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, li
                                str(steps), str(seed), solver, "1" if adaptive else "0", "1" if rebalance else "0", str(tmp_path)], env=env)
              for r in range(world)]
     try:
-        codes = [p.wait(timeout=600) for p in procs]
+        codes = [p.wait(timeout=240) for p in procs]
     finally:
         for p in procs:
             if p.poll() is None:
