@@ -5,6 +5,7 @@ particle exchange, edge-first stages so that halo traffic overlaps the interior 
 bootstraps it: the 128-byte RCCL token and the closing barrier / max-over-ranks travel over a gloo side group.
 (The torch.distributed restatement of the protocol that used to live here is test infrastructure: tests/slab_protocol.py.)
 """
+import os
 import time
 
 import torch
@@ -26,6 +27,11 @@ def run_slab_bench(args, rank, world, local_rank):
     import sphx
     torch.cuda.set_device(local_rank)
     sphx.set_device(local_rank)
+    # The edge stream of the slab layer is a default-priority stream unless asked otherwise (several PROCESSES sharing one device with a
+    # highest-priority queue each is what made a rank fail now and then: profiles/r04_slab_edge_stream_priority.txt).  A bench process
+    # has its device to itself -- one rank per GPU, or one process driving all slabs -- so it asks for the highest priority.
+    if world == 1 or torch.cuda.device_count() >= world:
+        os.environ.setdefault("SPHX_EDGE_PRIORITY", "high")
     P, fluid, boundary = sphx.scene(args.nx)
     solver_name = getattr(args, "solver", "dfsph")
     P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver_name]
