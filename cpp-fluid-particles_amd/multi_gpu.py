@@ -28,9 +28,11 @@ def run_slab_bench(args, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     sphx.set_device(local_rank)
     # The edge stream of the slab layer is a default-priority stream unless asked otherwise (several PROCESSES sharing one device with a
-    # highest-priority queue each is what made a rank fail now and then: profiles/r04_slab_edge_stream_priority.txt).  A bench process
-    # has its device to itself -- one rank per GPU, or one process driving all slabs -- so it asks for the highest priority.
-    if world == 1 or torch.cuda.device_count() >= world:
+    # highest-priority queue each is what made a rank fail now and then: profiles/r04_slab_edge_stream_priority.txt).  ONE process driving
+    # all slabs of a device is the setting every one-device measurement since r03 ran in with the highest priority, bit-exact throughout:
+    # it asks for it (worth 10 % with 8 slabs over the installed RCCL).  One rank per GPU keeps the default until a node has shown the
+    # high-priority queue to be safe there: with one slab per device the edge kernels are enqueued first and start first anyway.
+    if world == 1:
         os.environ.setdefault("SPHX_EDGE_PRIORITY", "high")
     P, fluid, boundary = sphx.scene(args.nx)
     solver_name = getattr(args, "solver", "dfsph")
