@@ -181,15 +181,29 @@ def _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, li
     env.update(extra_env or {})
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(slab_worker.ROOT, "tests"), os.path.join(slab_worker.ROOT, "cpp-fluid-particles_amd"),
                                          slab_worker.ROOT, env.get("PYTHONPATH", "")])
-    procs = [subprocess.Popen([sys.executable, os.path.join(slab_worker.ROOT, "tests", "slab_rccl_worker.py"), str(r), str(world), str(nx),
-                               str(steps), str(seed), solver, "1" if adaptive else "0", "1" if rebalance else "0", str(tmp_path)], env=env)
-             for r in range(world)]
-    try:
-        codes = [p.wait(timeout=240) for p in procs]
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    def launch():
+        procs = [subprocess.Popen([sys.executable, os.path.join(slab_worker.ROOT, "tests", "slab_rccl_worker.py"), str(r), str(world), str(nx),
+                                   str(steps), str(seed), solver, "1" if adaptive else "0", "1" if rebalance else "0", str(tmp_path)], env=env)
+                 for r in range(world)]
+        try:
+            return [p.wait(timeout=240) for p in procs]
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    codes = launch()
+    # Several processes oversubscribing the ONE test GPU is something the platform itself gets wrong now and then: a rank killed by the
+    # runtime (SIGABRT after "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION", 1 run in 7 before the edge stream lost its high priority, none in
+    # 38 since: profiles/r04_slab_edge_stream_priority.txt).  A rank that DIED OF A SIGNAL -- never a wrong result, a time-out or an
+    # error of ours -- gets the case one more run, said loudly.
+    if expect_codes is None and any(c is not None and c < 0 for c in codes):
+        print("\n[test_gpu_slab] rank exit codes %s: a rank was killed by a signal (platform, not an assertion); running the case once more" % (codes,))
+        for f in tmp_path.glob("rank*.npz"):
+            f.unlink()
+        token = tmp_path / "token"
+        if token.exists():
+            token.unlink()
+        codes = launch()
     if expect_codes is not None:
         return codes
     assert codes == [0] * world, "rank exit codes %s" % (codes,)
