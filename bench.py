@@ -80,6 +80,8 @@ def parse():
                     help="arithmetic contract of the HEADLINE leg: persistent (default: the north star's 1e-5 contract -- the reference's own "
                          "binary is built -use_fast_math -- with neighbour rows kept across steps), tolerance (the same arithmetic, rows rebuilt "
                          "every step) or strict (bit-exact IEEE, the parity contract)")
+    ap.add_argument("--tuning", default="", help="engine tuning for experiments: comma-separated sphx_tuning fields, e.g. row_capacity=64,dfsph_no_tail=1 "
+                                                  "(include/sphx_c.h; the library reads no SPHX_* environment variables)")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -220,11 +222,12 @@ def timed_steps(torch, sim, steps):
     return time.perf_counter() - t0, ms_events
 
 
-def settled_leg(sphx, torch, nx, solver, div, den, settle, steps):
+def settled_leg(sphx, torch, nx, solver, div, den, settle, steps, arith="strict"):
     """advance a fresh system past the impact, then time `steps` steps there"""
-    sim, P = make_system(sphx, nx, solver, div, den, 4)
+    sim, P = make_system(sphx, nx, solver, div, den, 4, arith=arith)
     what = "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults: 1e-3 thresholds, <= 20 iterations)"
-    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, strict arithmetic" % (nx, sim.n, what, P.dt), "after_steps": 1 + settle}
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, %s arithmetic" % (nx, sim.n, what, P.dt, arith), "arithmetic": arith,
+           "after_steps": 1 + settle}
     done, first = 0, None
     while done < settle:              # in slices, so that a run-away state shows up instead of eating the time budget
         k = min(50, settle - done)
@@ -248,17 +251,21 @@ def settled_leg(sphx, torch, nx, solver, div, den, settle, steps):
     leg.update({"steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
                 "step_hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS,
                 "neighbours_per_particle": neighbour_stats(sim)})
-    note("post-impact leg nx=%d done: %.2f ms/step" % (nx, wall * 1e3 / steps))
+    if arith == "persistent":
+        # (in use = at the end of the leg: while nearly every step rebuilds its rows the controller leaves the mode for 256 steps at a time)
+        in_use, builds, counted = sim.persistent_stats()
+        leg["persistent_rows"] = {"in_use_at_end": in_use, "row_builds": builds, "steps_in_mode": counted}
+    note("post-impact leg nx=%d (%s) done: %.2f ms/step" % (nx, arith, wall * 1e3 / steps))
     sim.close()
     return leg
 
 
-def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup):
+def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup, arith="strict"):
     """one of the BASELINE configs that are parity-test cases rather than the headline: graph-replayed steps"""
-    sim, P = make_system(sphx, nx, solver, div, den, pbd_iters)
+    sim, P = make_system(sphx, nx, solver, div, den, pbd_iters, arith=arith)
     sim.step_n(warmup)
     wall, _ = timed_steps(torch, sim, steps)
-    note("leg nx=%d %s: %.3f ms/step" % (nx, solver, wall * 1e3 / steps))
+    note("leg nx=%d %s (%s): %.3f ms/step" % (nx, solver, arith, wall * 1e3 / steps))
     sps = steps / wall
     what = {"wcsph": "WCSPH", "dfsph": "DFSPH(%d,%d fixed)" % (div, den) if div >= 0 else "DFSPH(adaptive, reference defaults)",
             "pbd": "PBD(%d Jacobi)" % pbd_iters}[solver]
@@ -267,7 +274,7 @@ def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup):
         div, den = sim.iters()                  # iteration counts of the last step
         what += ", last step ran (%d,%d) iterations" % (div, den)
     bpp = step_bytes_per_particle(solver, div, den, pbd_iters, fixed)
-    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, strict arithmetic" % (nx, sim.n, what, P.dt),
+    leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, %s arithmetic" % (nx, sim.n, what, P.dt, arith), "arithmetic": arith,
            "particles": sim.n, "steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
            "algorithmic_GBps": bpp * sim.n * sps / 1e9, "hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS}
     sim.close()
@@ -296,6 +303,9 @@ def main():
     import sphx
     if sphx.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    if args.tuning:
+        fields = dict(kv.split("=", 1) for kv in args.tuning.split(","))
+        sphx.set_tuning(**{k: (float(v) if k == "pbd_skin" else int(v)) for k, v in fields.items()})
 
     if args.gpus > 1 or args.force_slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
@@ -330,6 +340,7 @@ def main():
         wall, ms_events = timed_steps(torch, sim, args.steps)
         spans = sphx.kernel_timer_collect() if span else {}
         sphx.kernel_timer(False)
+        variant, kernel_name = sphx.last_rate_kernel()          # the instantiation the error sweeps of this leg were really launched as
         note("%s leg: %.2f ms/step" % (arith, wall * 1e3 / args.steps))
         nb = neighbour_stats(sim)
         sps = args.steps / wall
@@ -343,9 +354,11 @@ def main():
             tot_ms, launches = spans[span]
             avg_ms = tot_ms / launches
             achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
-            pmc = read_traffic("%s_nx%d%s" % (solver, args.nx, "" if arith == "strict" else "_tol"))    # None unless measured on exactly this source tree
+            # counters of THAT instantiation (profiles/traffic.json): strict quad walk "", the strict walk serving a tolerance step "_tolplain",
+            # the tolerance walk (with the skin re-test when rows persist) "_tol"; None unless measured on exactly this source tree
+            pmc = read_traffic("%s_nx%d%s" % (solver, args.nx, {1: "", 3: "_tolplain", 2: "_tol"}.get(variant, "_other")))
             flops = RATE_KERNEL_FLOP_PER_PAIR * nb["pairs"] / (avg_ms * 1e-3) / 1e12
-            leg["roofline"] = {"bound": "hbm", "kernel": "k_rate_quad<DENSITY_MODE, WARM, %d> (span '%s')" % (0 if arith == "strict" else 1, span),
+            leg["roofline"] = {"bound": "hbm", "kernel": "%s (span '%s')" % (kernel_name, span),
                                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
                                "avg_launch_ms": avg_ms, "launches": launches,
@@ -407,18 +420,21 @@ def main():
         # that impact (densities and velocities run away within ~50 steps: tools/settle_probe.py), so the
         # 10 M leg runs the reference's own adaptive iteration control (thresholds 1e-3, at most 20 iterations); the
         # 1 M config keeps its fixed counts, which do survive.
-        result["steady_state"] = [
-            settled_leg(sphx, torch, args.nx, "dfsph", -1, -1, args.settle_steps, args.steady_steps),
-            settled_leg(sphx, torch, 88, "dfsph", 1, 4, args.settle_steps, args.steady_steps),
-        ]
+        # r05: every arithmetic contract is timed here too -- the headline arithmetic is not only a free-fall number.
+        result["steady_state"] = [settled_leg(sphx, torch, args.nx, "dfsph", -1, -1, args.settle_steps, args.steady_steps, arith=a)
+                                  for a in ("strict", "tolerance", "persistent")]
+        result["steady_state"] += [settled_leg(sphx, torch, 88, "dfsph", 1, 4, args.settle_steps, args.steady_steps, arith=a)
+                                   for a in ("strict", "persistent")]
     if not args.no_extra_legs:
         legs = []
-        for nx, sv, steps in ((56, "wcsph", 200), (88, "dfsph", 100), (88, "pbd", 100)):      # BASELINE configs 2, 3, 4
-            legs.append(small_leg(sphx, torch, nx, sv, 1, 4, 4, steps, 10))
-        # the reference's own scene and defaults (20,736 particles; adaptive DFSPH, 20 PBD iterations), next to which
-        # BASELINE.md quotes 4.4 / 23.0 / 11.3 ms per frame on a GTX 1070
-        for sv, steps in (("wcsph", 300), ("dfsph", 100), ("pbd", 100)):
-            legs.append(small_leg(sphx, torch, 24, sv, -1, -1, 20, steps, 10))
+        # each in the parity contract (strict) and in the headline arithmetic (persistent; PBD keeps its own skin rows and runs as tolerance)
+        for arith in ("strict", "persistent"):
+            for nx, sv, steps in ((56, "wcsph", 200), (88, "dfsph", 100), (88, "pbd", 100)):      # BASELINE configs 2, 3, 4
+                legs.append(small_leg(sphx, torch, nx, sv, 1, 4, 4, steps, 10, arith=arith))
+            # the reference's own scene and defaults (20,736 particles; adaptive DFSPH, 20 PBD iterations), next to which
+            # BASELINE.md quotes 4.4 / 23.0 / 11.3 ms per frame on a GTX 1070
+            for sv, steps in (("wcsph", 300), ("dfsph", 100), ("pbd", 100)):
+                legs.append(small_leg(sphx, torch, 24, sv, -1, -1, 20, steps, 10, arith=arith))
         result["configs"] = legs
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, n)

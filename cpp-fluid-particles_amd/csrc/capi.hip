@@ -76,6 +76,45 @@ int sphx_device_pci_id(int ordinal, char* out, int capacity)
     return SPHX_OK;
 }
 
+// ------------------------------------------------------------------------------------ tuning block (sphx_tuning)
+int sphx_tuning_defaults(sphx_tuning* out)
+{
+    if (!out) return fail(SPHX_ERR_INVALID, "sphx_tuning_defaults: null block");
+    *out = sphx::default_tuning();
+    return SPHX_OK;
+}
+
+int sphx_set_tuning(const sphx_tuning* t)
+{
+    if (!t) { sphx::install_tuning(sphx::default_tuning()); return SPHX_OK; }
+    if (t->struct_size != (int)sizeof(sphx_tuning)) return fail(SPHX_ERR_INVALID, "sphx_set_tuning: struct_size does not match this library's sphx_tuning");
+    if ((t->row_capacity != 0 && (t->row_capacity < 8 || t->row_capacity > 1024)) || t->slab_comm_priority < 0 || t->slab_comm_priority > 2 ||
+        t->slab_edge_priority < 0 || t->slab_edge_priority > 1)
+        return fail(SPHX_ERR_INVALID, "sphx_set_tuning: a field is out of range (row_capacity 0 or 8..1024, slab_comm_priority 0..2, slab_edge_priority 0..1)");
+    sphx::install_tuning(*t);
+    return SPHX_OK;
+}
+
+int sphx_get_tuning(sphx_tuning* out)
+{
+    if (!out) return fail(SPHX_ERR_INVALID, "sphx_get_tuning: null block");
+    *out = sphx::tuning();
+    return SPHX_OK;
+}
+
+// the instantiation the most recent density / divergence error sweep was launched as (bench.py names it in its roofline block)
+int sphx_last_rate_kernel(char* out, int capacity)
+{
+    if (!out || capacity < 48) return fail(SPHX_ERR_INVALID, "sphx_last_rate_kernel: bad argument");
+    static const char* const names[] = {"none", "k_rate_quad<DENSITY_MODE, WARM, 0> (strict quad walk)", "k_rate_quad<DENSITY_MODE, WARM, 1> (tolerance quad walk)",
+                                        "k_rate_quad<DENSITY_MODE, WARM, 0> (strict quad walk serving a tolerance-mode step)",
+                                        "k_rate_duo<DENSITY_MODE, WARM>", "k_rate<DENSITY_MODE, WARM, false> (lane per particle)",
+                                        "k_rate<DENSITY_MODE, WARM, true> (LDS tiles)", "k_rate_brick<DENSITY_MODE, WARM>"};
+    const int v = std::min(std::max(sphx::g_lastRateVariant, 0), 7);
+    std::strncpy(out, names[v], (size_t)capacity - 1); out[capacity - 1] = 0;
+    return v;
+}
+
 // ------------------------------------------------------------------------------------ scene
 // Constants of main.cpp:54-67; block and shell samplers of main.cpp:73-117; scaling rule of
 // BASELINE.md §4 (s = nx/24; nx = 24 reproduces the reference scene bit-for-bit).
@@ -344,15 +383,28 @@ int sphx_iters(const sphx_system* h, int* div, int* den)
 }
 
 // ------------------------------------------------------------------------------------ fields
-int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
+// API fields: current in the reference's order after every step, whatever the mode.  Everything else is a per-particle array of the
+// solver, which lives in the WORKING order while persistent rows are in use.
+static bool api_field(int field)
 {
-    // persistent rows: the API arrays and the grid tables are current after every step; the solver's own per-particle arrays
-    // live in the working order until somebody asks for them
     switch (field) {
     case SPHX_F_POS: case SPHX_F_VEL: case SPHX_F_DENSITY: case SPHX_F_PRESSURE: case SPHX_F_MASS: case SPHX_F_CELL:
-    case SPHX_F_CELLSTART_F: case SPHX_F_CELLSTART_B: case SPHX_F_ID: case SPHX_F_BPOS: case SPHX_F_BMASS: break;
-    default: h->system->invalidatePersistentOrder(); break;
+    case SPHX_F_CELLSTART_F: case SPHX_F_CELLSTART_B: case SPHX_F_ID: case SPHX_F_BPOS: case SPHX_F_BMASS: return true;
+    default: return false;
     }
+}
+static int locate_noflush(const sphx_system* h, int field, void** ptr, size_t* bytes);
+
+// pointer + size of a field for callers that read or write it IN PLACE: with persistent rows the solver's own arrays are first
+// brought into the API order (the next step re-primes the working copy and rebuilds the rows); may throw
+int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
+{
+    if (!api_field(field)) h->system->invalidatePersistentOrder();
+    return locate_noflush(h, field, ptr, bytes);
+}
+
+static int locate_noflush(const sphx_system* h, int field, void** ptr, size_t* bytes)
+{
     const auto f = h->system->getFluids();
     const auto b = h->system->getBoundaries();
     const size_t n = (size_t)h->n, nb = (size_t)h->nb;
@@ -391,27 +443,57 @@ int sphx_locate(const sphx_system* h, int field, void** ptr, size_t* bytes)
 int sphx_field_bytes(const sphx_system* h, int field, size_t* bytes)
 {
     void* p;
-    if (!h || !bytes || sphx_locate(h, field, &p, bytes)) return fail(SPHX_ERR_INVALID, "sphx_field_bytes: unknown field for this solver");
+    if (!h || !bytes || locate_noflush(h, field, &p, bytes)) return fail(SPHX_ERR_INVALID, "sphx_field_bytes: unknown field for this solver");
     return SPHX_OK;
 }
 
+// Raw device pointer of a field.  With persistent rows (reserved[3] = 2): the API fields (POS ... BMASS) are exported by every step and
+// may be READ freely; a caller that WRITES one of them through the pointer must call sphx_invalidate_order() before the next step (the
+// solver steps a working copy: the write would otherwise be overwritten by the next export).  Asking for a solver-internal field
+// flushes the mode (the arrays are permuted into API order, the next step rebuilds its rows): use sphx_get for per-step diagnostics.
 int sphx_device_ptr(const sphx_system* h, int field, void** out)
 {
-    size_t sz;
-    if (!h || !out || sphx_locate(h, field, out, &sz)) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: unknown field for this solver");
-    return SPHX_OK;
+    if (!h || !out) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: bad argument");
+    return guarded("sphx_device_ptr", [&] {
+        size_t sz;
+        if (sphx_locate(h, field, out, &sz)) return fail(SPHX_ERR_INVALID, "sphx_device_ptr: unknown field for this solver");
+        return (int)SPHX_OK;
+    });
+}
+
+int sphx_invalidate_order(sphx_system* h)
+{
+    if (!h) return fail(SPHX_ERR_INVALID, "sphx_invalidate_order: null system");
+    return guarded("sphx_invalidate_order", [&] { h->system->invalidatePersistentOrder(); return (int)SPHX_OK; });
 }
 
 int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
 {
-    void* p; size_t sz;
-    if (!h || !dst || sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
-    if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_get: size mismatch");
-    if (!sz) return SPHX_OK;
-    if (hipMemcpyAsync(dst, p, sz, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
-        hipStreamSynchronize(sphx::stream()) != hipSuccess)
-        return fail(SPHX_ERR_HIP, "sphx_get: copy failed");
-    return SPHX_OK;
+    if (!h || !dst) return fail(SPHX_ERR_INVALID, "sphx_get: bad argument");
+    return guarded("sphx_get", [&] {
+        void* p; size_t sz;
+        if (locate_noflush(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
+        if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_get: size mismatch");
+        if (!sz) return (int)SPHX_OK;
+        // persistent rows: a solver-internal array is in the working order.  4- and 12-byte fields are read THROUGH the slot map into
+        // a scratch buffer (the mode stays as it is: a per-step diagnostic read costs one gather); the 16-byte engine mirrors flush it.
+        const int* slotMap = api_field(field) ? nullptr : h->system->persistentSlotMap();
+        const size_t n = (size_t)h->n;
+        std::unique_ptr<DArray<float>> scratch;
+        if (slotMap && n > 0 && (sz == 4 * n || sz == 12 * n)) {
+            const int live = (int)h->system->getFluids()->size();
+            scratch.reset(new DArray<float>((unsigned)(sz / 4)));
+            if (sz == 4 * n) ew_gather_float(scratch->addr(), static_cast<const float*>(p), slotMap, live);
+            else ew_gather_float3(reinterpret_cast<float3*>(scratch->addr()), static_cast<const float3*>(p), slotMap, live);
+            p = scratch->addr();
+        } else if (slotMap) {
+            if (sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_get: unknown field for this solver");
+        }
+        if (hipMemcpyAsync(dst, p, sz, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+            hipStreamSynchronize(sphx::stream()) != hipSuccess)
+            return fail(SPHX_ERR_HIP, "sphx_get: copy failed");
+        return (int)SPHX_OK;
+    });
 }
 
 int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
@@ -419,17 +501,20 @@ int sphx_set(sphx_system* h, int field, const void* src, size_t bytes)
     if (field != SPHX_F_POS && field != SPHX_F_VEL && field != SPHX_F_WARM && field != SPHX_F_BMASS && field != SPHX_F_POS_LAST &&
         field != SPHX_F_ID)
         return fail(SPHX_ERR_INVALID, "sphx_set: field is read-only");
-    void* p; size_t sz;
-    if (h) h->system->invalidatePersistentOrder();       // the working copy is re-primed from the API arrays by the next step
-    if (!h || !src || sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
-    if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
-    if (!sz) return SPHX_OK;
-    if (hipMemcpyAsync(p, src, sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
-        hipStreamSynchronize(sphx::stream()) != hipSuccess)
-        return fail(SPHX_ERR_HIP, "sphx_set: copy failed");
-    if (field == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
-    if (field == SPHX_F_POS_LAST && h->pbd) h->pbd->markPosLastInitialized();
-    return SPHX_OK;
+    if (!h || !src) return fail(SPHX_ERR_INVALID, "sphx_set: bad argument");
+    return guarded("sphx_set", [&] {
+        void* p; size_t sz;
+        h->system->invalidatePersistentOrder();       // the working copy is re-primed from the API arrays by the next step
+        if (sphx_locate(h, field, &p, &sz)) return fail(SPHX_ERR_INVALID, "sphx_set: unknown field for this solver");
+        if (bytes != sz) return fail(SPHX_ERR_INVALID, "sphx_set: size mismatch");
+        if (!sz) return (int)SPHX_OK;
+        if (hipMemcpyAsync(p, src, sz, hipMemcpyHostToDevice, sphx::stream()) != hipSuccess ||
+            hipStreamSynchronize(sphx::stream()) != hipSuccess)
+            return fail(SPHX_ERR_HIP, "sphx_set: copy failed");
+        if (field == SPHX_F_BMASS && h->wcsph) h->wcsph->invalidateBoundary();
+        if (field == SPHX_F_POS_LAST && h->pbd) h->pbd->markPosLastInitialized();
+        return (int)SPHX_OK;
+    });
 }
 
 int sphx_run_phase(sphx_system* h, int phase)
@@ -453,9 +538,11 @@ int sphx_error_total_fixed(sphx_system* h, long long* total)
 int sphx_set_count(sphx_system* h, int n_fluid)
 {
     if (!h || n_fluid < 0 || n_fluid > h->n) return fail(SPHX_ERR_INVALID, "sphx_set_count: count exceeds the capacity given to sphx_create");
-    h->system->invalidatePersistentOrder();
-    h->system->getFluids()->setActiveCount((unsigned)n_fluid);
-    return SPHX_OK;
+    return guarded("sphx_set_count", [&] {
+        h->system->invalidatePersistentOrder();
+        h->system->getFluids()->setActiveCount((unsigned)n_fluid);
+        return (int)SPHX_OK;
+    });
 }
 
 int sphx_use_stream(void* hip_stream)

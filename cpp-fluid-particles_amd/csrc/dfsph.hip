@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kErrorSlots) k_loop_decide(int* __restrict__ s
 
 bool DFSPHSolver::deviceLoops() const
 {
-    static const bool hostLoop = getenv("SPHX_DFSPH_HOST_LOOP") != nullptr;
+    const bool hostLoop = tuning().dfsph_host_loop != 0;
     const SweepCache& c = const_cast<DFSPHSolver*>(this)->cache();
     return fixedDiv < 0 && fixedDen < 0 && !hostLoop && !c.isSlab && c.fused() && !c.brickWanted && maxIter >= 1;
 }
@@ -81,7 +81,7 @@ void DFSPHSolver::fetchIterations()
         tailFailed = true;
         ++cache().generation;
         HIP_CALL(hipMemsetAsync(loopState.addr(kLoopFault), 0, sizeof(int), sphx::stream()));
-        throw "DFSPHSolver: the loop tail's grid barrier timed out (its blocks were not resident at once); the last step is invalid, the solver continues with gated launches";
+        throw "DFSPHSolver: the loop tail's grid barrier timed out (its blocks were not resident at once). The step that reported it and the steps enqueued behind it did NOT move any particle (positions are those of the last valid step) but their velocities are only partly corrected: restore velocities from a checkpoint or accept them; the solver continues with gated launches";
     }
 }
 
@@ -272,9 +272,9 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
                  rhoB, visc, G, surfaceTensionIntensity, airPressure, reduce);
     };
     const bool onDevice = deviceLoops();
-    if (onDevice && getenv("SPHX_DFSPH_WINDOW")) adaptWindows();
+    if (onDevice && tuning().dfsph_window >= 0) adaptWindows();
     // fixed counts with at least one divergence correction: the gravity kick rides in the last correction's store
-    const bool kickFused = !onDevice && fixedDiv >= 1 && !c.isSlab && num > 0 && getenv("SPHX_NO_KICK_FUSION") == nullptr;
+    const bool kickFused = !onDevice && fixedDiv >= 1 && !c.isSlab && num > 0 && !tuning().no_kick_fusion;
     kickDv = make_float3(dt * G.x, dt * G.y, dt * G.z);
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
     // `iterations` possible iterations of one loop, all enqueued: body(k) launches the sweeps of iteration k
@@ -340,7 +340,11 @@ void DFSPHSolver::step(std::shared_ptr<SPHParticles>& fluids, const std::shared_
         }
         lastDen = iter;
     }
+    // a step whose loop tail reported a fault (its grid barrier timed out: velocities only partly corrected) is NOT advected: positions,
+    // cell indices and the exported arrays stay those of the last valid step until the host has reported it (fetchIterations)
+    c.advectSkipIf = onDevice ? loopState.addr(kLoopFault) : nullptr;
     run(SPHX_PH_ADVECT);
+    c.advectSkipIf = nullptr;
     if (onDevice) {          // the counts of this step: device words -> pinned host memory, read on demand (fetchIterations)
         HIP_CALL(hipMemcpyAsync(hostIters, loopState.addr(kLoopDiv), 3 * sizeof(int), hipMemcpyDeviceToHost, sphx::stream()));      // counts + the tail's fault word
     }
@@ -363,9 +367,9 @@ void DFSPHSolver::tune(int stepsSinceLastCall)
 // grow at once (to twice the need, so that a rising count does not re-capture every few steps), shrink only when far too wide
 void DFSPHSolver::adaptWindows()
 {
-    // SPHX_DFSPH_WINDOW=k: fixed windows (tests: 0 leaves every iteration beyond the reference's minimum to the tail kernel)
-    if (const char* e = getenv("SPHX_DFSPH_WINDOW")) {
-        const int w = std::max(0, atoi(e));
+    // sphx_tuning.dfsph_window = k: fixed windows (tests: 0 leaves every iteration beyond the reference's minimum to the tail kernel)
+    if (tuning().dfsph_window >= 0) {
+        const int w = tuning().dfsph_window;
         if (w != windowDiv || w != windowDen) { windowDiv = windowDen = w; ++cache().generation; }
         return;
     }
@@ -385,7 +389,7 @@ void DFSPHSolver::adaptWindows()
 bool DFSPHSolver::runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& fluids, const DArray<int>& cellStartFluid,
                               const DArray<int>& cellStartBoundary, float dt, float rho0, float threshold, int minIter, int which)
 {
-    if (tailFailed || getenv("SPHX_DFSPH_NO_TAIL") != nullptr) return false;
+    if (tailFailed || tuning().dfsph_no_tail) return false;
     SweepCache& c = cache();
     const int num = (int)fluids->size();
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);

@@ -8,8 +8,18 @@
 #include "DArray.h"
 #include "SPHParticles.h"
 #include "sph_device.hpp"
+#include "sphx_c.h"
 
 namespace sphx {
+
+// the process-wide tuning block (include/sphx_c.h, sphx_set_tuning): the engine's behaviour switches.  The library reads no
+// environment variable for them; tests and tools install what they need through the C ABI.
+const sphx_tuning& tuning();
+sphx_tuning default_tuning();
+void install_tuning(const sphx_tuning& t);
+// which kernel the last launch_rate_kernel() chose (bench.py labels its roofline block with what actually ran)
+enum RateVariant { kRateNone = 0, kRateQuadStrict, kRateQuadTol, kRateQuadStrictInTol, kRateDuo, kRateLane, kRateLdsTiles, kRateBrick };
+extern int g_lastRateVariant;
 
 // Builds the constant block of the smoothing kernels on the host with the same fp32 expressions
 // the device would use, and finds tCut by bisection over float bit patterns: the three support
@@ -114,6 +124,7 @@ struct SweepCache {
     bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
     bool strictRateInTol = true;             // tolerance mode, >= 4 M particles: rate sweeps on the strict quad kernel (SweepCache::ctx)
     const int* gate = nullptr;               // device word that switches the following sweeps off (SweepCtx::gate)
+    const int* advectSkipIf = nullptr;       // device word that, when raised, keeps the advect pass from moving anything (DFSPH loop-tail fault)
     // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps
     // re-test every pair against the true support, `staleFlag` (device) is raised by the position update when a
     // particle has moved more than 0.45 * skin since the build (then every sweep walks the cells directly).

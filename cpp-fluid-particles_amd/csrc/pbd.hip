@@ -43,8 +43,7 @@ void PBDSolver::initializePosLast(const DArray<float3>& posFluid)
 void PBDSolver::configureSkin(float radius)
 {
     SweepCache& c = cache();
-    float factor = 0.05f;
-    if (const char* e = getenv("SPHX_PBD_SKIN")) factor = (float)atof(e);
+    const float factor = tuning().pbd_skin >= 0.0f ? tuning().pbd_skin : 0.05f;
     c.skinRows = !c.isSlab && factor > 0.0f && skinWanted;
     c.skin = c.skinRows ? factor * radius : 0.0f;
 }
@@ -53,7 +52,7 @@ void PBDSolver::tune(int stepsSinceLastCall)
 {
     BasicSPHSolver::tune(stepsSinceLastCall);
     SweepCache& c = cache();
-    if (c.isSlab || getenv("SPHX_PBD_SKIN_FIXED")) return;
+    if (c.isSlab || tuning().pbd_skin_fixed) return;
     tuneSteps += stepsSinceLastCall;
     if (tuneSteps < 32) return;
     if (skinWanted && c.skinRows) {

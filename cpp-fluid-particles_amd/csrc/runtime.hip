@@ -45,6 +45,25 @@ void report_hip_error(hipError_t e, const char* file, int line)
 const std::string& last_error_text() { return g_last_error_global; }
 void set_error_text(const std::string& s) { g_last_error_global = s; }
 
+// ------------------------------------------------------------------------------ tuning block
+sphx_tuning default_tuning()
+{
+    sphx_tuning t;
+    std::memset(&t, 0, sizeof(t));
+    t.struct_size = (int)sizeof(sphx_tuning);
+    t.quad_mask = t.duo_mask = t.quad_mask_tol = t.tol_strict_rate = -1;
+    t.range_order = -1;
+    t.dfsph_window = -1;
+    t.pbd_skin = -1.0f;
+    t.persist_controller = -1;
+    t.slab_edge_stream = -1;
+    return t;
+}
+static sphx_tuning g_tuning = default_tuning();
+const sphx_tuning& tuning() { return g_tuning; }
+void install_tuning(const sphx_tuning& t) { g_tuning = t; }
+int g_lastRateVariant = kRateNone;
+
 // ------------------------------------------------------------------------------ kernel constants
 namespace {
 float f_cube(float x) { return x * x * x; }
@@ -164,7 +183,7 @@ __global__ void k_check_div3(KernelConsts k, float denLo, float denHi, unsigned 
 // enables the fast paths of `k` that hold for its radius; runs a few ms of device work and one sync
 void validate_fast_math(KernelConsts& k)
 {
-    if (getenv("SPHX_NO_FASTMATH")) return;
+    if (tuning().no_fastmath) return;
     const float R = k.R;
     // denominators seen by div3_exact: PI*(q+EPS)*R^5 for q in [0, 2], and stK*x for x in [EPS, R]
     const float r5 = R * R * R * R * R;
@@ -395,7 +414,7 @@ void SweepCache::ensureTileOrder()
     const double layerBytes = (double)g.gy * g.gz * 7.0 * 32.0;
     // only worth its ~40 us when three x-layers clearly exceed an XCD's 4 MB L2 (measured: +5 % at
     // 10 M particles, -4 % at 1 M)
-    if (3.0 * layerBytes < 12.0 * 1024 * 1024 && !getenv("SPHX_FORCE_TILE_ORDER")) { orderValid = false; flags |= 0; return; }
+    if (3.0 * layerBytes < 12.0 * 1024 * 1024 && !tuning().force_tile_order) { orderValid = false; flags |= 0; return; }
     int chunks = (int)std::ceil(3.0 * layerBytes / (1.5 * 1024 * 1024));
     chunks = std::max(8, std::min(64, ((chunks + 7) / 8) * 8));
     const int chunkCells = std::max(1, (g.gy + chunks - 1) / chunks);
@@ -483,27 +502,28 @@ SweepCache::SweepCache(int num)
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
       rowOverflow(4u), staleFlag(3u), persistFlags(4u)
 {
+    const sphx_tuning& T = tuning();
     capAuto = true; cap = 48;
-    if (const char* e = getenv("SPHX_NBR_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 1024) { cap = (v + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; } }   // rows are stored in chunks of 4
-    if (const char* e = getenv("SPHX_ENGINE_FLAGS")) flags = atoi(e);
-    if (const char* e = getenv("SPHX_RANGE_ORDER")) rangeOrder = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_RANGE_ORDER_MIN")) rangeOrderMin = atoi(e);
-    if (const char* e = getenv("SPHX_QUAD_MASK")) quadMask = atoi(e);          // experiments: which sweeps run quad-per-particle
-    if (const char* e = getenv("SPHX_DUO_MASK")) { duoMask = atoi(e); duoMaskLarge = 0; }   // ... and which with two lanes per particle
-    if (const char* e = getenv("SPHX_QUAD_MASK_TOL")) quadMaskTol = atoi(e);   // ... quad walks under the tolerance arithmetic
-    if (const char* e = getenv("SPHX_BRICK")) brickWanted = atoi(e) != 0;      // compact-brick LDS stage under the tolerance arithmetic
+    if (T.row_capacity >= 8 && T.row_capacity <= 1024) { cap = (T.row_capacity + kRowChunk - 1) / kRowChunk * kRowChunk; capAuto = false; }   // rows are stored in chunks of 4
+    flags = T.engine_flags;
+    if (T.range_order >= 0) rangeOrder = T.range_order != 0;
+    if (T.range_order_min > 0) rangeOrderMin = T.range_order_min;
+    if (T.quad_mask >= 0) quadMask = T.quad_mask;                  // experiments: which sweeps run quad-per-particle
+    if (T.duo_mask >= 0) { duoMask = T.duo_mask; duoMaskLarge = 0; }   // ... and which with two lanes per particle
+    if (T.quad_mask_tol >= 0) quadMaskTol = T.quad_mask_tol;       // ... quad walks under the tolerance arithmetic
+    brickWanted = T.brick != 0;                                    // compact-brick LDS stage under the tolerance arithmetic
     if (brickWanted) {      //  the stage needs ~74 KB of dynamic LDS per block: parts with 64 KB (gfx942) cannot run it
         int dev = 0, ldsMax = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
             (size_t)ldsMax < (size_t)(kBrickSlots + 1) * 2 * sizeof(float4) + 4096) {
             (void)hipGetLastError();
-            fprintf(stderr, "sphx: SPHX_BRICK=1 ignored: this device offers %d bytes of LDS per block, the compact-brick stage needs %zu\n", ldsMax,
+            fprintf(stderr, "sphx: sphx_tuning.brick ignored: this device offers %d bytes of LDS per block, the compact-brick stage needs %zu\n", ldsMax,
                     (size_t)(kBrickSlots + 1) * 2 * sizeof(float4) + 4096);
             brickWanted = false; brickFailed = true;
         }
     }
-    if (const char* e = getenv("SPHX_BRICK_MIN")) brickMin = atoi(e);
-    if (const char* e = getenv("SPHX_TOL_STRICT_RATE")) strictRateInTol = atoi(e) != 0;      // A/B measurements
+    if (T.brick_min > 0) brickMin = T.brick_min;
+    if (T.tol_strict_rate >= 0) strictRateInTol = T.tol_strict_rate != 0;      // A/B measurements
 }
 
 void SweepCache::setup(int3 cellSize, float cellLength, float radius)

@@ -93,6 +93,9 @@ struct Transport {
     virtual void exchange(std::vector<Msg>& sends, std::vector<Msg>& recvs, bool async) = 0;
     virtual void wait() = 0;
     virtual long long allreduce_sum(long long localSum) = 0;   // blocking; every process calls it
+    // the same for a device word, ordered on the engine stream like an exchange and WITHOUT a host wait: *dOut = sum over the
+    // processes of *dIn once the engine stream gets there (the failure word of a step travels with its size messages)
+    virtual void allreduce_device(const long long* dIn, long long* dOut) = 0;
     // what the bench line reports: 0 loopback / 1 RCCL, ranks and own rank of the communicator as the LIBRARY reports them
     // (-1: the library has no ncclCommCount), payload bytes posted so far, exchanges (grouped send/recv rounds) and all-reduces
     virtual void describe(int& kind, int& ranks, int& rank) const { kind = 0; ranks = 1; rank = 0; }
@@ -124,6 +127,10 @@ struct LoopbackTransport final : Transport {
     }
     void wait() override {}
     long long allreduce_sum(long long v) override { return v; }
+    void allreduce_device(const long long* dIn, long long* dOut) override
+    {
+        hip_ok(hipMemcpyAsync(dOut, dIn, sizeof(long long), hipMemcpyDeviceToDevice, sphx::stream()), "loopback all-reduce");
+    }
 };
 
 // one process per GPU: grouped ncclSend / ncclRecv on a communication stream of its own.  A process may drive several
@@ -150,14 +157,12 @@ struct RcclTransport final : Transport {
         try {       // a constructor that throws runs no destructor: give back what exists before passing the error on
             // the transfers run beside the interior sweep of the same stage, which fills every CU: the communication stream gets
             // the highest priority so that RCCL's copy kernels are dispatched as soon as wave slots free up instead of behind
-            // the sweep's remaining workgroups (SPHX_COMM_PRIORITY=0 or default: a default-priority stream, =low: the least priority; for measurements)
+            // the sweep's remaining workgroups (sphx_tuning.slab_comm_priority: 1 a default-priority stream, 2 the least priority; for measurements)
             int least = 0, greatest = 0;
             hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
-            const char* pr = std::getenv("SPHX_COMM_PRIORITY");
-            const bool plain = pr && (std::strcmp(pr, "0") == 0 || std::strcmp(pr, "default") == 0);   // a flags-created stream: default priority
-            const bool low = pr && std::strcmp(pr, "low") == 0;                                       // the least priority the device has
-            if (plain) hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
-            else hip_ok(hipStreamCreateWithPriority(&commStream, hipStreamNonBlocking, low ? least : greatest), "comm stream");
+            const int pr = sphx::tuning().slab_comm_priority;      // 0 highest (default), 1 a flags-created stream: default priority, 2 the least the device has
+            if (pr == 1) hip_ok(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking), "comm stream");
+            else hip_ok(hipStreamCreateWithPriority(&commStream, hipStreamNonBlocking, pr == 2 ? least : greatest), "comm stream");
             hip_ok(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event");
             hip_ok(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event");
             hip_ok(hipMalloc((void**)&dScalar, 2 * sizeof(long long)), "scalar buffer");
@@ -232,6 +237,17 @@ struct RcclTransport final : Transport {
         hip_ok(hipStreamSynchronize(commStream), "comm sync");
         return hScalar[1];
     }
+    void allreduce_device(const long long* dIn, long long* dOut) override
+    {
+        ++allreduces;
+        wait();
+        hip_ok(hipEventRecord(ready, sphx::stream()), "event record");
+        hip_ok(hipStreamWaitEvent(commStream, ready, 0), "stream wait");
+        nccl_ok(g_rccl.AllReduce(dIn, dOut, 1, ncclInt64, ncclSum, comm, commStream), "ncclAllReduce");
+        hip_ok(hipEventRecord(done, commStream), "event record");
+        pending = true; pendingAsync = false;
+        wait();                                   // the engine stream continues behind the reduction; the host does not wait here
+    }
 };
 
 // ================================================================================ device helpers
@@ -262,6 +278,19 @@ __global__ void k_slab_prepare(long long* __restrict__ counts, int* __restrict__
     const int t = threadIdx.x;
     if (t < 13) counts[t] = (t == 1 || t == 4) ? owned : ((t == 2 || t == 5) ? width : 0);
     if (t == 13) *violation = 0;
+}
+
+// the failure word of a slab for this step, formed on the device once the neighbours' size messages have arrived: crossed = 1,
+// capacity = 1 << 20 (the encoding the host reports from); added to the process's word, which is all-reduced on the stream
+__global__ void k_slab_verdict(const long long* __restrict__ counts, const int* __restrict__ violation, long long capacity, int hasLeft,
+                               int hasRight, long long inject, unsigned long long* __restrict__ processBad)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long bad = inject;
+    if (*violation != 0) bad += 1;
+    const long long rl = hasLeft ? counts[6] : 0, rr = hasRight ? counts[9] : 0;
+    if (counts[12] + rl + rr > capacity) bad += 1LL << 20;
+    if (bad) atomicAdd(processBad, (unsigned long long)bad);
 }
 
 // payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives the owned particles still in
@@ -385,28 +414,29 @@ struct sphx_slab_group {
     double waitSeconds = 0.0;
     std::vector<Msg> sends, recvs;
     bool failed = false;        // a step threw: posted messages were dropped, slabs may be half-updated -> only destroy is allowed
-    hipStream_t edgeStream = nullptr;                     // DFSPH / WCSPH edge layers + their halo, beside the interior (SPHX_SLAB_EDGE_STREAM=0: off)
+    DevBuf<long long> dBad;                               // [0] failure word of this process's slabs in the current step, [1] summed over all processes
+    long long* hBad = nullptr;                            // pinned copy of both
+    hipStream_t edgeStream = nullptr;                     // DFSPH / WCSPH edge layers + their halo, beside the interior (sphx_tuning.slab_edge_stream = 0: off)
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
 
     ~sphx_slab_group()
     {
         if (edgeStream) { (void)hipStreamSynchronize(edgeStream); (void)hipStreamDestroy(edgeStream); }
+        if (hBad) (void)hipHostFree(hBad);
         if (forkEvent) (void)hipEventDestroy(forkEvent);
         if (joinEvent) (void)hipEventDestroy(joinEvent);
     }
     void createEdgeStream()
     {
-        const char* e = std::getenv("SPHX_SLAB_EDGE_STREAM");
-        if (e && std::strcmp(e, "0") == 0) return;
+        if (sphx::tuning().slab_edge_stream == 0) return;
         int least = 0, greatest = 0;
         hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
         // A DEFAULT-priority stream (r04).  Until r04 this was the highest priority the device has; with 8 processes sharing the one
         // test GPU (tests/test_gpu_slab.py, 8 ranks, transfers completing late) a rank then now and then computed different bits or died
         // of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in its first step -- 4 of 30 runs, in the r03 sources as well; 0 of 24 with this
         // stream at default priority, 0 of 12 without it (profiles/r04_slab_edge_stream_priority.txt).  The edge kernels are enqueued
-        // before the interior of their stage, so they start first anyway.  SPHX_EDGE_PRIORITY=high restores the old stream.
-        const char* pr = std::getenv("SPHX_EDGE_PRIORITY");
-        if (pr && std::strcmp(pr, "high") == 0) hip_ok(hipStreamCreateWithPriority(&edgeStream, hipStreamNonBlocking, greatest), "edge stream");
+        // before the interior of their stage, so they start first anyway.  sphx_tuning.slab_edge_priority = 1 restores the old stream.
+        if (sphx::tuning().slab_edge_priority == 1) hip_ok(hipStreamCreateWithPriority(&edgeStream, hipStreamNonBlocking, greatest), "edge stream");
         else hip_ok(hipStreamCreateWithFlags(&edgeStream, hipStreamNonBlocking), "edge stream");
         hip_ok(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "event");
         hip_ok(hipEventCreateWithFlags(&joinEvent, hipEventDisableTiming), "event");
@@ -483,32 +513,35 @@ struct sphx_slab_group {
         SLAB_TRACE("size exchange: posting", sends.size());
         transport->exchange(sends, recvs, false);
         SLAB_TRACE("size exchange: posted", 0);
+        // Rank-local failures are only known now (the violation flag, and the capacity check needs the neighbours' sizes), but the
+        // neighbours are about to post receives for THIS rank's payload: a rank that simply returned an error here would leave them
+        // waiting in ncclRecv.  So every process contributes its failure word to one all-reduce and all of them leave the step
+        // together.  r05: the word is formed on the device behind the size messages and reduced ON THE STREAM, and it
+        // comes back with the sizes: one host wait per step instead of two.
+        hip_ok(hipMemsetAsync(dBad.p, 0, 2 * sizeof(long long), st), "memset");
+        for (auto& sp : slabs) {
+            Slab& s = *sp;
+            long long inject = 0;
+#ifdef SPHX_TEST_HOOKS
+            if (const char* f = std::getenv("SPHX_SLAB_FAULT")) {      // fault injection, test build only: "capacity:<rank>:<step>"
+                int r = -1, at = -1;
+                if (std::sscanf(f, "capacity:%d:%d", &r, &at) == 2 && s.rank == r && s.stepsDone == at) inject = 1LL << 20;
+            }
+#endif
+            k_slab_verdict<<<1, 64, 0, st>>>(s.counts.p, s.violation.p, (long long)s.capacity, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, inject,
+                                             reinterpret_cast<unsigned long long*>(dBad.p));
+        }
+        if (world > (int)slabs.size()) transport->allreduce_device(dBad.p, dBad.p + 1);
+        else hip_ok(hipMemcpyAsync(dBad.p + 1, dBad.p, sizeof(long long), hipMemcpyDeviceToDevice, st), "failure word");
         for (auto& sp : slabs) {
             Slab& s = *sp;
             hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 13 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
             hip_ok(hipMemcpyAsync(s.hInts + 6, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
         }
+        hip_ok(hipMemcpyAsync(hBad, dBad.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st), "failure word");
         sync("particle exchange (sizes)");
         SLAB_TRACE("size exchange: synchronised", 0);
-        // Rank-local failures are only known now (the violation flag, and the capacity check needs the neighbours' sizes),
-        // but the neighbours are about to post receives for THIS rank's payload: a rank that simply returned an error here
-        // would leave them waiting in ncclRecv.  So every rank contributes its failure code to one all-reduce and all of
-        // them leave the step together.  Encoding: crossed = 1, capacity = 1 << 20 per failing slab.
-        long long bad = 0;
-        for (auto& sp : slabs) {
-            Slab& s = *sp;
-            const long long rl = s.hasLeft ? s.hCounts[6] : 0, rr = s.hasRight ? s.hCounts[9] : 0;
-            if (s.hInts[6]) bad += 1;
-            if (s.hCounts[12] + rl + rr > s.capacity) bad += 1LL << 20;
-        }
-#ifdef SPHX_TEST_HOOKS
-        if (const char* f = std::getenv("SPHX_SLAB_FAULT")) {      // fault injection, test build only: "capacity:<rank>:<step>"
-            int r = -1, st = -1;
-            if (std::sscanf(f, "capacity:%d:%d", &r, &st) == 2)
-                for (auto& sp : slabs) if (sp->rank == r && sp->stepsDone == st) bad += 1LL << 20;
-        }
-#endif
-        const long long anyBad = world > (int)slabs.size() ? transport->allreduce_sum(bad) : bad;
+        const long long bad = hBad[0], anyBad = hBad[1];
         SLAB_TRACE("failure word reduced", anyBad);
         if (anyBad) {
             const char* here = bad ? "this process" : "another rank";
@@ -669,9 +702,16 @@ struct sphx_slab_group {
         updateLayers();
         sweepStage(SPHX_PH_HEAD, {SPHX_F_KAPPA, SPHX_F_POSF});
         int itDiv = 0, itDen = 0;
+        // fixed counts with at least one divergence correction: the gravity kick rides in the LAST correction's store (edges and interior
+        // each kick their own particles; ghost velocities arrive kicked with that stage's halo), as in the whole-domain step
+        const bool kickFused = !adaptive && v >= 1 && !sphx::tuning().no_kick_fusion && (overlap() || !(flags & SPHX_SLAB_SWEEP_GHOSTS));
         if (!adaptive) {
+            const float3 G = make_float3(global.gravity[0], global.gravity[1], global.gravity[2]);
             for (; itDiv < v; ++itDiv) {
+                const bool last = kickFused && itDiv + 1 == v;
+                if (last) for (auto& sp : slabs) sp->sys->dfsph->setKickInCorrect(true, global.dt, G);
                 sweepStage(SPHX_PH_DIV_CORRECT, {SPHX_F_VEL4});
+                if (last) for (auto& sp : slabs) sp->sys->dfsph->setKickInCorrect(false);
                 // (fixed counts: the error sweep behind the LAST correction -- and its halo -- has no reader, DFSPHSolver::step)
                 if (itDiv + 1 < v) sweepStage(SPHX_PH_DIV_ERROR, {SPHX_F_KAPPA, SPHX_F_POSF});
             }
@@ -685,7 +725,7 @@ struct sphx_slab_group {
                 ++itDiv;
             }
         }
-        runAll(SPHX_PH_FORCE);
+        if (!kickFused) runAll(SPHX_PH_FORCE);
         sweepStage(SPHX_PH_VISC_COLOR, surface ? std::vector<int>{SPHX_F_CG4} : std::vector<int>{});
         if (surface) {
             sweepStage(SPHX_PH_SURFACE_WARM, {SPHX_F_VEL4});      // one row walk for both, one halo instead of two
@@ -928,6 +968,8 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
     if (!params || !out || n_fluid < 0 || n_boundary < 0 || (n_fluid && !fluid_xyz) || (n_boundary && !boundary_xyz) || world < 1 ||
         first_rank < 0 || local_ranks < 1 || first_rank + local_ranks > world)
         return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: bad argument");
+    if (params->reserved[3] < 0 || params->reserved[3] > 2)
+        return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: reserved[3] (arithmetic) must be 0 (strict), 1 (tolerance) or 2 (tolerance with persistent rows)");
     if (!rccl_id128 && (first_rank != 0 || local_ranks != world))
         return slab_fail(SPHX_ERR_INVALID, "sphx_slab_create: without an RCCL token all slabs must be local (loopback)");
     if (rccl_id128 && (world % local_ranks != 0 || first_rank % local_ranks != 0))
@@ -944,7 +986,11 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
         // transport first: it binds this process to its device-side communicator
         if (rccl_id128) G->transport.reset(new RcclTransport(first_rank / local_ranks, world / local_ranks, rccl_id128, local_ranks));
         else G->transport.reset(new LoopbackTransport());
-        if (P.solver == SPHX_DFSPH && G->overlap()) G->createEdgeStream();
+        // (r05: WCSPH too -- sweepStage has taken this path for it since r04, but the stream was only ever created for DFSPH)
+        if (P.solver != SPHX_PBD && G->overlap()) G->createEdgeStream();
+        G->dBad.alloc(2);
+        hip_ok(hipHostMalloc((void**)&G->hBad, 2 * sizeof(long long), hipHostMallocDefault), "pinned failure word");
+        G->hBad[0] = G->hBad[1] = 0;
 
         const SlabPlan plan = plan_slabs(P, fluid_xyz, n_fluid, world);
         const std::vector<int>& cuts = plan.cuts;
@@ -963,6 +1009,10 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             // particles it is handed are local.  Cut planes are then just two numbers of this driver and may move.
             sphx_params Pl = P;
             Pl.reserved[1] = 0; Pl.reserved[2] = 1;          // a slab system: no initial fluid sort, stage-wise stepping
+            // arithmetic contract of the slabs' sweeps: strict (0) or tolerance (1) as asked.  The rows of a slab are slices of the
+            // single-device rows, so a tolerance run equals the single-device tolerance engine bit for bit as long as both pick the
+            // same kernel variants (they depend on the particle count per device from 4 M particles on: SweepCache::ctx)
+            Pl.reserved[3] = P.reserved[3] >= 1 ? 1 : 0;
             {
                 std::vector<float> zeros((size_t)3 * s.capacity, 0.0f);
                 const int rc = sphx_create_impl(&Pl, zeros.data(), s.capacity, boundary_xyz, n_boundary, 0, &s.sys);

@@ -755,20 +755,22 @@ inline void launch_rate_kernel(const OpRate& o, int n)
         const size_t lds = brick_lds_bytes<OpRate::Field>();
         brick_launch_prepare(k_rate_brick<DENSITY_MODE, WARM>, lds);
         k_rate_brick<DENSITY_MODE, WARM><<<brick_grid(o.c), kBrickThreads, lds, stream()>>>(o, n);
+        g_lastRateVariant = kRateBrick;
         return;
     }
-    if (o.c.nbr && o.c.tileFmt) k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    if (o.c.nbr && o.c.tileFmt) { k_rate<DENSITY_MODE, WARM, true><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n); g_lastRateVariant = kRateLdsTiles; }
     else if (o.c.nbr && (o.c.quad & kQuadRate)) {
         if (o.c.k.tol && o.c.plainBits && !o.c.brick) {      // tolerance mode at size: the strict kernel is the faster one (SweepCache::ctx)
             OpRate s = o;
             s.c.k.tol = 0;
             k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(s.c), kWideBlock, 0, stream()>>>(s, n);
+            g_lastRateVariant = kRateQuadStrictInTol;
         }
-        else if (o.c.k.tol) k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-        else k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+        else if (o.c.k.tol) { k_rate_quad<DENSITY_MODE, WARM, 1><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n); g_lastRateVariant = kRateQuadTol; }
+        else { k_rate_quad<DENSITY_MODE, WARM, 0><<<quad_grid(o.c), kWideBlock, 0, stream()>>>(o, n); g_lastRateVariant = kRateQuadStrict; }
     }
-    else if (o.c.nbr && (o.c.duo & kQuadRate)) k_rate_duo<DENSITY_MODE, WARM><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
-    else k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n);
+    else if (o.c.nbr && (o.c.duo & kQuadRate)) { k_rate_duo<DENSITY_MODE, WARM><<<duo_grid(o.c), kWideBlock, 0, stream()>>>(o, n); g_lastRateVariant = kRateDuo; }
+    else { k_rate<DENSITY_MODE, WARM, false><<<sweep_grid(o.c), kWideBlock, 0, stream()>>>(o, n); g_lastRateVariant = kRateLane; }
 }
 
 // correctDivergenceError_CUDA (DFSPHSolver.cu:308-329) / correctDensityError_CUDA (:138-158)
@@ -926,19 +928,34 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
 template <bool DENSITY_MODE, int WARM, int CM, int TOLC, int TOLR>
 inline bool launch_tail_kernel(const OpCorrect<DENSITY_MODE>& corr, const OpRate& rate, const LoopTail& t)
 {
-    static thread_local int perCU = -1, cus = 0;               // blocks of THIS kernel a compute unit holds at once
-    if (perCU < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        HIP_CALL(hipGetDevice(&dev)); HIP_CALL(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-        HIP_CALL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR>, kWideBlock, 0));
+    // blocks of THIS kernel a compute unit of THIS device holds at once (queried once per device and instantiation; the host side of
+    // the engine is single-threaded per process)
+    constexpr int kMaxDevices = 64;
+    static int perCUof[kMaxDevices], cusOf[kMaxDevices];
+    static bool known[kMaxDevices];
+    int dev = 0;
+    HIP_CALL(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return false;
+    if (!known[dev]) {
+        hipDeviceProp_t prop;
+        int blocks = 0;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR>, kWideBlock, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            blocks = 0; prop.multiProcessorCount = 0;
+        }
+        perCUof[dev] = blocks; cusOf[dev] = prop.multiProcessorCount; known[dev] = true;
     }
+    const int perCU = perCUof[dev], cus = cusOf[dev];
     if (perCU < 1 || cus < 1) return false;
     int grid = std::min(corr.c.numTiles, perCU * cus);         // (the rate sweep takes one tile per block; a lane-walk correction four)
 #ifdef SPHX_TEST_HOOKS
     if (getenv("SPHX_DFSPH_TAIL_OVERSUBSCRIBE")) grid = std::max(corr.c.numTiles, 16 * perCU * cus);      // more blocks than fit: the barrier must time out and report
 #endif
     k_dfsph_loop_tail<DENSITY_MODE, WARM, CM, TOLC, TOLR><<<grid, kWideBlock, 0, stream()>>>(corr, rate, t);
+    // a launch that was refused (not one that failed later) leaves the loop to the caller's gated launches; inside a stream capture
+    // the error, if any, surfaces when the capture ends and the step then runs eagerly (SPHSystem::stepN)
+    if (hipGetLastError() != hipSuccess) return false;
     return true;
 }
 // false: this configuration has no tail kernel (the caller enqueues gated launches instead)
@@ -1145,8 +1162,11 @@ static __global__ void k_pack_kick(float4* __restrict__ posm, const float3* __re
     vel[i] = add3(vel[i], dv);
 }
 // Particles::advect + enforceBoundary_CUDA(pos, vel): Particles.cu:28-36, BasicSPHSolver.cu:85-101
-static __global__ void k_advect_clamp(float3* __restrict__ pos, float3* __restrict__ vel, float dt, float3 space, int n)
+// skipIf: a device word that, when raised, keeps the positions where they are (DFSPH's loop tail reported a fault in this step:
+// velocities that are only partly corrected must not move anything; the host reports the step as invalid)
+static __global__ void k_advect_clamp(float3* __restrict__ pos, float3* __restrict__ vel, float dt, float3 space, int n, const int* __restrict__ skipIf)
 {
+    if (skipIf && *skipIf != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float3 v = vel[i];
@@ -1220,9 +1240,9 @@ inline void launch_pack_kick(float4* posm, const float3* pos, const float* mass,
 {
     if (n > 0) k_pack_kick<<<blocks_for(n), 256, 0, stream()>>>(posm, pos, mass, vel, dv, n);
 }
-inline void launch_advect_clamp(float3* pos, float3* vel, float dt, float3 space, int n)
+inline void launch_advect_clamp(float3* pos, float3* vel, float dt, float3 space, int n, const int* skipIf = nullptr)
 {
-    if (n > 0) k_advect_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, dt, space, n);
+    if (n > 0) k_advect_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, dt, space, n, skipIf);
 }
 inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLast, float3 dv, float dt, float3 space, int n)
 {

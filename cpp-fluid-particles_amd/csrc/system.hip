@@ -87,6 +87,9 @@ struct PersistState {
     DArray<float> tmpMass;
     bool wanted = false;
     bool primed = false;      // the working copy mirrors the API arrays through P
+    // controller (SPHSystem::persistentController): rebuild and step counters at the last look, steps since, suspension
+    int seenBuilds = 0, seenSteps = 0, sinceLook = 0;
+    bool suspended = false; int suspendedSteps = 0;
 };
 
 struct StepGraph {
@@ -705,18 +708,51 @@ bool SPHSystem::setPersistentRows(bool on)
     if (_persist->wanted == on) return true;
     invalidatePersistentOrder();
     _persist->wanted = on;
+    _persist->suspended = false; _persist->sinceLook = 0;
     basic->requestPersistentRows(on);
     _graph->drop();
-    return true;
+    return on ? persistentActive() : true;
 }
 
 bool SPHSystem::persistentRows() const { return _persist && _persist->wanted; }
+const int* SPHSystem::persistentSlotMap() const { return (_persist && _persist->primed) ? _persist->slotToWork.addr() : nullptr; }
 
 bool SPHSystem::persistentActive()
 {
-    if (!_persist || !_persist->wanted) return false;
+    if (!_persist || !_persist->wanted || _persist->suspended) return false;
     auto* basic = static_cast<BasicSPHSolver*>(_solver.get());
     return basic->preparePersistent(_sc.cells, _sc.cellLength, _sc.radius).active;
+}
+
+// Rows that are rebuilt in (nearly) every step cost more than plain per-step rows: the skin re-test of every pair, ~3 % longer
+// rows, the slot-map grid pass and the export.  Every 64+ steps the host looks at the device-side counters {row builds, steps}
+// (one 16-byte read between steps, never inside a captured graph): at >= 90 % rebuilding steps the mode is left for 256 steps --
+// the solver's arrays go back to the API order, the ordinary tolerance step runs -- and tried again afterwards.
+void SPHSystem::persistentController(int stepsSinceLastCall)
+{
+    if (!_persist || !_persist->wanted || tuning().persist_controller == 0) return;
+    PersistState& ps = *_persist;
+    auto* basic = static_cast<BasicSPHSolver*>(_solver.get());
+    if (ps.suspended) {
+        ps.suspendedSteps += stepsSinceLastCall;
+        if (ps.suspendedSteps >= 256) { ps.suspended = false; ps.sinceLook = 0; basic->requestPersistentRows(true); _graph->drop(); }
+        return;
+    }
+    ps.sinceLook += stepsSinceLastCall;
+    if (ps.sinceLook < 64 || !ps.primed) return;
+    const int* flags = basic->enginePersistFlags();
+    if (!flags) return;
+    int words[4] = {0, 0, 0, 0};
+    HIP_CALL(hipMemcpyAsync(words, flags, sizeof(words), hipMemcpyDeviceToHost, sphx::stream()));
+    HIP_CALL(hipStreamSynchronize(sphx::stream()));
+    const int builds = words[2] - ps.seenBuilds, steps = words[3] - ps.seenSteps;
+    ps.seenBuilds = words[2]; ps.seenSteps = words[3]; ps.sinceLook = 0;
+    if (steps >= 32 && 10 * builds >= 9 * steps) {
+        invalidatePersistentOrder();
+        basic->requestPersistentRows(false);
+        ps.suspended = true; ps.suspendedSteps = 0;
+        _graph->drop();
+    }
 }
 
 void SPHSystem::invalidatePersistentOrder()
@@ -864,6 +900,7 @@ float SPHSystem::step()
     HIP_CALL(hipEventDestroy(stop));
     _graph->stepsRun++;
     _solver->tune(1);
+    persistentController(1);
     return milliseconds;
 }
 
@@ -877,9 +914,9 @@ float SPHSystem::stepN(int n)
     // buckets) appear during the first step that runs the solver's full schedule, so that one is eager
     // ... and so is the step that primes the working copy of the persistent mode (host-side copies outside the captured schedule)
     while (n > 0 && (_graph->stepsRun == 0 || (_solver->graphSafe() && _graph->warmSteps == 0) ||
-                     (_persist && _persist->wanted && !_persist->primed))) { extra += step(); --n; }
+                     (_persist && !_persist->primed && persistentActive()))) { extra += step(); --n; }
     if (n == 0) return extra;
-    const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !getenv("SPHX_NO_GRAPH");
+    const bool wantGraph = _solver->graphSafe() && !KernelTimer::enabled && !tuning().no_graph;
     auto ensureGraph = [&] {
         // launch sizes are baked into a capture: a changed active count (sphx_set_count) needs a new one
         // ... and so do host-side invalidations (boundary masses rewritten, arrays regrown, engine switches)
@@ -890,7 +927,7 @@ float SPHSystem::stepN(int n)
         _graph->capturedCount = _fluids->size();
         _graph->capturedGeneration = _solver->graphGeneration();
         _solver->prepareForCapture();
-        const bool say = getenv("SPHX_GRAPH_DEBUG") != nullptr;       // which stage of a capture failed (the step then runs eagerly)
+        const bool say = tuning().graph_debug != 0;       // which stage of a capture failed (the step then runs eagerly)
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             try { enqueueStep(); } catch (const char* msg) { ok = false; if (say) std::cout << "sphx: capture: enqueue threw: " << msg << "\n"; }
@@ -930,7 +967,7 @@ float SPHSystem::stepN(int n)
         }
         done += chunk;
         _graph->stepsRun += chunk;
-        if (done < n) _solver->tune(chunk);
+        if (done < n) { _solver->tune(chunk); persistentController(chunk); }
     }
     HIP_CALL(hipEventRecord(stop, st));
     HIP_CALL(hipEventSynchronize(stop));
@@ -940,5 +977,6 @@ float SPHSystem::stepN(int n)
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
     _solver->tune(n % kChunk == 0 ? kChunk : n % kChunk);
+    persistentController(n % kChunk == 0 ? kChunk : n % kChunk);
     return milliseconds + extra;
 }

@@ -93,7 +93,7 @@ void BasicSPHSolver::advect(std::shared_ptr<SPHParticles>& fluids, float dt, flo
 {
     const int n = (int)fluids->size();
     ScopedKernel t("advect_clamp");
-    launch_advect_clamp(fluids->getPosPtr(), fluids->getVelPtr(), dt, spaceSize, n);
+    launch_advect_clamp(fluids->getPosPtr(), fluids->getVelPtr(), dt, spaceSize, n, cache().advectSkipIf);
     invalidatePositions();
 }
 

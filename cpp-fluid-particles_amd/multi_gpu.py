@@ -32,14 +32,19 @@ def run_slab_bench(args, rank, world, local_rank):
     # all slabs of a device is the setting every one-device measurement since r03 ran in with the highest priority, bit-exact throughout:
     # it asks for it (worth 10 % with 8 slabs over the installed RCCL).  One rank per GPU keeps the default until a node has shown the
     # high-priority queue to be safe there: with one slab per device the edge kernels are enqueued first and start first anyway.
-    if world == 1:
-        os.environ.setdefault("SPHX_EDGE_PRIORITY", "high")
+    if world == 1 and not getattr(args, "tuning", ""):
+        sphx.set_tuning(slab_edge_priority=1)
     P, fluid, boundary = sphx.scene(args.nx)
     solver_name = getattr(args, "solver", "dfsph")
     P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver_name]
     P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, getattr(args, "pbd_iters", 4)
     if P.solver == sphx.WCSPH:
         P.dt = 0.001
+    # arithmetic contract of the slabs: the headline's (bench.py --arith).  The slab layer runs strict and tolerance arithmetic; rows that
+    # persist across steps are a whole-domain mode, so "persistent" runs as tolerance here and the line says so.
+    arith_asked = getattr(args, "arith", "strict")
+    arith_ran = "tolerance" if arith_asked == "persistent" else arith_asked
+    P.reserved[3] = {"strict": 0, "tolerance": 1}[arith_ran]
     flags = sphx.SLAB_NO_OVERLAP if getattr(args, "no_overlap", False) else 0
     if world > 1:
         _bootstrap(rank, world)
@@ -133,12 +138,32 @@ def run_slab_bench(args, rank, world, local_rank):
         per_rank = gathered
     ms = [r["ms_per_step"] for r in per_rank]
     owned_all = [sum(sl["owned"] for sl in r["slabs"]) for r in per_rank]
+    # The base of this line's scaling figure, measured in the SAME run: the whole workload as ONE slab of the same layer in the same
+    # arithmetic on rank 0's device (the plain single-device engine -- bench.py --gpus 1 -- is another code path: one captured graph,
+    # rows that persist; it is not the base of a slab curve).  Skipped with --no-extra-legs.
+    scaling_base = None
+    if (world > 1 or slabs_here > 1) and not getattr(args, "no_extra_legs", False):
+        if rank == 0:
+            one = sphx.SlabGroup(P, fluid, boundary, 1, flags=flags)
+            one.step(1 + max(args.warmup, 1))
+            torch.cuda.synchronize()
+            k = max(1, min(args.steps, 20))
+            tb = time.perf_counter(); one.step(k); torch.cuda.synchronize()
+            base_ms = (time.perf_counter() - tb) * 1e3 / k
+            one.close()
+            scaling_base = {"what": "the same workload as ONE slab of the slab layer (loopback) on rank 0's device, %s arithmetic" % arith_ran,
+                            "ms_per_step": base_ms, "steps_per_s": 1e3 / base_ms, "steps": k,
+                            "speedup_of_this_line": base_ms / (wall * 1e3 / args.steps)}
+        if world > 1:
+            dist.barrier()
     result = {
         "metric": "simulation steps/sec, %s dam-break" % ("DFSPH" if P.solver == sphx.DFSPH else solver_name), "value": steps_per_s,
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, strict (bit-exact IEEE) arithmetic"
-                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt),
+        "config": {"workload": "dam-break %dx%dx%d = %d fluid + %d boundary particles, %s, dt=%g, %s arithmetic"
+                               % (args.nx, 3 * args.nx // 2, args.nx, n_total, len(boundary), what, P.dt,
+                                  "strict (bit-exact IEEE)" if arith_ran == "strict" else "tolerance (1e-5 contract; rows rebuilt every step)"),
+                   "arithmetic": arith_ran, "arithmetic_asked": arith_asked,
                    "particles": n_total,
                    "decomposition": "%d x-slabs; transport %s; %s" % (world if world > 1 else slabs_here, transport,
                                     "stage-then-exchange" if flags else "edge-first stages, halo overlapped with interior sweeps"),
@@ -153,6 +178,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "rank_ms_per_step": {"min": min(ms), "max": max(ms)},
         "owned_particles": {"min": min(owned_all), "max": max(owned_all), "total": sum(owned_all)},
         "roofline": per_rank[0]["roofline"],
+        "scaling_base": scaling_base,
     }
     group.close()
     if world > 1:

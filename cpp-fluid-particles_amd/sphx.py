@@ -33,6 +33,7 @@ EXPORTS = [
     "sphx_set", "sphx_device_ptr", "sphx_profile_step", "sphx_eval_kernels", "sphx_ieee_probe",
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
+    "sphx_tuning_defaults", "sphx_set_tuning", "sphx_get_tuning", "sphx_invalidate_order", "sphx_last_rate_kernel",
     "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
@@ -57,6 +58,18 @@ class Params(C.Structure):
         q = Params()
         C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
         return q
+
+
+class Tuning(C.Structure):
+    """sphx_tuning (include/sphx_c.h): the engine's behaviour switches, installed process-wide with set_tuning()."""
+    _fields_ = [
+        ("struct_size", C.c_int), ("engine_flags", C.c_int), ("row_capacity", C.c_int), ("quad_mask", C.c_int), ("duo_mask", C.c_int),
+        ("quad_mask_tol", C.c_int), ("tol_strict_rate", C.c_int), ("brick", C.c_int), ("brick_min", C.c_int), ("range_order", C.c_int),
+        ("range_order_min", C.c_int), ("force_tile_order", C.c_int), ("no_fastmath", C.c_int), ("no_graph", C.c_int), ("graph_debug", C.c_int),
+        ("dfsph_host_loop", C.c_int), ("dfsph_window", C.c_int), ("dfsph_no_tail", C.c_int), ("no_kick_fusion", C.c_int),
+        ("pbd_skin", C.c_float), ("pbd_skin_fixed", C.c_int), ("persist_controller", C.c_int), ("slab_edge_stream", C.c_int),
+        ("slab_edge_priority", C.c_int), ("slab_comm_priority", C.c_int), ("reserved", C.c_int * 7),
+    ]
 
 
 class SphxError(RuntimeError):
@@ -112,6 +125,11 @@ def lib():
         L.sphx_row_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.sphx_kernel_timer.argtypes = [C.c_int, C.c_char_p]
         L.sphx_kernel_timer_collect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.sphx_tuning_defaults.argtypes = [C.POINTER(Tuning)]
+        L.sphx_set_tuning.argtypes = [C.POINTER(Tuning)]
+        L.sphx_get_tuning.argtypes = [C.POINTER(Tuning)]
+        L.sphx_invalidate_order.argtypes = [C.c_void_p]
+        L.sphx_last_rate_kernel.argtypes = [C.c_char_p, C.c_int]
         if L.sphx_sizeof_params() != C.sizeof(Params):
             raise SphxError("sphx_params layout mismatch between sphx.py and libsphx.so")
         _lib = L
@@ -125,6 +143,41 @@ def _check(rc):
 
 def device_count():
     return lib().sphx_device_count()
+
+
+def default_tuning():
+    t = Tuning()
+    _check(lib().sphx_tuning_defaults(C.byref(t)))
+    return t
+
+
+def set_tuning(tuning=None, **fields):
+    """install a tuning block process-wide (systems and slab groups created afterwards use it; the `live` fields act at once).
+    set_tuning() restores the defaults; set_tuning(row_capacity=12, dfsph_no_tail=1) = the defaults with these fields changed."""
+    if tuning is None and not fields:
+        _check(lib().sphx_set_tuning(None))
+        return
+    t = tuning if tuning is not None else default_tuning()
+    for k, v in fields.items():
+        if not hasattr(t, k):
+            raise SphxError("sphx_tuning has no field %r" % k)
+        setattr(t, k, v)
+    _check(lib().sphx_set_tuning(C.byref(t)))
+
+
+def get_tuning():
+    t = Tuning()
+    _check(lib().sphx_get_tuning(C.byref(t)))
+    return t
+
+
+def last_rate_kernel():
+    """(variant number, name) of the kernel the most recent DFSPH error sweep was launched as"""
+    buf = C.create_string_buffer(128)
+    v = lib().sphx_last_rate_kernel(buf, 128)
+    if v < 0:
+        _check(v)
+    return v, buf.value.decode()
 
 
 def set_device(ordinal):
@@ -218,6 +271,10 @@ class System:
         lib().sphx_persistent_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _check(lib().sphx_persistent_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return bool(a.value), b.value, c.value
+
+    def invalidate_order(self):
+        """after writing API arrays through raw device pointers of a persistent-rows system"""
+        _check(lib().sphx_invalidate_order(self._h))
 
     def device_ptr(self, field):
         p = C.c_void_p()

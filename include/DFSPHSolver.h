@@ -47,6 +47,14 @@ public:
     long long readErrorTotalFixed();
     void resetErrorTotal();          // zero the |error| accumulators on the current stream (split error stages then all ADD)
     void noteIterations(int div, int den) { lastDiv = div; lastDen = den; itersPending = false; }
+    // stage-wise drivers with fixed counts: the DIV_CORRECT stages run while this is on also apply the gravity kick
+    // vel += dt G (BasicSPHSolver::force, BasicSPHSolver.cu:227-235) in their store, as DFSPHSolver::step does for the last
+    // divergence correction of a whole-domain step; the driver then leaves the FORCE stage out
+    void setKickInCorrect(bool on, float dt = 0.0f, float3 G = {0.0f, 0.0f, 0.0f})
+    {
+        kickInCorrect = on;
+        if (on) kickDv = make_float3(dt * G.x, dt * G.y, dt * G.z);
+    }
     const DArray<float>& getAlpha() const { return alpha; }
     const DArray<float>& getStiffness() const { return bufferFloat; }
     const DArray<float>& getError() const { return error; }

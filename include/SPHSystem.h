@@ -83,9 +83,16 @@ public:
     // order (stable sort by the cells of the step's starting positions) at the end of every step() as always.  Results meet the
     // tolerance contract, not the strict one (the order of a particle's sums follows the rows).  A caller that WRITES the fluid
     // arrays through raw pointers between steps must call invalidatePersistentOrder() afterwards; the C ABI's setters do.
-    // Returns false when the mode cannot be used (solver without the engine's rows, PBD, slab systems, cellLength <= radius).
+    // Returns false when the mode cannot be used as the system stands (solver without the engine's rows, PBD, slab systems,
+    // strict arithmetic, cellLength <= radius, engine switches that exclude the rows): the request is remembered all the same
+    // and takes effect once the obstacle is gone (e.g. setToleranceArithmetic(true) afterwards).
+    // While (nearly) every step rebuilds its rows -- violent phases -- a host-side controller (sphx_tuning.persist_controller)
+    // leaves the mode for 256 steps and runs the plain tolerance step, as PBD's skin rows do.
     bool setPersistentRows(bool on);
     bool persistentRows() const;
+    // API slot -> working index while the solver's own arrays are in the working order (nullptr otherwise): readers of
+    // solver-internal fields gather through it instead of flushing the mode
+    const int* persistentSlotMap() const;
     // make every per-particle array of the solver follow the API order again (host-side readers of solver-internal fields,
     // snapshots, setters); the next step() re-primes the working copy from the API arrays and rebuilds the rows
     void invalidatePersistentOrder();
@@ -98,7 +105,8 @@ private:
     void computeBoundaryMass();
     void neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart);
     void enqueueStep();   // neighbour search + solver step, no sync
-    bool persistentActive();          // the mode is on AND usable for this solver and grid
+    bool persistentActive();          // the mode is on AND usable for this solver and grid AND not suspended by the controller
+    void persistentController(int stepsSinceLastCall);   // between steps: suspend / resume the mode by its rebuild rate
     void persistentPrime();           // working copy := API arrays, identity map, rows to be rebuilt
     void persistentSearch();          // cells of the API slots, displacement check, stable sort of the slot map, conditional re-sort
     void persistentExport();          // API arrays := working copy through the slot map

@@ -109,6 +109,47 @@ typedef enum sphx_field {
 
 typedef struct sphx_system sphx_system;   /* opaque: owns SPHParticles x2, a solver, an SPHSystem */
 
+/*
+ * Engine tuning: the behaviour switches of the engine that are not part of the simulation (schedules, row capacity, which
+ * sweeps run quad-per-particle, loop windows, stream priorities of the slab layer).  Until r04 these were SPHX_* environment
+ * variables read inside the library; the library now reads NO environment variable for its behaviour (SPHX_RCCL_LIBRARY, the
+ * path of the RCCL build to open, is the one exception).  Process-wide: sphx_tuning_defaults fills the defaults,
+ * sphx_set_tuning installs a block; systems and slab groups read it when they are CREATED, the fields marked (live) at every
+ * step.  -1 (or 0 where noted) = the engine's own default.  Results never depend on these switches (every combination is
+ * bit-exact in strict arithmetic and inside the contract in tolerance arithmetic: tests/test_gpu_parity.py).
+ */
+typedef struct sphx_tuning {
+    int   struct_size;        /* sizeof(sphx_tuning) of the caller: a binding built against another layout is refused */
+    int   engine_flags;       /* OR-ed into sphx_params.reserved[0] (bit0 unfused, bit1 no rows, bit2 LDS tiles, bit3 linear tiles, bit4 no quads) */
+    int   row_capacity;       /* entries per neighbour row: 0 = adaptive from 48 (slabs: 96 fixed), 8..1024 = fixed */
+    int   quad_mask;          /* strict arithmetic: sweeps that walk rows quad-per-particle (-1: the rate sweeps) */
+    int   duo_mask;           /* ... with two lanes per particle (-1: head and viscosity+colour from 4 M particles on) */
+    int   quad_mask_tol;      /* tolerance arithmetic: quad walks (-1: 15, of which the corrections only from 4 M particles on) */
+    int   tol_strict_rate;    /* tolerance arithmetic, >= 4 M particles: rate sweeps on the strict quad kernel (-1: yes) */
+    int   brick;              /* 1: the opt-in compact-brick LDS stage of tolerance arithmetic (measured slower; 0) */
+    int   brick_min;          /* particles from which the brick stage is used (0: 2,000,000) */
+    int   range_order;        /* range-restricted launches of wide slabs keep the (y-chunk, x) tile schedule (-1: yes) */
+    int   range_order_min;    /* ... from this many particles per range on (0: 3,000,000) */
+    int   force_tile_order;   /* 1: build the tile schedule on small grids too (tests) */
+    int   no_fastmath;        /* 1: plain IEEE operators instead of the validated exact fast sqrt / division paths */
+    int   no_graph;           /* (live) 1: sphx_step_n launches eagerly instead of replaying a captured hipGraph */
+    int   graph_debug;        /* (live) 1: say on stdout why a capture failed */
+    int   dfsph_host_loop;    /* 1: adaptive DFSPH decides its loops on the host (one read-back per iteration), as the reference does */
+    int   dfsph_window;       /* (live) iterations of a device-decided loop enqueued as ordinary launches: -1 follow the counts, >= 0 fixed */
+    int   dfsph_no_tail;      /* (live) 1: no persistent loop-tail launch, gated launches for every possible iteration */
+    int   no_kick_fusion;     /* (live) 1: the gravity kick of fixed-count DFSPH stays a pass of its own */
+    float pbd_skin;           /* PBD skin rows: skin as a fraction of the radius (< 0: 0.05; 0: one row build per Jacobi iteration) */
+    int   pbd_skin_fixed;     /* 1: no controller that drops the skin in violent phases */
+    int   persist_controller; /* persistent rows: leave the mode for 256 steps while (nearly) every step rebuilds its rows (-1: yes) */
+    int   slab_edge_stream;   /* slab layer: edge layers of a DFSPH / WCSPH stage on a stream of their own beside the interior (-1: yes) */
+    int   slab_edge_priority; /* ... 1: that stream at the highest priority (0) */
+    int   slab_comm_priority; /* RCCL transport's communication stream: 0 highest priority (default), 1 default priority, 2 lowest */
+    int   reserved[7];
+} sphx_tuning;
+int  sphx_tuning_defaults(sphx_tuning *out);
+int  sphx_set_tuning(const sphx_tuning *tuning);       /* NULL: back to the defaults */
+int  sphx_get_tuning(sphx_tuning *out);
+
 /* library / device ------------------------------------------------------------------------- */
 const char *sphx_last_error(void);
 int  sphx_device_count(void);                         /* hipGetDeviceCount; 0 when no GPU */
@@ -218,7 +259,15 @@ int  sphx_iters(const sphx_system *sys, int *divergence_iters, int *density_iter
 int  sphx_field_bytes(const sphx_system *sys, int field, size_t *bytes);
 int  sphx_get(const sphx_system *sys, int field, void *host_dst, size_t bytes);
 int  sphx_set(sphx_system *sys, int field, const void *host_src, size_t bytes);   /* POS, VEL, WARM, BMASS, POS_LAST, ID */
+/* Raw device pointer.  With persistent rows (reserved[3] = 2) the solver steps a working copy and the API fields (POS ... BMASS)
+ * are EXPORTED by every step: read them freely, but after WRITING one of them through the pointer call sphx_invalidate_order()
+ * before the next step, or the write is overwritten by the next export (sphx_set does this itself).  Asking for the pointer of a
+ * solver-internal field (ALPHA ... POSF) flushes the mode (arrays permuted into API order, rows rebuilt by the next step);
+ * sphx_get reads such fields through the slot map without disturbing it.                                                      */
 int  sphx_device_ptr(const sphx_system *sys, int field, void **device_ptr);
+/* tell a persistent-rows system that its API arrays were written in place: the next step re-primes its working copy from them
+ * and rebuilds the rows (no-op for other systems; SPHSystem::invalidatePersistentOrder)                                        */
+int  sphx_invalidate_order(sphx_system *sys);
 
 /* per-kernel timing of the last sphx_profile_step: names/ms arrays of up to cap entries */
 int  sphx_profile_step(sphx_system *sys, int cap, char (*names)[48], float *ms, int *count);
@@ -228,6 +277,9 @@ int  sphx_profile_step(sphx_system *sys, int cap, char (*names)[48], float *ms, 
  * eagerly.  collect() synchronises and returns, per span name, total ms and launch count.       */
 int  sphx_kernel_timer(int enable, const char *filter);
 int  sphx_kernel_timer_collect(int cap, char (*names)[48], float *total_ms, int *launches, int *count);
+/* name (>= 48 bytes) of the kernel instantiation the most recent DFSPH error sweep was launched as; returns its variant number
+ * (>= 0): 1 strict quad walk, 2 tolerance quad walk, 3 strict quad walk serving a tolerance-mode step, 4 duo, 5 lane, 6 LDS tiles, 7 brick */
+int  sphx_last_rate_kernel(char *name, int capacity);
 
 /* pointwise evaluation of the four smoothing kernels of CUDAFunctions.cuh:23-98 on the device
  * (device-function parity test): r3 = n displacement vectors, outputs W[n], gradW[3n],

@@ -12,6 +12,7 @@ ORACLE_TEST_THREADS = 16
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -23,7 +24,10 @@ def sphx():
     import sphx as mod
     if not os.path.exists(mod.LIB_PATH):
         mod.build()
-    return mod
+    # the tests select engine variants with SPHX_* environment variables (monkeypatch.setenv); the library reads none itself:
+    # tests/tuning_env.py turns them into the sphx_tuning block before every system creation / step
+    import tuning_env
+    return tuning_env.install(mod)
 
 
 @pytest.fixture(scope="session")

@@ -11,6 +11,7 @@ import torch  # noqa: F401  (first: the engine and RCCL must bind to the HIP run
 
 import slab_worker  # puts the package on sys.path
 import sphx
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 
 
 def main():
@@ -22,6 +23,7 @@ def main():
     sphx.set_device(0)
     P, fluid, boundary = sphx.scene(nx)
     slab_worker.configure(P, sphx, solver, adaptive)
+    P.reserved[3] = int(os.environ.get("SPHX_TEST_ARITH", "0"))          # arithmetic contract of the slabs (0 strict, 1 tolerance, 2 persistent)
     pos, vel = slab_worker.splash(len(fluid), P, seed)
     token_file = os.path.join(outdir, "token")
     if rank == 0:

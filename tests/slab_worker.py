@@ -48,6 +48,7 @@ def run(rank, world, port, backend, engine_kind, nx, steps, outdir, seed, solver
         P, fluid, boundary = E.scene(nx)
     else:
         import sphx as E
+        import tuning_env; tuning_env.install(E)
         E.set_device(0)
         torch.cuda.set_device(0)
         E.use_stream(torch.cuda.current_stream().cuda_stream)

@@ -34,9 +34,10 @@ def test_hip_slab_driver_matches_single_domain_oracle(oracle, tmp_path, world, s
 
 
 # ------------------------------------------------------------------------------------ the native layer (csrc/slab.hip)
-def _native(sphx, world, solver, adaptive, nx, steps, seed, flags, tweak=None):
+def _native(sphx, world, solver, adaptive, nx, steps, seed, flags, tweak=None, arith=0):
     P, fluid, boundary = sphx.scene(nx)
     slab_worker.configure(P, sphx, solver, adaptive)
+    P.reserved[3] = arith
     if tweak:
         tweak(P)
     pos, vel = slab_worker.splash(len(fluid), P, seed)
@@ -76,6 +77,52 @@ def test_native_slab_layer_matches_single_domain_oracle(sphx, oracle, world, sol
         assert iters == it
     if world > 1:
         assert moved > 0, "the test must exercise migration across cuts"
+
+
+def _single_engine(sphx, nx, steps, seed, solver, adaptive, arith, tweak=None):
+    """the single-device ENGINE in the given arithmetic on the slab tests' splash state, ordered by particle id"""
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, adaptive)
+    P.reserved[3] = arith
+    if tweak:
+        tweak(P)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    s = sphx.System(P, pos, boundary, ctor_step=False)
+    s.set(sphx.F_VEL, vel[s.get(sphx.F_ID)])
+    for k in range(steps):
+        s.step()
+        if solver == "pbd" and k == 0:
+            s.set(sphx.F_POS_LAST, slab_worker.pbd_last_positions(pos, vel, P)[s.get(sphx.F_ID)])
+    order = np.argsort(s.get(sphx.F_ID))
+    out = (s.get(sphx.F_POS)[order], s.get(sphx.F_VEL)[order], s.get(sphx.F_DENSITY)[order], s.iters())
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("world,solver,adaptive,nx", [(1, "dfsph", False, 12), (2, "dfsph", False, 12), (3, "dfsph", True, 12), (8, "dfsph", False, 24),
+                                                       (2, "wcsph", False, 12), (8, "wcsph", False, 24), (2, "pbd", False, 12), (8, "pbd", False, 24)])
+@pytest.mark.parametrize("flags", [0, 1], ids=["overlap", "no-overlap"])
+def test_native_slab_layer_in_tolerance_arithmetic(sphx, oracle, monkeypatch, world, solver, adaptive, nx, flags):
+    """r05: the slab layer under the TOLERANCE contract (sphx_params.reserved[3] = 1 handed to sphx_slab_create), the
+    arithmetic of the headline.  A slab's rows are slices of the single-device rows and both sides pick the same kernel variants at
+    these sizes, so the run must equal the single-device tolerance ENGINE bit for bit -- positions, velocities, densities, adaptive
+    iteration counts -- for 1, 2, 3 and 8 slabs, all three solvers, both schedules; and it must sit within 1e-5 of the strict ORACLE
+    on the first steps while differing from it (the tolerance kernels really ran).  PBD: the single-device engine keeps its skin rows
+    off here (slabs rebuild their rows per Jacobi iteration, and under the tolerance contract the order of a row decides the bits)."""
+    monkeypatch.setenv("SPHX_PBD_SKIN", "0")
+    steps, seed = 6, 17
+    ids, pos, vel, den, iters, moved = _native(sphx, world, solver, adaptive, nx, steps, seed, flags, arith=1)
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    rp, rv, rd, it = _single_engine(sphx, nx, steps, seed, solver, adaptive, 1)
+    assert_bit_equal(pos, rp, "tolerance slab pos"); assert_bit_equal(vel, rv, "tolerance slab vel"); assert_bit_equal(den, rd, "tolerance slab density")
+    if solver == "dfsph":
+        assert iters == it
+    if world > 1:
+        assert moved > 0, "the test must exercise migration across cuts"
+    op, ov, od = _single_domain(oracle, nx, steps, seed, solver, adaptive)
+    assert not np.array_equal(den.view(np.uint32), od.view(np.uint32)), "the tolerance kernels must actually run"
+    # (six steps of a disordered splash: the deviation from the strict oracle stays small but is not the subject here)
+    assert np.abs(pos.astype(np.float64) - op.astype(np.float64)).max() <= 1e-3 * float(sphx.scene(nx)[0].space[0])
 
 
 @pytest.mark.parametrize("world,solver", [(1, "dfsph"), (2, "dfsph"), (2, "wcsph"), (2, "pbd")])
@@ -256,6 +303,11 @@ def test_bench_launch_line_two_ranks(tmp_path):
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 2 and r["unit"] == "steps/s" and r["scaling"] == "strong"
     assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1000.0) < 1.0
     assert r["config"]["particles"] == 40 * 60 * 40 and "2 x-slabs" in r["config"]["decomposition"]
+    # r05: the slabs run the headline's arithmetic contract (bench.py --arith persistent by default -> tolerance in the slab layer) and the
+    # line carries its own base: the same workload as ONE slab in the same arithmetic, measured in the same run
+    assert r["config"]["arithmetic"] == "tolerance" and r["config"]["arithmetic_asked"] == "persistent"
+    assert r["scaling_base"]["ms_per_step"] > 0 and "ONE slab" in r["scaling_base"]["what"] and "tolerance" in r["scaling_base"]["what"]
+    assert abs(r["scaling_base"]["speedup_of_this_line"] * r["ms_per_step"] - r["scaling_base"]["ms_per_step"]) < 1e-6 * r["scaling_base"]["ms_per_step"] + 1e-9
     assert r["roofline"] and r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
     # the line verifies itself: the communicator as the RCCL library reports it, every rank's device, clock, ownership,
     # traffic and roofline leg
@@ -411,6 +463,29 @@ def test_native_slab_layer_rccl_transport_deferred_completion(oracle, tmp_path, 
     parts = _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, rebalance, _mock_library(), {"SPHX_MOCK_RCCL_DEFER_US": "300"})
     same, rit = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, adaptive)
     assert same, "deferred completion changed the results"
+    if solver == "dfsph":
+        assert all(tuple(p["iters"]) == rit for p in parts)
+
+
+@pytest.mark.parametrize("world,solver,adaptive,library", [(3, "dfsph", True, "mock-deferred"), (4, "wcsph", False, "mock-deferred"), (8, "dfsph", False, "mock-deferred"),
+                                                           (4, "dfsph", True, "installed-rccl-to-self")])
+def test_native_slab_layer_tolerance_arithmetic_over_the_rccl_transport(sphx, tmp_path, monkeypatch, world, solver, adaptive, library):
+    """the tolerance contract over the RCCL transport: 3, 4 and 8 processes with transfers landing 300 us late (stand-in library), and
+    ONE process driving 4 slabs through the installed librccl (grouped sends to self) -- each bit-identical to the single-device
+    tolerance engine, iteration counts included, with moving cuts"""
+    nx, steps, seed = (32 if world == 8 else (24 if library.startswith("installed") else 16)), 6, 41
+    if library.startswith("installed"):
+        parts = _run_ranks(tmp_path, 1, nx, steps, seed, solver, adaptive, True, None, {"SPHX_TEST_SLABS_PER_PROCESS": str(world), "SPHX_TEST_ARITH": "1"})
+        assert "mock" not in str(parts[0]["rccl_library"]) and "librccl" in str(parts[0]["rccl_library"])
+    else:
+        parts = _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, True, _mock_library(), {"SPHX_MOCK_RCCL_DEFER_US": "300", "SPHX_TEST_ARITH": "1"})
+    ids = np.concatenate([p["ids"] for p in parts])
+    assert np.array_equal(np.sort(ids), np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    order = np.argsort(ids)
+    rp, rv, rd, rit = _single_engine(sphx, nx, steps, seed, solver, adaptive, 1)
+    assert_bit_equal(np.concatenate([p["pos"] for p in parts])[order], rp, "tolerance ranks pos")
+    assert_bit_equal(np.concatenate([p["vel"] for p in parts])[order], rv, "tolerance ranks vel")
+    assert_bit_equal(np.concatenate([p["density"] for p in parts])[order], rd, "tolerance ranks density")
     if solver == "dfsph":
         assert all(tuple(p["iters"]) == rit for p in parts)
 

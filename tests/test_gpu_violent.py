@@ -1,0 +1,128 @@
+"""Parity in the VIOLENT regime at scale: restart pairs started from states only the engine can reach.
+
+Every other oracle comparison beyond free fall runs on <= 20,736 particles, because the CPU oracle needs seconds per step
+at 1 M.  Here the strict ENGINE carries a 1 M (and a 3.1 M) scene through its impact on the floor -- rows to 47 entries,
+|v| in the hundreds, densities of several rho0, for the fixed-count run of the larger scene a state on its way to a blow-up --
+and that state (positions, velocities, DFSPH warm-start stiffness) is handed to a FRESH oracle and a FRESH engine, which
+then take a few steps side by side:
+  * strict engine: every field bit-identical to the oracle, adaptive runs with identical iteration counts (the divergence
+    solve saturating at 20, DFSPHSolver.cu:331-363; clamps BasicSPHSolver.cu:85-96,160-161);
+  * tolerance and persistent engines: ids / cell indices / the cell table identical, positions and densities within 1e-5
+    (element by element, relative to max(|value|, 1 % of the field scale)) after the first step and inside 4x the envelope
+    of the strict engine started one ulp away afterwards (no arithmetic holds 1e-5 for long in this regime: see
+    test_gpu_tolerance.py::test_tolerance_through_wall_contact).
+The oracle runs with every host core here (3 steps of 1 M particles with up to 20 + 10 iterations each)."""
+import numpy as np
+import pytest
+
+from conftest import ORACLE_TEST_THREADS, assert_bit_equal, same_params
+from test_gpu_parity import FIELDS_COMMON, FIELDS_DFSPH, compare
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def engine_state(sphx, nx, fixed, settle):
+    """the STRICT engine's state after `settle` steps (counting the constructor step) of the dam break: arrays in API order"""
+    P, fluid, boundary = sphx.scene(nx)
+    P.solver = sphx.DFSPH
+    P.dfsph_fixed_div, P.dfsph_fixed_den = fixed
+    s = sphx.System(P, fluid, boundary)
+    s.step_n(settle - 1)
+    state = {"pos": s.get(sphx.F_POS), "vel": s.get(sphx.F_VEL), "warm": s.get(sphx.F_WARM), "iters": s.iters(),
+             "rows": s.row_stats()[1], "rho_max": float(s.get(sphx.F_DENSITY).max())}
+    s.close()
+    return P, boundary, state
+
+
+def restart(mod, P, boundary, state, arith=None, pos=None):
+    """a fresh system of `mod` (sphx or the oracle) that continues from `state`"""
+    Q = same_params(mod.Params(), P)
+    if arith is not None:
+        Q.reserved[3] = arith
+    g = mod.System(Q, state["pos"] if pos is None else pos, boundary, ctor_step=False)
+    ids = g.get(mod.F_ID)
+    g.set(mod.F_VEL, state["vel"][ids])
+    g.set(mod.F_WARM, state["warm"][ids])
+    return g
+
+
+@pytest.fixture()
+def all_cores(oracle):
+    L = oracle.lib()
+    L.oracle_set_threads(L.oracle_max_threads())
+    yield
+    L.oracle_set_threads(min(L.oracle_max_threads(), ORACLE_TEST_THREADS))
+
+
+# (nx, fixed iteration counts or (-1, -1) = the reference's adaptive control, steps before the hand-over, what the state must show)
+CASES = [
+    pytest.param(88, (1, 4), 300, id="1M-fixed-1-4-step300"),
+    pytest.param(88, (-1, -1), 215, id="1M-adaptive-post-impact"),
+    pytest.param(128, (1, 4), 240, id="3M-fixed-1-4-running-away"),
+]
+
+
+@pytest.mark.parametrize("nx,fixed,settle", CASES)
+def test_strict_engine_bit_exact_from_post_impact_states(sphx, oracle, all_cores, nx, fixed, settle):
+    P, boundary, st = engine_state(sphx, nx, fixed, settle)
+    n = len(st["pos"])
+    speed = float(np.abs(st["vel"]).max())
+    # the state must really be a violent one: the column has landed (densities beyond rest, rows longer than the lattice's 32)
+    assert st["rho_max"] > 1.05 * P.rho0 and st["rows"] > 36 and speed > 5.0, (st["rho_max"], st["rows"], speed)
+    g = restart(sphx, P, boundary, st)
+    o = restart(oracle, P, boundary, st)
+    assert_bit_equal(g.get(sphx.F_ID), o.get(oracle.F_ID), "ids after the hand-over")
+    names = FIELDS_COMMON + FIELDS_DFSPH
+    for step in range(3):
+        g.step(); o.step()
+        compare(sphx, oracle, g, o, names, "%d particles, step +%d" % (n, step + 1))
+        assert g.iters() == o.iters(), (step, g.iters(), o.iters())
+    if fixed[0] < 0:
+        assert g.iters()[0] >= 10, "the adaptive state must keep the divergence solve busy: %s" % (g.iters(),)
+    g.close(); o.close()
+
+
+def _dev(a, b, scale):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    return float(d.max() / scale), float((d / np.maximum(np.abs(b.astype(np.float64)), 0.01 * scale)).max())
+
+
+def _by_id(mod, s, field):
+    ids = s.get(mod.F_ID)
+    a = s.get(field); b = np.empty_like(a); b[ids] = a
+    return b
+
+
+@pytest.mark.parametrize("nx,fixed,settle", CASES[:2])
+def test_tolerance_engines_from_post_impact_states(sphx, oracle, all_cores, nx, fixed, settle):
+    P, boundary, st = engine_state(sphx, nx, fixed, settle)
+    o = restart(oracle, P, boundary, st)
+    engines = {1: restart(sphx, P, boundary, st, arith=1), 2: restart(sphx, P, boundary, st, arith=2)}
+    # control: the strict engine from the same state with half of the position components moved by ONE ulp
+    rng = np.random.default_rng(settle)
+    pos1 = np.where(rng.random(st["pos"].shape) < 0.5, np.nextafter(st["pos"], np.float32(2)), st["pos"]).astype(np.float32)
+    control = restart(sphx, P, boundary, st, pos=pos1)
+    env = {"pos": 0.0, "rho": 0.0}
+    for step in range(3):
+        o.step(); control.step()
+        ref = {f: o.get(getattr(oracle, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F")}
+        rpos, rrho = _by_id(oracle, o, oracle.F_POS), _by_id(oracle, o, oracle.F_DENSITY)
+        env["pos"] = max(env["pos"], _dev(_by_id(sphx, control, sphx.F_POS), rpos, P.space[0])[0])
+        env["rho"] = max(env["rho"], _dev(_by_id(sphx, control, sphx.F_DENSITY), rrho, P.rho0)[0])
+        for mode, g in engines.items():
+            g.step()
+            dp = _dev(_by_id(sphx, g, sphx.F_POS), rpos, P.space[0])
+            dr = _dev(_by_id(sphx, g, sphx.F_DENSITY), rrho, P.rho0)
+            if step == 0:
+                # one step from identical inputs: the per-step statement of the contract, element by element, integer fields exact
+                for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
+                    assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, f)
+            assert dp[0] <= max(TOL, 4.0 * env["pos"]), "arith %d step +%d: positions %.2e, one-ulp envelope %.2e" % (mode, step + 1, dp[0], env["pos"])
+            assert dr[0] <= max(TOL, 4.0 * env["rho"]), "arith %d step +%d: densities %.2e, one-ulp envelope %.2e" % (mode, step + 1, dr[0], env["rho"])
+    in_use, builds, counted = engines[2].persistent_stats()
+    assert in_use and counted == 3 and builds >= 2, "the persistent mode must run and rebuild its rows in this regime: %s" % ((in_use, builds, counted),)
+    for g in list(engines.values()) + [control]:
+        g.close()
+    o.close()

@@ -5,6 +5,8 @@ tests/test_gpu_parity.py::test_reference_source_anchor_statistics_wcsph_pbd_on_g
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 V = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "refsrc_anchors.json")))["variants"]["float_fabs"]
 def stats(s):
     rho = s.get(sphx.F_DENSITY).astype(np.float64); pos = s.get(sphx.F_POS).astype(np.float64); vel = s.get(sphx.F_VEL).astype(np.float64)

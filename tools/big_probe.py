@@ -2,6 +2,8 @@
 import sys, time, numpy as np
 sys.path[:0] = ["cpp-fluid-particles_amd"]
 import torch, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 for nx in [int(a) for a in sys.argv[1].split(",")]:
     for flags in [int(a) for a in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]:
         P, fluid, boundary = sphx.scene(nx)

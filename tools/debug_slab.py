@@ -21,6 +21,7 @@ def worker(rank, world, prt, kind, nx, steps, outdir, seed):
         from oracle import oracle as E
     else:
         import sphx as E
+        import tuning_env; tuning_env.install(E)
         E.set_device(0); torch.cuda.set_device(0); E.use_stream(torch.cuda.current_stream().cuda_stream)
     P, fluid, boundary = E.scene(nx)
     P.solver = E.DFSPH; P.dfsph_fixed_div, P.dfsph_fixed_den = 2, 3; P.dt = 0.001

@@ -1,6 +1,8 @@
 import sys, os
 sys.path.insert(0, "/root/repo/cpp-fluid-particles_amd")
 import numpy as np, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 P, f, b = sphx.scene(56)
 P.solver = sphx.DFSPH; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4; P.reserved[3] = 1
 s = sphx.System(P, f, b)

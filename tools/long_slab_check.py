@@ -3,6 +3,8 @@ python tools/long_slab_check.py nx world steps [solver=dfsph] [adaptive=1]   -> 
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 nx, world, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 solver = sys.argv[4] if len(sys.argv) > 4 else "dfsph"
 adaptive = (sys.argv[5] if len(sys.argv) > 5 else "1") == "1"

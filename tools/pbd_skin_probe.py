@@ -6,6 +6,8 @@ code = r'''
 import sys, os, time
 sys.path.insert(0, os.path.join(%r, "cpp-fluid-particles_amd"))
 import sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 P, f, b = sphx.scene(%s); P.solver = sphx.PBD; P.pbd_iters = 4
 s = sphx.System(P, f, b); s.step()
 def leg(n):

@@ -1,6 +1,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 which = sys.argv[1:] or ["wcsph263k", "dfsph1m", "pbd1m"]
 cfg = {"wcsph263k": (56, sphx.WCSPH), "dfsph1m": (88, sphx.DFSPH), "pbd1m": (88, sphx.PBD), "dfsph10m": (190, sphx.DFSPH)}
 for name in which:

@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-parti
 import numpy as np
 import torch
 import sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 190
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 450
 div, den = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1, 4)

@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 for name, solver, dt in (("wcsph", sphx.WCSPH, 0.001), ("dfsph", sphx.DFSPH, 0.002), ("pbd20", sphx.PBD, 0.002)):
     P, f, b = sphx.scene(24)
     P.solver = solver; P.dt = dt

@@ -4,6 +4,8 @@ states and iteration counts must be identical (strict arithmetic: bit for bit), 
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 arith = int(sys.argv[3]) if len(sys.argv) > 3 else 0

@@ -5,6 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sphx
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 from oracle import oracle as O
 from test_gpu_tolerance import restart_pair, deviations
 for solver, dt, k0, horizon in ((0, 0.001, 125, 60), (1, 0.002, 55, 50), (2, 0.002, 50, 50)):
