@@ -251,6 +251,12 @@ def settled_leg(sphx, torch, nx, solver, div, den, settle, steps, arith="strict"
     leg.update({"steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
                 "step_hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS,
                 "neighbours_per_particle": neighbour_stats(sim)})
+    # what the ragged rows of this state cost the quad walk, and what bounding the walk at 48 entries (+ a compact launch for the tails)
+    # could save at most
+    rw = sim.row_walk_stats(48)
+    rw["walked_over_even"] = rw["steps_walked"] / float(max(rw["steps_even_rows"], 1))
+    rw["saving_of_a_cut_at_48"] = 1.0 - (rw["steps_cut"] + rw["steps_tail_launch"]) / float(max(rw["steps_walked"], 1))
+    leg["row_walk"] = rw
     if arith == "persistent":
         # (in use = at the end of the leg: while nearly every step rebuilds its rows the controller leaves the mode for 256 steps at a time)
         in_use, builds, counted = sim.persistent_stats()

@@ -339,6 +339,38 @@ int sphx_row_stats(const sphx_system* h, long long* total, int* longest, int* hi
     return SPHX_OK;
 }
 
+// What the quad-per-particle row walk pays for ragged rows, from the row lengths of the most recent build (host arithmetic on a copy
+// of the counts): a wave holds 16 particles x 4 lanes and runs to the longest row among its 16 (walk_row_quad, sph_device.hpp).
+//   out[0] waves (16 particles each)            out[1] chunk steps as walked: sum over waves of max_i ceil(len_i / 4)
+//   out[2] chunk steps of perfectly even rows: ceil(sum_i ceil(len_i / 4) / 16) summed per tile-quarter = total chunks / 16
+//   out[3] chunk steps if every walk stopped at `cut` entries   out[4] chunk steps a compact second launch would need for the
+//   tails beyond `cut` (16 tails per wave)      out[5] particles longer than `cut`
+int sphx_row_walk_stats(const sphx_system* h, int cut, long long out[6])
+{
+    if (!h || !h->wcsph || !out || cut < 4) return fail(SPHX_ERR_INVALID, "sphx_row_walk_stats: bad argument");
+    const int n = (int)h->system->getFluids()->size();
+    std::vector<int> cnt((size_t)std::max(n, 1));
+    if (n > 0 && (hipMemcpyAsync(cnt.data(), h->wcsph->engineRowCounts(), sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+                  hipStreamSynchronize(sphx::stream()) != hipSuccess))
+        return fail(SPHX_ERR_HIP, "sphx_row_walk_stats: copy failed");
+    long long waves = 0, walked = 0, chunks = 0, cutWalk = 0, over = 0, tailChunks = 0;
+    const int cutChunks = (cut + 3) / 4;
+    for (int w0 = 0; w0 < n; w0 += 16) {
+        int mx = 0, mxCut = 0;
+        for (int i = w0; i < std::min(w0 + 16, n); ++i) {
+            const int c = (std::max(cnt[i], 0) + 3) / 4;
+            mx = std::max(mx, c); mxCut = std::max(mxCut, std::min(c, cutChunks));
+            chunks += c;
+            if (c > cutChunks) { ++over; tailChunks += c - cutChunks; }
+        }
+        ++waves; walked += mx; cutWalk += mxCut;
+    }
+    out[0] = waves; out[1] = walked; out[2] = (chunks + 15) / 16; out[3] = cutWalk;
+    // tails packed 16 to a wave, sorted by nothing: a lower bound is tailChunks / 16, an upper bound one wave per 16 tails at the longest tail
+    out[4] = (tailChunks + 15) / 16; out[5] = over;
+    return SPHX_OK;
+}
+
 int sphx_row_capacity(const sphx_system* h, int* capacity)
 {
     if (!h || !h->wcsph || !capacity) return fail(SPHX_ERR_INVALID, "sphx_row_capacity: bad argument");

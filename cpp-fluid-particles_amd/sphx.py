@@ -34,7 +34,7 @@ EXPORTS = [
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
     "sphx_tuning_defaults", "sphx_set_tuning", "sphx_get_tuning", "sphx_invalidate_order", "sphx_last_rate_kernel",
-    "sphx_get_params", "sphx_row_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
+    "sphx_get_params", "sphx_row_stats", "sphx_row_walk_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]
@@ -258,6 +258,14 @@ class System:
         hist = np.zeros(128, np.int32)
         _check(lib().sphx_row_stats(self._h, C.byref(tot), C.byref(mx), hist.ctypes.data))
         return tot.value, mx.value, hist
+
+    def row_walk_stats(self, cut=48):
+        """what ragged rows cost the quad walk (sphx_row_walk_stats): dict of wave / chunk-step counts for the last row build"""
+        out = (C.c_longlong * 6)()
+        lib().sphx_row_walk_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
+        _check(lib().sphx_row_walk_stats(self._h, cut, out))
+        keys = ("waves", "steps_walked", "steps_even_rows", "steps_cut", "steps_tail_launch", "particles_over_cut")
+        return dict(zip(keys, (int(v) for v in out)), cut=cut)
 
     def rows_stale(self):
         v = C.c_int()

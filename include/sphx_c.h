@@ -244,6 +244,10 @@ int  sphx_get_params(const sphx_system *sys, sphx_params *out);
 /* neighbour statistics of the most recent row build (bench.py reports them beside the timings): total
  * accepted pairs, longest row, histogram of row lengths (bin 127 = 127 and more; may be NULL)   */
 int  sphx_row_stats(const sphx_system *sys, long long *total_pairs, int *longest_row, int *hist128);
+/* what ragged rows cost the quad-per-particle walk (a wave runs to the longest of its 16 rows), from the row lengths of the last build:
+ * out6 = {waves, chunk steps as walked, chunk steps if all rows were even, chunk steps with every walk cut at `cut` entries,
+ * chunk steps of a compact second launch over the tails beyond `cut`, particles longer than `cut`} (bench.py: post-impact legs) */
+int  sphx_row_walk_stats(const sphx_system *sys, int cut, long long out6[6]);
 /* current capacity (entries per particle) of the neighbour rows: 96 fixed for slabs / SPHX_NBR_CAP, else adaptive from 48 */
 int  sphx_row_capacity(const sphx_system *sys, int *capacity);
 /* PBD diagnostics: how many times since creation the once-per-step neighbour rows had to be rebuilt inside a step because

@@ -7,9 +7,10 @@ and that state (positions, velocities, DFSPH warm-start stiffness) is handed to 
 then take a few steps side by side:
   * strict engine: every field bit-identical to the oracle, adaptive runs with identical iteration counts (the divergence
     solve saturating at 20, DFSPHSolver.cu:331-363; clamps BasicSPHSolver.cu:85-96,160-161);
-  * tolerance and persistent engines: ids / cell indices / the cell table identical, positions and densities within 1e-5
-    (element by element, relative to max(|value|, 1 % of the field scale)) after the first step and inside 4x the envelope
-    of the strict engine started one ulp away afterwards (no arithmetic holds 1e-5 for long in this regime: see
+  * tolerance and persistent engines: after the first step ids / cell indices / the cell table identical, every density within
+    1e-5, all but a handful of the million positions within 1e-5 of the domain (velocities of hundreds of m/s turn a relative
+    velocity error of 1e-5 into that much displacement in ONE step) and less deviation than the strict engine started one ulp
+    away; afterwards inside 4x the envelope of that control (no arithmetic holds 1e-5 for long in this regime: see
     test_gpu_tolerance.py::test_tolerance_through_wall_contact).
 The oracle runs with every host core here (3 steps of 1 M particles with up to 20 + 10 iterations each)."""
 import numpy as np
@@ -116,9 +117,17 @@ def test_tolerance_engines_from_post_impact_states(sphx, oracle, all_cores, nx, 
             dp = _dev(_by_id(sphx, g, sphx.F_POS), rpos, P.space[0])
             dr = _dev(_by_id(sphx, g, sphx.F_DENSITY), rrho, P.rho0)
             if step == 0:
-                # one step from identical inputs: the per-step statement of the contract, element by element, integer fields exact
+                # One step from identical inputs: integer fields exact, every density within 1e-5.  Positions: with |v| in the hundreds
+                # a relative velocity error of 1e-5 moves a particle 1e-5 of the domain in one step, so a handful of the million
+                # particles pass 1e-5 (measured: 3 of 1,022,208 in the fixed-count state at 1.5e-5, 29 in the adaptive one;
+                # the one-ulp control: 61 / 501 at 5e-4 / 1e-4 -- profiles/r05_violent_restart_pairs.txt): all but <= 100, and 99.99 %
+                # of them far inside it.
                 for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
                     assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, f)
+                assert dr[0] <= TOL and dr[1] <= TOL, (mode, dr)
+                per = np.abs(_by_id(sphx, g, sphx.F_POS).astype(np.float64) - rpos.astype(np.float64)).max(axis=1) / P.space[0]
+                assert int((per > TOL).sum()) <= 100 and np.quantile(per, 0.9999) <= TOL, (mode, int((per > TOL).sum()), float(np.quantile(per, 0.9999)))
+                assert dp[0] <= env["pos"], "arith %d: after one step the tolerance engine must deviate less than the one-ulp control (%.2e vs %.2e)" % (mode, dp[0], env["pos"])
             assert dp[0] <= max(TOL, 4.0 * env["pos"]), "arith %d step +%d: positions %.2e, one-ulp envelope %.2e" % (mode, step + 1, dp[0], env["pos"])
             assert dr[0] <= max(TOL, 4.0 * env["rho"]), "arith %d step +%d: densities %.2e, one-ulp envelope %.2e" % (mode, step + 1, dr[0], env["rho"])
     in_use, builds, counted = engines[2].persistent_stats()
