@@ -424,6 +424,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         c.packBoundary(*boundaries);
         c.ensureList(cellStartFluid, cellStartBoundary);
         ScopedKernel t("warm_permute");   // DFSPHSolver.cu:170-171
+        if (warmSorted) { warmSorted = false; return; }      // (a staged slab sort delivered it in sorted order)
         if (c.persistRows) {              // the arrays were re-sorted in this step only if the rows are being rebuilt (device flag)
             ew_gather_float_if(scratch.addr(), denWarmStiff.addr(), fluids->getSortPerm(), num, c.persistFlags.addr(0));
             ew_copy_float_if(denWarmStiff.addr(), scratch.addr(), num, c.persistFlags.addr(0));

@@ -562,7 +562,11 @@ struct sphx_slab_group {
             Slab& s = *sp;
             const int m = (int)s.hCounts[12], nl = s.hasLeft ? (int)s.hCounts[6] : 0, nr = s.hasRight ? (int)s.hCounts[9] : 0;   // m: kept
             const int n = nl + m + nr;
-            if (n > 0)
+            // DFSPH / WCSPH: the rows [from left | kept | from right] ARE the pre-sort order of this step; the SEARCH stage sorts them
+            // straight into the engine's arrays (no unpack pass, no copy back, the warm stiffness arrives sorted).  PBD unpacks.
+            if (s.solver != SPHX_PBD)
+                s.sys->system->setStagedInput(SPHSystem::StagedRows{{s.recvL.p, s.own.p, s.recvR.p}, {nl, m, nr}, s.extraFloats, s.extraFloats ? s.extra : nullptr});
+            else if (n > 0)
                 k_slab_unpack<<<blocks_for(n), 256, 0, st>>>(s.pos, s.vel, s.ids, s.extra, s.extraFloats, s.recvL.p, nl, s.own.p, m, s.recvR.p, nr);
             s.sys->system->getFluids()->setActiveCount((unsigned)n);
             s.held = n;

@@ -302,6 +302,57 @@ __global__ void k_copy_back_sorted(float3* __restrict__ pos, float3* __restrict_
     pos[i] = tp[i]; vel[i] = tv[i]; id[i] = ti[i];
 }
 
+// ---- the same sort fed from payload rows (slab drivers, SPHSystem::setStagedInput) ----------------------------------------
+// row t of the pre-sort order [from left | kept | from right]; W = 7 + E floats: pos(3) vel(3) id(1) extras(E)
+struct RowSource { const float* rows[3]; int count[3]; int W; };
+__device__ __forceinline__ const float* staged_row(const RowSource& r, int t)
+{
+    if (t < r.count[0]) return r.rows[0] + (size_t)t * r.W;
+    t -= r.count[0];
+    if (t < r.count[1]) return r.rows[1] + (size_t)t * r.W;
+    return r.rows[2] + (size_t)(t - r.count[1]) * r.W;
+}
+// k_cell_and_count with the position read from the staged rows (same keys, same run-compressed histogram atomics)
+__global__ void __launch_bounds__(256) k_cell_and_count_rows(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts, RowSource src,
+                                                             GridDesc g, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    int id = -1;
+    if (valid) {
+        const float* row = staged_row(src, i);
+        const int3 c = cell_of(v3(row[0], row[1], row[2]), g);
+        id = cell_id(c.x, c.y, c.z, g);
+        p2c[i] = id;
+    }
+    const int prev = __shfl_up(id, 1, 64);
+    const bool head = valid && (lane == 0 || prev != id);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long live = __ballot(valid);
+    if (!valid) return;
+    const unsigned long long below = heads & (~0ull >> (63 - lane));
+    const int first = 63 - __builtin_clzll(below);
+    const unsigned long long above = heads & ~(~0ull >> (63 - lane));
+    const int end = above ? __builtin_ctzll(above) : (64 - __builtin_clzll(live));
+    int base = 0;
+    if (head) base = atomicAdd(&counts[id], end - first);
+    base = __shfl(base, first, 64);
+    slot[i] = base + (lane - first);
+}
+// the sort's payload in ONE pass: sorted slot q takes row perm[q]
+__global__ void k_gather_rows_sorted(float3* __restrict__ pos, float3* __restrict__ vel, int* __restrict__ id, float* __restrict__ extra, int E,
+                                     RowSource src, const int* __restrict__ perm, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float* row = staged_row(src, perm[q]);
+    pos[q] = make_float3(row[0], row[1], row[2]);
+    vel[q] = make_float3(row[3], row[4], row[5]);
+    id[q] = __float_as_int(row[6]);
+    for (int e = 0; e < E; ++e) extra[(size_t)q * E + e] = row[7 + e];
+}
+
 // computeBoundaryMass_CUDA, SPHSystem.cu:79-105: mass_b = rhoB / max(EPS, sum_j W_ij) over the
 // boundary grid (the self term is excluded by W(0) = 0).
 struct BoundaryMassBody {
@@ -479,7 +530,10 @@ void SPHSystem::phase(int p)
     if ((p >= SPHX_PH_W_SEARCH && p <= SPHX_PH_W_PRESSURE) || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
         auto* w = dynamic_cast<BasicSPHSolver*>(_solver.get());
         if (!w || dynamic_cast<DFSPHSolver*>(_solver.get())) throw "SPHSystem::phase: WCSPH stages need a BasicSPHSolver";
-        if (p == SPHX_PH_W_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
+        if (p == SPHX_PH_W_SEARCH) {
+            if (_hasStaged) { _hasStaged = false; neighborSearchStaged(_staged); } else neighborSearch(_fluids, _fluidCellStart);
+            if (_afterSort) _afterSort();
+        }
         w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                          _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
                          _sc.surfaceTension, _sc.airPressure);
@@ -488,7 +542,14 @@ void SPHSystem::phase(int p)
     }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
     if (!dfsph) throw "SPHSystem::phase: stage-wise stepping needs a DFSPHSolver";
-    if (p == SPHX_PH_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
+    if (p == SPHX_PH_SEARCH) {
+        if (_hasStaged) {      // (the rows carry the warm-start stiffness: it arrives sorted, DFSPHSolver.cu:170-171 has nothing left to do)
+            _hasStaged = false;
+            neighborSearchStaged(_staged);
+            if (_staged.extraOut && _staged.extraFloats == 1) dfsph->noteWarmStiffnessSorted();
+        } else neighborSearch(_fluids, _fluidCellStart);
+        if (_afterSort) _afterSort();
+    }
     dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                     _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
                     _sc.airPressure, false);
@@ -580,6 +641,51 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
                                                          particles->getIdPtr(), perm, num);
         k_copy_back_sorted<<<blocks_for(num), 256, 0, st>>>(particles->getPosPtr(), particles->getVelPtr(), particles->getIdPtr(), _grid->tmp3.addr(), tv,
                                                             _grid->tmpi.addr(), num);
+    }
+}
+
+// The fluid sort of a slab step fed from payload rows (SPHSystem.h, StagedRows): neighborSearch with the cell keys read from the
+// staged positions and the gather writing every array the rows carry in sorted order.
+void SPHSystem::neighborSearchStaged(const StagedRows& staged)
+{
+    const int num = (int)_fluids->size();
+    if (staged.count[0] + staged.count[1] + staged.count[2] != num) throw "SPHSystem: the staged rows do not add up to the active particle count";
+    const int cellsPlusOne = _sc.cells.x * _sc.cells.y * _sc.cells.z + 1;
+    const GridDesc g = make_grid_desc(_sc.cells, _sc.cellLength, _cellOffsetX);
+    hipStream_t st = sphx::stream();
+    int* p2c = _fluids->getParticle2Cell();
+    int* perm = _fluids->getSortPerm();
+    DArray<int>& cellStart = _fluidCellStart;
+    const RowSource src{{staged.rows[0], staged.rows[1], staged.rows[2]}, {staged.count[0], staged.count[1], staged.count[2]}, 7 + staged.extraFloats};
+    HIP_CALL(hipMemsetAsync(cellStart.addr(), 0, sizeof(int) * cellsPlusOne, st));
+    if (num > 0) {
+        ScopedKernel t("grid_cell_count");
+        k_cell_and_count_rows<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), src, g, num);
+    }
+    {
+        ScopedKernel t("grid_scan");
+        device_exclusive_scan(cellStart.addr(), cellsPlusOne, _grid->blockSums.addr());
+    }
+    if (num <= 0) return;
+    {
+        ScopedKernel t("grid_stable_rank");
+        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
+        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
+        {
+            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
+            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            if (tiles > 1) {
+                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
+                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
+            }
+        }
+        k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
+        k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(), num, cellsPlusOne);
+    }
+    {
+        ScopedKernel t("grid_gather");
+        k_gather_rows_sorted<<<blocks_for(num), 256, 0, st>>>(_fluids->getPosPtr(), _fluids->getVelPtr(), _fluids->getIdPtr(), staged.extraOut,
+                                                               staged.extraOut ? staged.extraFloats : 0, src, perm, num);
     }
 }
 

@@ -47,6 +47,9 @@ public:
     long long readErrorTotalFixed();
     void resetErrorTotal();          // zero the |error| accumulators on the current stream (split error stages then all ADD)
     void noteIterations(int div, int den) { lastDiv = div; lastDen = den; itersPending = false; }
+    // the warm-start stiffness of this step is in sorted order already (a slab driver's staged sort wrote it there): the coming
+    // SEARCH stage leaves its permutation out (one-shot)
+    void noteWarmStiffnessSorted() { warmSorted = true; }
     // stage-wise drivers with fixed counts: the DIV_CORRECT stages run while this is on also apply the gravity kick
     // vel += dt G (BasicSPHSolver::force, BasicSPHSolver.cu:227-235) in their store, as DFSPHSolver::step does for the last
     // divergence correction of a whole-domain step; the driver then leaves the FORCE stage out
@@ -96,6 +99,7 @@ private:
     const float divergenceErrorThreshold;
     const int maxIter;
     int fixedDiv = -1, fixedDen = -1;
+    bool warmSorted = false;
     bool headDidFirstError = false;   // the fused head sweep already produced the first divergence error
     int lastDiv = 0, lastDen = 0;
     // device-side adaptive loops: {done, iteration, divergence iterations, density iterations, grid-barrier word} of the current step on the device,

@@ -76,6 +76,14 @@ public:
     // called inside a SEARCH stage right after the sort, before packing and row construction are enqueued: a slab driver reads
     // its layer boundaries from the fresh cell table there, so that the read-back overlaps the row build
     void setAfterSortHook(std::function<void()> hook) { _afterSort = std::move(hook); }
+    // Slab drivers hand the particles of a step over as PAYLOAD ROWS in three device buffers -- [from the left neighbour | kept |
+    // from the right neighbour], each row = pos(3) vel(3) id(1, bit pattern) + `extraFloats` solver floats -- which is the pre-sort
+    // order of the step.  The next SEARCH stage (DFSPH / WCSPH) then sorts the rows STRAIGHT into the particle arrays: cell keys from
+    // the staged positions, the same stable permutation, one gather that writes positions, velocities, ids and the solver's extra
+    // array (DFSPH: the warm-start stiffness) in sorted order -- no unpack pass, no copy back, no separate permutation of the extras
+    // (r05; same bits as unpacking and sorting in place).  One-shot: consumed by that stage.
+    struct StagedRows { const float* rows[3]; int count[3]; int extraFloats; float* extraOut; };
+    void setStagedInput(const StagedRows& staged) { _staged = staged; _hasStaged = true; }
     // Persistent neighbour rows (opt-in; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems; C ABI: reserved[3] = 2).
     // The solver steps a working copy of the fluid arrays that stays in the order of the last row build, the rows carry a skin
     // and are rebuilt only when a device-side check finds that some particle has moved more than 0.49 skin relative to the
@@ -104,6 +112,7 @@ private:
     void initialise(float sphM0, bool runStep, bool sortFluid = true);
     void computeBoundaryMass();
     void neighborSearch(const std::shared_ptr<SPHParticles>& particles, DArray<int>& cellStart);
+    void neighborSearchStaged(const StagedRows& staged);      // the fluid sort of a slab step, fed from payload rows
     void enqueueStep();   // neighbour search + solver step, no sync
     bool persistentActive();          // the mode is on AND usable for this solver and grid AND not suspended by the controller
     void persistentController(int stepsSinceLastCall);   // between steps: suspend / resume the mode by its rebuild rate
@@ -130,6 +139,8 @@ private:
     std::unique_ptr<sphx::GridScratch> _grid;
     std::unique_ptr<sphx::StepGraph> _graph;
     std::function<void()> _afterSort;
+    StagedRows _staged{};
+    bool _hasStaged = false;
     int _cellOffsetX = 0;     // slab decompositions: global x index of local cell column 0
     bool _slab = false;
 };

@@ -378,8 +378,62 @@ def test_tolerance_engines_at_headline_size_against_the_strict_engine(sphx):
                 assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, batch, f)
             assert _rel(g.get(sphx.F_POS), ref["F_POS"], P.space[0]) <= TOL, (mode, batch)
             assert _rel(g.get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0) <= TOL, (mode, batch)
+            for f, scale in (("F_POS", P.space[0]), ("F_DENSITY", P.rho0)):      # ... and element by element (r05)
+                a = g.get(getattr(sphx, f)).astype(np.float64); b = ref[f].astype(np.float64)
+                assert (np.abs(a - b) / np.maximum(np.abs(b), 0.01 * scale)).max() <= TOL, (mode, batch, f)
     in_use, builds, steps = runs[2].persistent_stats()
     assert in_use and steps == 12 and builds < steps, (in_use, builds, steps)
+    for g in runs.values():
+        g.close()
+
+
+def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
+    """the headline arithmetic at the headline SIZE outside free fall.  The 10,288,500-particle block is started 0.05
+    above the floor moving down at 1.5 m/s (positions and velocities through the C ABI, no constructor step), so that its bottom layers
+    meet the boundary particles after ~4 steps: boundary terms, the near-boundary (absolute-displacement) criterion of the persistent
+    rows, tiles and the (y-chunk, x) schedule all active at 10 M.  Tolerance and persistent engines against the STRICT engine (oracle-
+    identical wherever the oracle reaches, incl. post-impact states at 1-3 M: test_gpu_violent.py): ids, cell indices and the cell table
+    equal, positions and densities within 1e-5 ELEMENT BY ELEMENT (relative to max(|value|, 1 % of the field scale)) for 8 steps, and
+    inside 4x the envelope of a strict engine started one ulp away at step 12."""
+    P, fluid, boundary = sphx.scene(190)
+    P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
+    pos = fluid.copy()
+    pos[:, 1] -= np.float32(pos[:, 1].min() - 0.05)
+    vel = np.zeros_like(pos); vel[:, 1] = -1.5
+    rng = np.random.default_rng(12)
+    pos1 = np.where(rng.random(pos.shape) < 0.5, np.nextafter(pos, np.float32(8)), pos).astype(np.float32)
+    runs = {}
+    for mode, start in ((0, pos), (1, pos), (2, pos), ("control", pos1)):
+        Q = P.copy(); Q.reserved[3] = mode if mode != "control" else 0
+        g = sphx.System(Q, start, boundary, ctor_step=False)
+        g.set(sphx.F_VEL, vel[g.get(sphx.F_ID)])
+        runs[mode] = g
+    assert runs[0].n == 10288500
+
+    def elem(a, b, scale):
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        return float(d.max() / scale), float((d / np.maximum(np.abs(b.astype(np.float64)), 0.01 * scale)).max())
+
+    for batch in range(3):
+        for g in runs.values():
+            g.step_n(4)
+        ref = {f: runs[0].get(getattr(sphx, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F", "F_POS", "F_DENSITY")}
+        ids_c = runs["control"].get(sphx.F_ID)
+        same_order = np.array_equal(ids_c, ref["F_ID"])
+        env_p = elem(runs["control"].get(sphx.F_POS), ref["F_POS"], P.space[0])[0] if same_order else 1.0
+        env_r = elem(runs["control"].get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)[0] if same_order else 1.0
+        for mode in (1, 2):
+            g = runs[mode]
+            for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
+                assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, batch, f)
+            dp = elem(g.get(sphx.F_POS), ref["F_POS"], P.space[0]); dr = elem(g.get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
+            if batch < 2:
+                assert max(dp) <= TOL and max(dr) <= TOL, (mode, batch, dp, dr)
+            else:
+                assert dp[0] <= max(TOL, 4.0 * env_p) and dr[0] <= max(TOL, 4.0 * env_r), (mode, batch, dp, dr, env_p, env_r)
+    assert float(runs[0].get(sphx.F_POS)[:, 1].min()) < 0.03, "the block's bottom layers must be inside the support (0.04) of the floor's boundary particles"
+    in_use, builds, steps = runs[2].persistent_stats()
+    assert in_use and steps == 12 and builds >= 2, (in_use, builds, steps)
     for g in runs.values():
         g.close()
 
