@@ -257,14 +257,18 @@ template <class B> __device__ __forceinline__ constexpr bool has_pair2_impl(long
 template <class B> __device__ __forceinline__ constexpr bool has_pair2() { return has_pair2_impl<B>(0); }
 
 // ---- tolerance arithmetic ---------------------------------------------------------------------------------------
-// The same formulas with v_rsq_f32 / v_rcp_f32 (1 ulp), contraction into FMAs and folded constants: relative
+// The same formulas with v_rsq_f32 / v_rcp_f32 (1 ulp), fused multiply-adds and folded constants: relative
 // deviations of a few 1e-7 per pair term from the strict path (the reference binary itself is built with
 // -use_fast_math, src/CMakeLists.txt:43).  Only the row walks use it; support tests are unchanged because the rows
 // were built with the exact threshold.  tests/test_gpu_tolerance.py bounds the deviation from the oracle.
+// r05: every fused multiply-add is WRITTEN (fmaf), nothing is left to the compiler's contraction.  With `#pragma clang fp
+// contract(fast)` the choice of which product of `a*b + c*d + e*f` is fused differed between instantiations of the same
+// source (the 4-chunk body and the 1-chunk remainder of walk_row_quad), so a pair term depended on how long the OTHER rows
+// of its wave were -- i.e. on how particles are grouped into waves: a slab run and the single-device run agreed to 1e-7,
+// not bit for bit (tools/slab_tol_diag.py).  Now a tolerance-mode result is a function of the row and its inputs alone.
 struct TolPair { float r, q, rcpq; };      // |d|, 2|d|/R, 1/(q + EPS)
 __device__ __forceinline__ TolPair tol_pair(float r2, const KernelConsts& k)
 {
-#pragma clang fp contract(fast)
     TolPair t;
     t.r = r2 * __builtin_amdgcn_rsqf(fmaxf(r2, 1.0e-36f));
     t.q = t.r * k.twoOverR;
@@ -274,34 +278,34 @@ __device__ __forceinline__ TolPair tol_pair(float r2, const KernelConsts& k)
 // W (CUDAFunctions.cuh:23-35)
 __device__ __forceinline__ float tol_W(const TolPair& t, const KernelConsts& k)
 {
-#pragma clang fp contract(fast)
     const float a = 2.0f - t.q;
-    const float w = k.wA * ((t.q > 1.0f) ? a * a * a : ((3.0f * t.q - 6.0f) * t.q * t.q + 4.0f));
+    const float near = fmaf(fmaf(3.0f, t.q, -6.0f) * t.q, t.q, 4.0f);      // (3q - 6) q^2 + 4
+    const float w = k.wA * ((t.q > 1.0f) ? a * a * a : near);
     return (t.q < kEps) ? 0.0f : w;
 }
 // gradW = d * tol_gradW_scale (CUDAFunctions.cuh:37-50)
 __device__ __forceinline__ float tol_gradW_scale(const TolPair& t, const KernelConsts& k)
 {
-#pragma clang fp contract(fast)
-    const float poly = (t.q > 1.0f) ? ((12.0f - 3.0f * t.q) * t.q - 12.0f) : ((9.0f * t.q - 12.0f) * t.q);
+    const float poly = (t.q > 1.0f) ? fmaf(fmaf(-3.0f, t.q, 12.0f), t.q, -12.0f) : (fmaf(9.0f, t.q, -12.0f) * t.q);
     return poly * k.gradScale * t.rcpq;
 }
 // viscosity laplacian (CUDAFunctions.cuh:52-54)
 __device__ __forceinline__ float tol_viscLap(const TolPair& t, const KernelConsts& k)
 {
-#pragma clang fp contract(fast)
     return (k.R - t.r) * k.viscScale;
 }
 // surface-tension gradient = d * tol_surf_scale (CUDAFunctions.cuh:82-98)
 __device__ __forceinline__ float tol_surf_scale(const TolPair& t, const KernelConsts& k)
 {
-#pragma clang fp contract(fast)
     const float x = t.r;
     const float c3 = cube(k.R - x) * cube(x);
-    const float poly = (2.0f * x <= k.R) ? (2.0f * c3 - k.stC) : c3;
+    const float poly = (2.0f * x <= k.R) ? fmaf(2.0f, c3, -k.stC) : c3;
     const float s = -k.stScale * __builtin_amdgcn_rcpf(fmaxf(x, kEps)) * poly;
     return (x < kEps) ? 0.0f : s;
 }
+// a + d * s per component, and the dot products of the pair terms, each as the one chain of fused multiply-adds written here
+__device__ __forceinline__ float3 tol_axpy(const float3 a, const float3 d, const float s) { return v3(fmaf(d.x, s, a.x), fmaf(d.y, s, a.y), fmaf(d.z, s, a.z)); }
+__device__ __forceinline__ float tol_dot(const float ax, const float ay, const float az, const float3 b) { return fmaf(az, b.z, fmaf(ay, b.y, ax * b.x)); }
 
 // x^7 of the Tait equation of state (BasicSPHSolver.cu:108): fp64 multiply chain, one rounding
 __device__ __forceinline__ float pow7(float x)

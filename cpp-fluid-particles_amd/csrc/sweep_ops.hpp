@@ -221,20 +221,19 @@ struct OpFluidProps {
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
             if (VISC && !isB) {
                 const float s = mj * __builtin_amdgcn_rcpf(o.rho0) * tol_viscLap(t, o.c.k);
-                a = v3(a.x + (vj.x - vi.x) * s, a.y + (vj.y - vi.y) * s, a.z + (vj.z - vi.z) * s);
+                a = tol_axpy(a, v3(vj.x - vi.x, vj.y - vi.y, vj.z - vi.z), s);
             }
             if (COLOR || DENS) {
                 const float w = tol_W(t, o.c.k);
-                if (DENS) den += mj * w;
+                if (DENS) den = fmaf(mj, w, den);
                 if (COLOR) {
                     const float vol = mj * __builtin_amdgcn_rcpf(isB ? o.rhoB : o.rho0);
                     const float s = vol * tol_gradW_scale(t, o.c.k);
-                    cg = v3(cg.x + d.x * s, cg.y + d.y * s, cg.z + d.z * s);
-                    cden += vol * w;
+                    cg = tol_axpy(cg, d, s);
+                    cden = fmaf(vol, w, cden);
                 }
             }
         }
@@ -326,12 +325,11 @@ struct OpSurface {
         }
         __device__ __forceinline__ void pair_tol(Field cg4, bool, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
             const float m2 = mj * __builtin_amdgcn_rcpf(o.rho0 * o.rho0);
-            const float s = 0.25f * m2 * o.tension * (dii + cg4.x * cg4.x + cg4.y * cg4.y + cg4.z * cg4.z) * tol_surf_scale(t, o.c.k) +
-                            o.airPressure * m2 * tol_gradW_scale(t, o.c.k) * li * __builtin_amdgcn_rcpf(ml);
-            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+            const float air = o.airPressure * m2 * tol_gradW_scale(t, o.c.k) * li * __builtin_amdgcn_rcpf(ml);
+            const float s = fmaf(0.25f * m2 * o.tension * (dii + tol_dot(cg4.x, cg4.y, cg4.z, v3(cg4.x, cg4.y, cg4.z))), tol_surf_scale(t, o.c.k), air);
+            a = tol_axpy(a, d, s);
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
@@ -388,17 +386,16 @@ struct OpSurfaceThen {
         }
         __device__ __forceinline__ void pair_tol(Field f, bool isB, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
             const float g = tol_gradW_scale(t, o.c.k);
             if (!isB) {
                 const float m2 = mj * __builtin_amdgcn_rcpf(o.rho0 * o.rho0);
-                const float s = 0.25f * m2 * o.tension * (dii + f.cg.x * f.cg.x + f.cg.y * f.cg.y + f.cg.z * f.cg.z) * tol_surf_scale(t, o.c.k) +
-                                o.airPressure * m2 * g * li * __builtin_amdgcn_rcpf(ml);
-                a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+                const float air = o.airPressure * m2 * g * li * __builtin_amdgcn_rcpf(ml);
+                const float s = fmaf(0.25f * m2 * o.tension * (dii + tol_dot(f.cg.x, f.cg.y, f.cg.z, v3(f.cg.x, f.cg.y, f.cg.z))), tol_surf_scale(t, o.c.k), air);
+                a = tol_axpy(a, d, s);
             }
             const float sb = (NEXT == 1 ? mj : -mj) * (si + f.s) * g;
-            b = v3(b.x + d.x * sb, b.y + d.y * sb, b.z + d.z * sb);
+            b = tol_axpy(b, d, sb);
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
         {
@@ -451,9 +448,8 @@ struct OpPressureForce {
         }
         __device__ __forceinline__ void pair_tol(Field ptj, bool, float3 d, float r2, float mj)      // rows never hold the particle itself
         {
-#pragma clang fp contract(fast)
             const float s = -mj * (pti + ptj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
-            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+            a = tol_axpy(a, d, s);
         }
         static constexpr bool kPair2 = true;      // (rows never hold the particle itself, so no j == i test)
         __device__ __forceinline__ void pair2(Body& A, Body& B, Field ta, Field tb, bool, bool, float3 pi, float4 pa, float4 pb) const
@@ -535,14 +531,13 @@ struct OpDfsphHeadT {
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
-            den += mj * tol_W(t, o.c.k);
+            den = fmaf(mj, tol_W(t, o.c.k), den);
             const float g = tol_gradW_scale(t, o.c.k), s = mj * g;
             const float3 gr = v3(d.x * s, d.y * s, d.z * s);
             gs = v3(gs.x + gr.x, gs.y + gr.y, gs.z + gr.z);
-            if (!isB) sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
-            if (withRate) e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
+            if (!isB) sl += tol_dot(gr.x, gr.y, gr.z, gr);
+            if (withRate) e = fmaf(s, tol_dot(vix - vj.x, viy - vj.y, viz - vj.z, d), e);
         }
         static constexpr bool kPair2 = true;
         __device__ __forceinline__ void pair2(Body& A, Body& B, Field va, Field vb, bool isBa, bool isBb, float3 pi, float4 pa, float4 pb) const
@@ -664,9 +659,8 @@ struct OpRate {
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const float s = mj * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
-            e += s * ((vix - vj.x) * d.x + (viy - vj.y) * d.y + (viz - vj.z) * d.z);
+            e = fmaf(s, tol_dot(vix - vj.x, viy - vj.y, viz - vj.z, d), e);
         }
         static constexpr bool kPair2 = true;
         __device__ __forceinline__ void pair2(Body& A, Body& B, Field va, Field vb, bool, bool, float3 pi, float4 pa, float4 pb) const
@@ -795,9 +789,8 @@ struct OpCorrect {
         }
         __device__ __forceinline__ void pair_tol(Field kj, bool, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const float s = mj * (ki + kj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
-            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+            a = tol_axpy(a, d, s);
         }
         static constexpr bool kPair2 = true;
         __device__ __forceinline__ void pair2(Body& A, Body& B, Field ka, Field kb, bool, bool, float3 pi, float4 pa, float4 pb) const
@@ -1004,14 +997,13 @@ struct OpLambda {
         }
         __device__ __forceinline__ void pair_tol(Field, bool, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
-            den += mj * tol_W(t, o.c.k);
+            den = fmaf(mj, tol_W(t, o.c.k), den);
             float s = -mj * tol_gradW_scale(t, o.c.k);
             if (o.rb != 1.0f) s = s / o.rb;
             const float3 gr = v3(d.x * s, d.y * s, d.z * s);
             gs = v3(gs.x - gr.x, gs.y - gr.y, gs.z - gr.z);
-            sl += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
+            sl += tol_dot(gr.x, gr.y, gr.z, gr);
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)
         {
@@ -1050,9 +1042,8 @@ struct OpDeltaPos {
         }
         __device__ __forceinline__ void pair_tol(Field lj, bool, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const float s = mj * (li + lj) * tol_gradW_scale(tol_pair(r2, o.c.k), o.c.k);
-            a = v3(a.x + d.x * s, a.y + d.y * s, a.z + d.z * s);
+            a = tol_axpy(a, d, s);
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f) { f(a.x, other.a.x); f(a.y, other.a.y); f(a.z, other.a.z); }
     };
@@ -1094,15 +1085,14 @@ struct OpXsph {
         }
         __device__ __forceinline__ void pair_tol(Field vj, bool isB, float3 d, float r2, float mj)
         {
-#pragma clang fp contract(fast)
             const TolPair t = tol_pair(r2, o.c.k);
             const float w = tol_W(t, o.c.k);
-            if (!isB) { const float s = mj * w; a = v3(a.x + (vj.x - vi.x) * s, a.y + (vj.y - vi.y) * s, a.z + (vj.z - vi.z) * s); }
+            if (!isB) a = tol_axpy(a, v3(vj.x - vi.x, vj.y - vi.y, vj.z - vi.z), mj * w);
             if (COLOR) {
                 const float vol = mj * __builtin_amdgcn_rcpf(isB ? o.rhoB : o.rho0);
                 const float s = vol * tol_gradW_scale(t, o.c.k);
-                cg = v3(cg.x + d.x * s, cg.y + d.y * s, cg.z + d.z * s);
-                cden += vol * w;
+                cg = tol_axpy(cg, d, s);
+                cden = fmaf(vol, w, cden);
             }
         }
         template <class F> __device__ __forceinline__ void each_acc(Body& other, F f)

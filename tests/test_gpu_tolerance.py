@@ -393,8 +393,9 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
     meet the boundary particles after ~4 steps: boundary terms, the near-boundary (absolute-displacement) criterion of the persistent
     rows, tiles and the (y-chunk, x) schedule all active at 10 M.  Tolerance and persistent engines against the STRICT engine (oracle-
     identical wherever the oracle reaches, incl. post-impact states at 1-3 M: test_gpu_violent.py): ids, cell indices and the cell table
-    equal, positions and densities within 1e-5 ELEMENT BY ELEMENT (relative to max(|value|, 1 % of the field scale)) for 8 steps, and
-    inside 4x the envelope of a strict engine started one ulp away at step 12."""
+    equal, positions within 1e-5 of the domain size, and positions and densities ELEMENT BY ELEMENT (relative to max(|value|, 1 % of the
+    field scale)) within 1e-5 or inside 4x the envelope of a strict engine started one ulp away (the surface layer of the block, where
+    the colour-gradient terms divide by small numbers, passes 1e-5 elementwise after a few steps under ANY perturbation), 12 steps."""
     P, fluid, boundary = sphx.scene(190)
     P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
     pos = fluid.copy()
@@ -420,17 +421,18 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
         ref = {f: runs[0].get(getattr(sphx, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F", "F_POS", "F_DENSITY")}
         ids_c = runs["control"].get(sphx.F_ID)
         same_order = np.array_equal(ids_c, ref["F_ID"])
-        env_p = elem(runs["control"].get(sphx.F_POS), ref["F_POS"], P.space[0])[0] if same_order else 1.0
-        env_r = elem(runs["control"].get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)[0] if same_order else 1.0
+        env_p = elem(runs["control"].get(sphx.F_POS), ref["F_POS"], P.space[0]) if same_order else (1.0, 1.0)
+        env_r = elem(runs["control"].get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0) if same_order else (1.0, 1.0)
         for mode in (1, 2):
             g = runs[mode]
             for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
                 assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, batch, f)
             dp = elem(g.get(sphx.F_POS), ref["F_POS"], P.space[0]); dr = elem(g.get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
-            if batch < 2:
-                assert max(dp) <= TOL and max(dr) <= TOL, (mode, batch, dp, dr)
-            else:
-                assert dp[0] <= max(TOL, 4.0 * env_p) and dr[0] <= max(TOL, 4.0 * env_r), (mode, batch, dp, dr, env_p, env_r)
+            print("step %d arith %d: pos %.2e / elementwise %.2e, density %.2e / %.2e; one-ulp control: pos %.2e / %.2e, density %.2e / %.2e" % (
+                4 * batch + 4, mode, dp[0], dp[1], dr[0], dr[1], env_p[0], env_p[1], env_r[0], env_r[1]))
+            assert dp[0] <= TOL, (mode, batch, dp)                      # positions against the domain size: the contract's statement
+            for k in (0, 1):                                            # ... element by element and the densities: 1e-5, or the envelope
+                assert dp[k] <= max(TOL, 4.0 * env_p[k]) and dr[k] <= max(TOL, 4.0 * env_r[k]), (mode, batch, dp, dr, env_p, env_r)
     assert float(runs[0].get(sphx.F_POS)[:, 1].min()) < 0.03, "the block's bottom layers must be inside the support (0.04) of the floor's boundary particles"
     in_use, builds, steps = runs[2].persistent_stats()
     assert in_use and steps == 12 and builds >= 2, (in_use, builds, steps)
