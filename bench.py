@@ -360,9 +360,9 @@ def main():
             tot_ms, launches = spans[span]
             avg_ms = tot_ms / launches
             achieved = RATE_KERNEL_BYTES_PER_PARTICLE * n / (avg_ms * 1e-3) / 1e9
-            # counters of THAT instantiation (profiles/traffic.json): strict quad walk "", the strict walk serving a tolerance step "_tolplain",
-            # the tolerance walk (with the skin re-test when rows persist) "_tol"; None unless measured on exactly this source tree
-            pmc = read_traffic("%s_nx%d%s" % (solver, args.nx, {1: "", 3: "_tolplain", 2: "_tol"}.get(variant, "_other")))
+            # counters of the dominant kernel AS THIS LEG RUNS IT (profiles/traffic.json, one entry per arithmetic contract, collected by
+            # tools/collect_round.sh with the same bench arguments); None unless measured on exactly this source tree
+            pmc = read_traffic("%s_nx%d_%s" % (solver, args.nx, arith))
             flops = RATE_KERNEL_FLOP_PER_PAIR * nb["pairs"] / (avg_ms * 1e-3) / 1e12
             leg["roofline"] = {"bound": "hbm", "kernel": "%s (span '%s')" % (kernel_name, span),
                                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -122,7 +122,8 @@ struct SweepCache {
     int rangeOrderMin = 3000000;            // particles a range must hold to keep the tile schedule (SPHX_RANGE_ORDER_MIN; tests lower it)
     int rangeLo2 = -1, rangeHi2 = -1;       // a second range behind the first, swept by the SAME launches (the two edge layers of a slab)
     bool keepErrorAccum = false;             // a later part of a split error stage adds to the running |error| total
-    bool strictRateInTol = true;             // tolerance mode, >= 4 M particles: rate sweeps on the strict quad kernel (SweepCache::ctx)
+    bool strictRateInTol = false;            // tolerance mode, >= 4 M particles: rate sweeps on the strict quad kernel (SweepCache::ctx); r05: off,
+                                             // the tolerance walk with written-out FMAs fits 8 waves per SIMD too and wins (12.13 vs 12.32 ms per step)
     const int* gate = nullptr;               // device word that switches the following sweeps off (SweepCtx::gate)
     const int* advectSkipIf = nullptr;       // device word that, when raised, keeps the advect pass from moving anything (DFSPH loop-tail fault)
     // Skin rows (PBD, whole-domain systems): ONE row build per step with the cutoff enlarged by `skin`; sweeps

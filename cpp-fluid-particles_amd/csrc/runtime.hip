@@ -665,11 +665,10 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.buildCut = k.tCut;
     if ((skinRows || persistRows) && skin > 0.0f) { const float rc = sqrtf(k.tCut) + skin; c.buildCut = rc * rc; }
     c.gate = gate;
-    // From 4 M particles on the rate sweeps of a tolerance-mode step take the STRICT quad kernel (bit-exact results are inside any
-    // tolerance): it is cut for 8 waves per SIMD where the tolerance walk needs 6, and once the sweep waits for the vector memory
-    // path that occupancy is worth more than the tolerance walk's fewer instructions (r04, 10.3 M: 0.787 vs 0.840 ms per launch;
-    // at 1 M the tolerance kernel wins, 0.053 vs 0.071 ms).  Not with persistent rows: their strict walk would re-derive the
-    // plain-operator predicate per pair.
+    // (r04: from 4 M particles on the rate sweeps of a tolerance-mode step took the STRICT quad kernel -- cut for 8 waves per SIMD where
+    // the tolerance walk needed 6: 0.787 vs 0.840 ms per launch at 10.3 M.  r05: with its fused multiply-adds written out the tolerance
+    // walk needs 64 VGPRs, runs at 8 waves too and wins, 12.13 vs 12.32 ms per step; sphx_tuning.tol_strict_rate = 1 restores the r04
+    // choice for measurements.  Never with persistent rows: their strict walk would re-derive the plain-operator predicate per pair.)
     c.plainBits = (tolerance && !(persistRows && skin > 0.0f) && !(skinRows && skin > 0.0f) && n >= 4000000 && strictRateInTol) ? 1 : 0;
     c.persist = (persistRows && skin > 0.0f && use && rowCell) ? 1 : 0;
     if (c.persist) { c.rowCell = rowCell->addr(); c.tileFmt = nullptr; }

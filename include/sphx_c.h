@@ -125,7 +125,7 @@ typedef struct sphx_tuning {
     int   quad_mask;          /* strict arithmetic: sweeps that walk rows quad-per-particle (-1: the rate sweeps) */
     int   duo_mask;           /* ... with two lanes per particle (-1: head and viscosity+colour from 4 M particles on) */
     int   quad_mask_tol;      /* tolerance arithmetic: quad walks (-1: 15, of which the corrections only from 4 M particles on) */
-    int   tol_strict_rate;    /* tolerance arithmetic, >= 4 M particles: rate sweeps on the strict quad kernel (-1: yes) */
+    int   tol_strict_rate;    /* tolerance arithmetic, >= 4 M particles: rate sweeps on the strict quad kernel (-1: no since r05) */
     int   brick;              /* 1: the opt-in compact-brick LDS stage of tolerance arithmetic (measured slower; 0) */
     int   brick_min;          /* particles from which the brick stage is used (0: 2,000,000) */
     int   range_order;        /* range-restricted launches of wide slabs keep the (y-chunk, x) tile schedule (-1: yes) */

@@ -175,9 +175,10 @@ def test_bench_refuses_cpu_and_checks_traffic_provenance(tmp_path, monkeypatch):
     h = engine_source_hash()
     assert len(h) == 16 and h == engine_source_hash()
     table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert set(table) <= {"dfsph_nx190", "dfsph_nx190_tol"} and "dfsph_nx190" in table      # the strict and the tolerance kernel of the headline
-    entry = table["dfsph_nx190"]
-    got = bench.read_traffic("dfsph_nx190")
+    # one entry per arithmetic contract of the headline workload (r05: keyed by the leg that launched the kernel, not by a guess of its instantiation)
+    assert set(table) <= {"dfsph_nx190_strict", "dfsph_nx190_tolerance", "dfsph_nx190_persistent"} and "dfsph_nx190_strict" in table
+    entry = table["dfsph_nx190_strict"]
+    got = bench.read_traffic("dfsph_nx190_strict")
     if entry["source_hash"] == h:
         assert got["hbm_bytes_per_launch"] == entry["hbm_bytes_per_launch"] and got["hbm_bytes_per_launch"] > 4.5e8   # more than the algorithmic 0.45 GB
         assert "valu_issue_frac" in got and (got["valu_issue_frac"] is None or 0.0 < got["valu_issue_frac"] <= 1.05), "calibrated, never clipped"

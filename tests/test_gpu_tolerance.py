@@ -418,16 +418,17 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
     for batch in range(3):
         for g in runs.values():
             g.step_n(4)
-        ref = {f: runs[0].get(getattr(sphx, f)) for f in ("F_ID", "F_CELL", "F_CELLSTART_F", "F_POS", "F_DENSITY")}
-        ids_c = runs["control"].get(sphx.F_ID)
-        same_order = np.array_equal(ids_c, ref["F_ID"])
-        env_p = elem(runs["control"].get(sphx.F_POS), ref["F_POS"], P.space[0]) if same_order else (1.0, 1.0)
-        env_r = elem(runs["control"].get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0) if same_order else (1.0, 1.0)
+        # (matched by particle id: once the runs differ by an ulp, a particle next to a cell face crosses it a step earlier in one run than
+        # in the other, and the sort orders part -- the integer fields are compared while they can be equal, the first batch)
+        ref = {f: by_particle(sphx, runs[0], getattr(sphx, f)) for f in ("F_POS", "F_DENSITY")}
+        env_p = elem(by_particle(sphx, runs["control"], sphx.F_POS), ref["F_POS"], P.space[0])
+        env_r = elem(by_particle(sphx, runs["control"], sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
         for mode in (1, 2):
             g = runs[mode]
-            for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
-                assert np.array_equal(g.get(getattr(sphx, f)), ref[f]), (mode, batch, f)
-            dp = elem(g.get(sphx.F_POS), ref["F_POS"], P.space[0]); dr = elem(g.get(sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
+            if batch == 0:
+                for f in ("F_ID", "F_CELL", "F_CELLSTART_F"):
+                    assert np.array_equal(g.get(getattr(sphx, f)), runs[0].get(getattr(sphx, f))), (mode, batch, f)
+            dp = elem(by_particle(sphx, g, sphx.F_POS), ref["F_POS"], P.space[0]); dr = elem(by_particle(sphx, g, sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
             print("step %d arith %d: pos %.2e / elementwise %.2e, density %.2e / %.2e; one-ulp control: pos %.2e / %.2e, density %.2e / %.2e" % (
                 4 * batch + 4, mode, dp[0], dp[1], dr[0], dr[1], env_p[0], env_p[1], env_r[0], env_r[1]))
             assert dp[0] <= TOL, (mode, batch, dp)                      # positions against the domain size: the contract's statement

@@ -1,5 +1,5 @@
 """profiles/traffic.json from the counter passes of tools/profile_gpu.sh (gpurun_out/traffic_<tag>.json).
-   python tools/make_traffic_json.py r02 dfsph_nx190"""
+   python tools/make_traffic_json.py r05persistent dfsph_nx190_persistent"""
 import json
 import os
 import sys
@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, key = sys.argv[1], sys.argv[2]
 src = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % tag)))["k_rate_density"]
 entry = {
-    "kernel": "k_rate_quad<true,2,%d> (computeDensityError_CUDA, quad-per-particle walk, %s arithmetic), one launch at 10,288,500 particles"
-              % ((1, "tolerance") if key.endswith("_tol") else (0, "strict")),
+    "kernel": "the density-error sweep k_rate_quad<true, 2, *> (computeDensityError_CUDA, quad-per-particle walk) as the %s leg of bench.py launches it, "
+              "one launch at 10,288,500 particles" % key.rsplit("_", 1)[-1],
     "hbm_bytes_per_launch": src["hbm_bytes_fetch_x2"],
     "fetch_size_raw_bytes": src["FETCH_SIZE"], "write_size_bytes": src["WRITE_SIZE"],
     "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: gfx950 reports half of the fetched bytes; calibrated for THIS path's "
@@ -27,7 +27,7 @@ entry = {
     "avg_launch_us_rocprof": src.get("avg_launch_us_rocprof"),
     "source_hash": src["source_hash"],
     "source": "profiles/%s_rocprofv3_dfsph10m_%s_summary.txt (tools/profile_gpu.sh %s --arith %s)"
-              % (tag.replace("strict", ""), "strict" if tag.endswith("strict") else "headline", tag, "strict" if tag.endswith("strict") else "persistent"),
+              % (tag[:3], key.rsplit("_", 1)[-1], tag, key.rsplit("_", 1)[-1]),
 }
 path = os.path.join(ROOT, "profiles", "traffic.json")
 try:
