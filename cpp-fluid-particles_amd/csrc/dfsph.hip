@@ -62,6 +62,22 @@ __global__ void __launch_bounds__(kErrorSlots) k_loop_decide(int* __restrict__ s
 }
 }  // namespace
 
+namespace {
+__global__ void k_set_posf_w(float4* __restrict__ posf, const float* __restrict__ src, int lo, int hi)
+{
+    const int i = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < hi) posf[i].w = src[i];
+}
+}  // namespace
+
+void DFSPHSolver::packWarmIntoPosf(int lo, int hi)
+{
+    SweepCache& c = cache();
+    lo = std::max(lo, 0); hi = std::min(hi, c.n);
+    if (hi > lo) k_set_posf_w<<<blocks_for(hi - lo), 256, 0, sphx::stream()>>>(c.posfw(), denWarmStiff.addr(), lo, hi);
+    warmInPosfGhosts = true;
+}
+
 bool DFSPHSolver::deviceLoops() const
 {
     const bool hostLoop = tuning().dfsph_host_loop != 0;
@@ -418,6 +434,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     const int num = (int)fluids->size();
     const bool surface = surfaceTensionIntensity > EPSILON || airPressure > EPSILON;
     if (phase == SPHX_PH_SEARCH) {
+        warmInPosfAll = warmInPosfGhosts = false;
         invalidatePositions();
         c.setup(cellSize, cellLength, radius);
         c.packFluid(*fluids);
@@ -466,9 +483,11 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
     case SPHX_PH_VISC_COLOR: {
         if (surface) {
             ScopedKernel t("visc_color");
-            // whole-domain systems: the warm stiffness rides in posf.w for the fused surface + warm-start sweep that follows
+            // the warm stiffness rides in posf.w for the fused surface + warm-start sweep that follows (slab drivers, which sweep their
+            // owned particles only, add the ghosts' with packWarmIntoPosf)
             launch_op(OpFluidProps<true, true, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), cg.addr(), nullptr, nullptr,
-                                                      nullptr, rho0, rhoB, visc, dt, 0.0f, c.isSlab ? nullptr : denWarmStiff.addr()}, num);
+                                                      nullptr, rho0, rhoB, visc, dt, 0.0f, denWarmStiff.addr()}, num);
+            if (c.rangeLo < 0) warmInPosfAll = true;
         } else {
             ScopedKernel t("viscosity");
             launch_op(OpFluidProps<true, false, false>{ctx, fluids->getVelPtr(), c.aux3.addr(), nullptr, nullptr, nullptr,
@@ -496,7 +515,7 @@ void DFSPHSolver::runPhase(int phase, std::shared_ptr<SPHParticles>& fluids, con
         if (!surface) throw "DFSPHSolver::runPhase: the fused surface stage needs surface effects enabled";
         ScopedKernel t("surface_warm_correct");
         launch_op(OpSurfaceThen<1>{ctx, cg.addr(), fluids->getVelPtr(), c.aux3.addr(), fluids->getVelPtr(), denWarmStiff.addr(), rho0,
-                                   surfaceTensionIntensity, airPressure, dt, !c.isSlab}, num);
+                                   surfaceTensionIntensity, airPressure, dt, !c.isSlab || warmInPosfAll || warmInPosfGhosts}, num);
         break;
     }
     case SPHX_PH_WARM_CORRECT: {

@@ -732,6 +732,9 @@ struct sphx_slab_group {
         if (!kickFused) runAll(SPHX_PH_FORCE);
         sweepStage(SPHX_PH_VISC_COLOR, surface ? std::vector<int>{SPHX_F_CG4} : std::vector<int>{});
         if (surface) {
+            // (the fused sweep takes the neighbour's warm-start stiffness from posf.w, the record it gathers anyway: VISC_COLOR left it
+            // there for the owned particles, the ghosts' -- known locally since the exchange -- are written here)
+            for (auto& sp : slabs) { sp->sys->dfsph->packWarmIntoPosf(0, sp->o0); sp->sys->dfsph->packWarmIntoPosf(sp->o1, sp->held); }
             sweepStage(SPHX_PH_SURFACE_WARM, {SPHX_F_VEL4});      // one row walk for both, one halo instead of two
         } else {
             sweepStage(SPHX_PH_SURFACE, {SPHX_F_VEL4});

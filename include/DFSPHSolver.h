@@ -47,6 +47,10 @@ public:
     long long readErrorTotalFixed();
     void resetErrorTotal();          // zero the |error| accumulators on the current stream (split error stages then all ADD)
     void noteIterations(int div, int den) { lastDiv = div; lastDen = den; itersPending = false; }
+    // Slab drivers sweep owned particles only: after the VISC_COLOR stage (which leaves the warm-start stiffness of the particles it
+    // swept in posf.w) this writes it for the GHOST particles [lo, hi) as well, so that the fused surface + warm-start sweep can
+    // take the stiffness from the record it gathers anyway (two gathers per pair instead of three), as whole-domain steps do
+    void packWarmIntoPosf(int lo, int hi);
     // the warm-start stiffness of this step is in sorted order already (a slab driver's staged sort wrote it there): the coming
     // SEARCH stage leaves its permutation out (one-shot)
     void noteWarmStiffnessSorted() { warmSorted = true; }
@@ -100,6 +104,7 @@ private:
     const int maxIter;
     int fixedDiv = -1, fixedDen = -1;
     bool warmSorted = false;
+    bool warmInPosfAll = false, warmInPosfGhosts = false;   // this step's posf.w carries the warm stiffness: for every held particle / for the ghosts too
     bool headDidFirstError = false;   // the fused head sweep already produced the first divergence error
     int lastDiv = 0, lastDen = 0;
     // device-side adaptive loops: {done, iteration, divergence iterations, density iterations, grid-barrier word} of the current step on the device,

@@ -393,9 +393,10 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
     meet the boundary particles after ~4 steps: boundary terms, the near-boundary (absolute-displacement) criterion of the persistent
     rows, tiles and the (y-chunk, x) schedule all active at 10 M.  Tolerance and persistent engines against the STRICT engine (oracle-
     identical wherever the oracle reaches, incl. post-impact states at 1-3 M: test_gpu_violent.py): ids, cell indices and the cell table
-    equal, positions within 1e-5 of the domain size, and positions and densities ELEMENT BY ELEMENT (relative to max(|value|, 1 % of the
-    field scale)) within 1e-5 or inside 4x the envelope of a strict engine started one ulp away (the surface layer of the block, where
-    the colour-gradient terms divide by small numbers, passes 1e-5 elementwise after a few steps under ANY perturbation), 12 steps."""
+    equal and positions within 1e-5 of the domain size at step 4; positions and densities ELEMENT BY ELEMENT (relative to max(|value|,
+    1 % of the field scale)) within 1e-5 or inside 4x the envelope of a strict engine started one ulp away, through step 12 (this impact
+    amplifies a one-ulp perturbation to 14 % in density within four steps of contact: no arithmetic holds 1e-5 there, the comparative
+    statement is the one that can be made -- and the tolerance engines stay BELOW the one-ulp control)."""
     P, fluid, boundary = sphx.scene(190)
     P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 4
     pos = fluid.copy()
@@ -431,8 +432,11 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
             dp = elem(by_particle(sphx, g, sphx.F_POS), ref["F_POS"], P.space[0]); dr = elem(by_particle(sphx, g, sphx.F_DENSITY), ref["F_DENSITY"], P.rho0)
             print("step %d arith %d: pos %.2e / elementwise %.2e, density %.2e / %.2e; one-ulp control: pos %.2e / %.2e, density %.2e / %.2e" % (
                 4 * batch + 4, mode, dp[0], dp[1], dr[0], dr[1], env_p[0], env_p[1], env_r[0], env_r[1]))
-            assert dp[0] <= TOL, (mode, batch, dp)                      # positions against the domain size: the contract's statement
-            for k in (0, 1):                                            # ... element by element and the densities: 1e-5, or the envelope
+            if batch == 0:
+                assert dp[0] <= TOL, (mode, batch, dp)                  # positions against the domain size while the statement can hold
+            # (measured, r05: four steps after the bottom layers enter the floor's support a ONE-ULP perturbation of the strict engine has
+            # grown to 3e-4 of the domain in position and 14 % in density -- the tolerance engines to 1.6e-4 and 12 %)
+            for k in (0, 1):                                            # element by element and the densities: 1e-5, or the envelope
                 assert dp[k] <= max(TOL, 4.0 * env_p[k]) and dr[k] <= max(TOL, 4.0 * env_r[k]), (mode, batch, dp, dr, env_p, env_r)
     assert float(runs[0].get(sphx.F_POS)[:, 1].min()) < 0.03, "the block's bottom layers must be inside the support (0.04) of the floor's boundary particles"
     in_use, builds, steps = runs[2].persistent_stats()
