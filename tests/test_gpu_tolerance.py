@@ -390,7 +390,7 @@ def test_tolerance_engines_at_headline_size_against_the_strict_engine(sphx):
 def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
     """the headline arithmetic at the headline SIZE outside free fall.  The 10,288,500-particle block is started 0.05
     above the floor moving down at 1.5 m/s (positions and velocities through the C ABI, no constructor step), so that its bottom layers
-    meet the boundary particles after ~4 steps: boundary terms, the near-boundary (absolute-displacement) criterion of the persistent
+    meet the floor's boundary particles within the first steps: boundary terms, the near-boundary (absolute-displacement) criterion of the persistent
     rows, tiles and the (y-chunk, x) schedule all active at 10 M.  Tolerance and persistent engines against the STRICT engine (oracle-
     identical wherever the oracle reaches, incl. post-impact states at 1-3 M: test_gpu_violent.py): ids, cell indices and the cell table
     equal and positions within 1e-5 of the domain size at step 4; positions and densities ELEMENT BY ELEMENT (relative to max(|value|,
@@ -438,7 +438,8 @@ def test_tolerance_engines_at_headline_size_through_first_wall_contact(sphx):
             # grown to 3e-4 of the domain in position and 14 % in density -- the tolerance engines to 1.6e-4 and 12 %)
             for k in (0, 1):                                            # element by element and the densities: 1e-5, or the envelope
                 assert dp[k] <= max(TOL, 4.0 * env_p[k]) and dr[k] <= max(TOL, 4.0 * env_r[k]), (mode, batch, dp, dr, env_p, env_r)
-    assert float(runs[0].get(sphx.F_POS)[:, 1].min()) < 0.03, "the block's bottom layers must be inside the support (0.04) of the floor's boundary particles"
+    # the floor has acted: free fall alone would leave every particle at -1.5 - 9.8 t (the bottom layers were stopped and thrown back)
+    assert float(runs[0].get(sphx.F_VEL)[:, 1].max()) > -1.0, "the block's bottom layers must have met the floor's boundary particles"
     in_use, builds, steps = runs[2].persistent_stats()
     assert in_use and steps == 12 and builds >= 2, (in_use, builds, steps)
     for g in runs.values():
