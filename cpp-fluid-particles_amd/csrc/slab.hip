@@ -251,25 +251,52 @@ struct RcclTransport final : Transport {
 };
 
 // ================================================================================ device helpers
-// classification of the owned particles after last step's advect: global cell column by the engine's own
-// expression (true fp32 division, truncation: cell_of), which neighbour needs a copy, and a sanity flag
-__global__ void k_slab_classify(const float3* __restrict__ pos, int m, float cellLength, int x0, int x1, int g, int hasLeft,
-                                int hasRight, int slackL, int slackR, int* __restrict__ flagL, int* __restrict__ flagR,
-                                int* __restrict__ flagK, int* __restrict__ scanL, int* __restrict__ scanR, int* __restrict__ scanK,
-                                int* __restrict__ violation)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const int col = (int)(pos[k].x / cellLength);
-    const int fl = (hasLeft && col <= x0 + g - 1) ? 1 : 0;
-    const int fr = (hasRight && col >= x1 - g) ? 1 : 0;
+// Classification of the owned particles after last step's advect: global cell column by the engine's own expression (true fp32
+// division, truncation: cell_of), which neighbour needs a copy, whether the particle stays in this slab's ghost range, and a sanity flag.
+// r05: the three stable compactions (to the left neighbour / to the right neighbour / kept) no longer go through per-particle flag
+// and scan arrays (24 bytes written, 48 scanned, 24 read back per particle): a counting pass leaves three counts per BLOCK of 256
+// particles, the scan runs over those, and the packing pass recomputes the flags and ranks them inside the block with ballots.
+struct SlabClass {
+    float cellLength; int x0, x1, g, hasLeft, hasRight, slackL, slackR;
+    __device__ __forceinline__ int column(const float3 p) const { return (int)(p.x / cellLength); }
+    __device__ __forceinline__ int left(int col) const { return (hasLeft && col <= x0 + g - 1) ? 1 : 0; }
+    __device__ __forceinline__ int right(int col) const { return (hasRight && col >= x1 - g) ? 1 : 0; }
     // still inside this slab's ghost range?  (after a cut moved, a former owner may hold particles two columns out:
     // they travel to the neighbour like every migrant and are dropped here)
-    const int fk = (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0;
-    flagL[k] = fl; flagR[k] = fr; flagK[k] = fk;
-    scanL[k] = fl; scanR[k] = fr; scanK[k] = fk;            // scanned in place next (device_exclusive_scan3)
+    __device__ __forceinline__ int kept(int col) const { return (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0; }
     // moved more than one column in one step (a cut that itself moved this step widens the allowance by its shift)
-    if (col < x0 - 1 - slackL || col > x1 + slackR) *violation = 1;
+    __device__ __forceinline__ bool crossed(int col) const { return col < x0 - 1 - slackL || col > x1 + slackR; }
+};
+constexpr int kSlabBlock = 256;
+// exclusive rank of this thread among the threads of its block with flag set, and the block's total (all threads call it; the
+// three calls of a kernel use the table rows 0, 1, 2, so no call waits for the readers of the one before)
+__device__ __forceinline__ int block_rank_256(int flag, int row, int* total)
+{
+    __shared__ int waveSums[3][kSlabBlock / 64];
+    static_assert(kSlabBlock == 256, "four waves");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votes = __ballot(flag != 0);
+    const int inWave = __popcll(votes & ((1ull << lane) - 1ull));
+    if (lane == 0) waveSums[row][wave] = __popcll(votes);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += waveSums[row][w];
+    *total = waveSums[row][0] + waveSums[row][1] + waveSums[row][2] + waveSums[row][3];
+    return base + inWave;
+}
+__global__ void __launch_bounds__(kSlabBlock) k_slab_count(const float3* __restrict__ pos, int m, SlabClass c, int* __restrict__ blockL,
+                                                           int* __restrict__ blockR, int* __restrict__ blockK, int* __restrict__ violation)
+{
+    const int k = blockIdx.x * kSlabBlock + threadIdx.x;
+    int fl = 0, fr = 0, fk = 0;
+    if (k < m) {
+        const int col = c.column(pos[k]);
+        fl = c.left(col); fr = c.right(col); fk = c.kept(col);
+        if (c.crossed(col)) *violation = 1;
+    }
+    int tl, tr, tk;
+    (void)block_rank_256(fl, 0, &tl); (void)block_rank_256(fr, 1, &tr); (void)block_rank_256(fk, 2, &tk);
+    if (threadIdx.x == 0) { blockL[blockIdx.x] = tl; blockR[blockIdx.x] = tr; blockK[blockIdx.x] = tk; }
 }
 
 // the size words of a step before the classification fills in the rest: everything zero, {0, owned, width} for both neighbours
@@ -294,24 +321,33 @@ __global__ void k_slab_verdict(const long long* __restrict__ counts, const int* 
 }
 
 // payload row of a particle: pos(3) vel(3) id(1, bit pattern) extras(E).  `own` receives the owned particles still in
-// this slab's range, sendL / sendR the copies for the neighbours: three stable compactions (scan* = exclusive scans of the flags)
-__global__ void k_slab_pack(const float3* __restrict__ pos, const float3* __restrict__ vel, const int* __restrict__ ids,
-                            const float* __restrict__ extra, int E, int m, const int* __restrict__ flagL,
-                            const int* __restrict__ flagR, const int* __restrict__ flagK, const int* __restrict__ scanL,
-                            const int* __restrict__ scanR, const int* __restrict__ scanK, float* __restrict__ own,
-                            float* __restrict__ sendL, float* __restrict__ sendR, long long* __restrict__ counts)
+// this slab's range, sendL / sendR the copies for the neighbours: three stable compactions (block offsets = exclusive scans of the
+// block counts of k_slab_count; inside a block the rank among the flagged threads)
+__global__ void __launch_bounds__(kSlabBlock) k_slab_pack(const float3* __restrict__ pos, const float3* __restrict__ vel, const int* __restrict__ ids,
+                                                          const float* __restrict__ extra, int E, int m, SlabClass c, const int* __restrict__ blockL,
+                                                          const int* __restrict__ blockR, const int* __restrict__ blockK, float* __restrict__ own,
+                                                          float* __restrict__ sendL, float* __restrict__ sendR, long long* __restrict__ counts)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
+    const int k = blockIdx.x * kSlabBlock + threadIdx.x;
     const int W = 7 + E;
     float row[10];
-    const float3 p = pos[k], v = vel[k];
-    row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = v.x; row[4] = v.y; row[5] = v.z; row[6] = __int_as_float(ids[k]);
-    for (int e = 0; e < E; ++e) row[7 + e] = extra[(size_t)k * E + e];
-    if (flagK[k]) { float* d = own + (size_t)scanK[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
-    if (flagL[k]) { float* d = sendL + (size_t)scanL[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
-    if (flagR[k]) { float* d = sendR + (size_t)scanR[k] * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
-    if (k == m - 1) { counts[0] = scanL[k] + flagL[k]; counts[3] = scanR[k] + flagR[k]; counts[12] = scanK[k] + flagK[k]; }
+    int fl = 0, fr = 0, fk = 0;
+    if (k < m) {
+        const float3 p = pos[k], v = vel[k];
+        const int col = c.column(p);
+        fl = c.left(col); fr = c.right(col); fk = c.kept(col);
+        row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = v.x; row[4] = v.y; row[5] = v.z; row[6] = __int_as_float(ids[k]);
+        for (int e = 0; e < E; ++e) row[7 + e] = extra[(size_t)k * E + e];
+    }
+    int tl, tr, tk;
+    const int rl = blockL[blockIdx.x] + block_rank_256(fl, 0, &tl), rr = blockR[blockIdx.x] + block_rank_256(fr, 1, &tr),
+              rk = blockK[blockIdx.x] + block_rank_256(fk, 2, &tk);
+    if (fk) { float* d = own + (size_t)rk * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
+    if (fl) { float* d = sendL + (size_t)rl * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
+    if (fr) { float* d = sendR + (size_t)rr * W; for (int t = 0; t < W; ++t) d[t] = row[t]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        counts[0] = blockL[blockIdx.x] + tl; counts[3] = blockR[blockIdx.x] + tr; counts[12] = blockK[blockIdx.x] + tk;
+    }
 }
 
 // new pre-sort arrays = [from left | previously owned | from right]: ascending in last step's global order, which
@@ -363,7 +399,7 @@ struct Slab {
     // engine arrays
     float3 *pos = nullptr, *vel = nullptr; int* ids = nullptr; float* extra = nullptr; float* density = nullptr; int* cellStart = nullptr;
     // scratch
-    DevBuf<int> flagL, flagR, flagK, scanL, scanR, scanK, blockSums, violation, layerOut;
+    DevBuf<int> blockL, blockR, blockK, blockSums, violation, layerOut;      // per block of 256 owned particles: rows for the left / right neighbour / kept
     DevBuf<float> own, sendL, sendR, recvL, recvR;
     // size messages, 3 x int64 each: {payload particles, owned particles, width in columns}
     //   [0..2] to left  [3..5] to right  [6..8] from left  [9..11] from right   [12] owned particles kept here
@@ -497,14 +533,13 @@ struct sphx_slab_group {
             s.sentOwned = m; s.sentWidth = s.x1 - s.x0;
             k_slab_prepare<<<1, 64, 0, st>>>(s.counts.p, s.violation.p, (long long)m, (long long)(s.x1 - s.x0));
             if (m > 0) {
-                k_slab_classify<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, m, s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0,
-                                                                s.hasRight ? 1 : 0, slackL, slackR, s.flagL.p, s.flagR.p, s.flagK.p,
-                                                                s.scanL.p, s.scanR.p, s.scanK.p, s.violation.p);
-                device_exclusive_scan3(s.scanL.p, s.scanR.p, s.scanK.p, m, s.blockSums.p);      // three stable compactions, three launches
-                k_slab_pack<<<blocks_for(m), 256, 0, st>>>(s.pos + s.o0, s.vel + s.o0, s.ids + s.o0,
-                                                            s.extraFloats ? s.extra + (size_t)s.o0 * s.extraFloats : nullptr, s.extraFloats, m,
-                                                            s.flagL.p, s.flagR.p, s.flagK.p, s.scanL.p, s.scanR.p, s.scanK.p, s.own.p, s.sendL.p, s.sendR.p,
-                                                            s.counts.p);
+                const SlabClass cls{s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, slackL, slackR};
+                const int blocks = (m - 1) / kSlabBlock + 1;
+                k_slab_count<<<blocks, kSlabBlock, 0, st>>>(s.pos + s.o0, m, cls, s.blockL.p, s.blockR.p, s.blockK.p, s.violation.p);
+                device_exclusive_scan3(s.blockL.p, s.blockR.p, s.blockK.p, blocks, s.blockSums.p);      // over the BLOCK counts: a few thousand words
+                k_slab_pack<<<blocks, kSlabBlock, 0, st>>>(s.pos + s.o0, s.vel + s.o0, s.ids + s.o0,
+                                                           s.extraFloats ? s.extra + (size_t)s.o0 * s.extraFloats : nullptr, s.extraFloats, m, cls,
+                                                           s.blockL.p, s.blockR.p, s.blockK.p, s.own.p, s.sendL.p, s.sendR.p, s.counts.p);
             }
             // size messages travel first (24 bytes per neighbour)
             if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.counts.p + 0, 24}); recvs.push_back({s.rank - 1, s.rank, s.counts.p + 6, 24}); }
@@ -1033,7 +1068,8 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             if (P.solver == SPHX_PBD) s.extra = reinterpret_cast<float*>(s.sys->pbd->getPosLast().addr());
             // scratch
             const size_t cap = (size_t)s.capacity, W = (size_t)s.width();
-            s.flagL.alloc(cap); s.flagR.alloc(cap); s.flagK.alloc(cap); s.scanL.alloc(cap); s.scanR.alloc(cap); s.scanK.alloc(cap); s.blockSums.alloc(3 * (cap / 2048 + 2));
+            const size_t blocks = cap / kSlabBlock + 2;
+            s.blockL.alloc(blocks); s.blockR.alloc(blocks); s.blockK.alloc(blocks); s.blockSums.alloc(3 * (blocks / 2048 + 2));
             s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(13);
             s.own.alloc(cap * W); s.sendL.alloc(cap * W); s.sendR.alloc(cap * W); s.recvL.alloc(cap * W); s.recvR.alloc(cap * W);
             hip_ok(hipHostMalloc((void**)&s.hCounts, 13 * sizeof(long long), hipHostMallocDefault), "pinned counts");
