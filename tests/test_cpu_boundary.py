@@ -190,3 +190,47 @@ def test_bench_refuses_cpu_and_checks_traffic_provenance(tmp_path, monkeypatch):
     # SURVEY 8d's figures; fixed-count DFSPH leaves out the 44-byte error sweep nobody reads (DFSPHSolver::step)
     assert bench.step_bytes_per_particle("dfsph", 1, 4, 0, fixed=False) == 1000 and bench.step_bytes_per_particle("dfsph", 1, 4, 0) == 956
     assert bench.step_bytes_per_particle("pbd", 0, 0, 4) == 788
+
+
+def test_tuning_block_round_trip_and_validation(sphx):
+    """sphx_tuning (r05: the library's behaviour switches, formerly SPHX_* environment variables): defaults, set / get, refusal of a
+    block built against another layout or with fields out of range, and the translation the test suite itself relies on
+    (tests/tuning_env.py: variables present in the environment -> fields).  Host-only, no GPU."""
+    import ctypes as C
+    import tuning_env
+    d = sphx.default_tuning()
+    assert d.struct_size == C.sizeof(sphx.Tuning) and d.row_capacity == 0 and d.quad_mask == -1 and d.dfsph_window == -1 and d.pbd_skin < 0
+    try:
+        sphx.set_tuning(row_capacity=64, dfsph_no_tail=1, pbd_skin=0.1)
+        g = sphx.get_tuning()
+        assert (g.row_capacity, g.dfsph_no_tail) == (64, 1) and abs(g.pbd_skin - 0.1) < 1e-7
+        bad = sphx.default_tuning(); bad.struct_size -= 4
+        with pytest.raises(sphx.SphxError):
+            sphx.set_tuning(bad)
+        with pytest.raises(sphx.SphxError):
+            sphx.set_tuning(row_capacity=5)
+        with pytest.raises(sphx.SphxError):
+            sphx.set_tuning(no_such_field=1)
+        assert sphx.get_tuning().row_capacity == 64, "a refused block changes nothing"
+        t = tuning_env.from_environment(sphx, {"SPHX_NBR_CAP": "12", "SPHX_DFSPH_NO_TAIL": "1", "SPHX_COMM_PRIORITY": "low", "SPHX_EDGE_PRIORITY": "high",
+                                               "SPHX_SLAB_EDGE_STREAM": "0", "SPHX_PBD_SKIN": "0.3", "SPHX_DFSPH_WINDOW": "0"})
+        assert (t.row_capacity, t.dfsph_no_tail, t.slab_comm_priority, t.slab_edge_priority, t.slab_edge_stream, t.dfsph_window) == (12, 1, 2, 1, 0, 0)
+        assert abs(t.pbd_skin - 0.3) < 1e-7
+    finally:
+        sphx.set_tuning()
+    assert sphx.get_tuning().row_capacity == 0
+
+
+def test_library_reads_no_behaviour_switch_from_the_environment():
+    """getenv survives in the product sources only for the RCCL library path and, inside #ifdef SPHX_TEST_HOOKS, for
+    the test build's fault injection."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "cpp-fluid-particles_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        hooks = 0
+        for n, line in enumerate(open(path), 1):
+            if line.lstrip().startswith("#ifdef SPHX_TEST_HOOKS"):
+                hooks += 1
+            elif line.lstrip().startswith("#endif") and hooks:
+                hooks -= 1
+            if "getenv(" in line.split("//")[0] and not hooks:
+                assert "SPHX_RCCL_LIBRARY" in line, "%s:%d reads the environment: %s" % (path, n, line.strip())

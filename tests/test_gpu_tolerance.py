@@ -505,6 +505,43 @@ def test_persistent_rows_snapshot_and_count_changes(sphx, oracle, tmp_path):
     close_to_oracle(g, "after sphx_set of the warm stiffness")
     g.close(); r.close(); o.close()
 
+def test_persistent_rows_raw_pointer_writes_need_invalidate_order(sphx, oracle):
+    """in persistent mode the solver steps a working copy and the API arrays are exported by every step, so a caller that
+    WRITES them through sphx_device_ptr must say so (sphx_invalidate_order): with the call the run follows the oracle driven through the
+    same change; without it the write is overwritten by the next export (asserted too: that is the documented behaviour, not a silent
+    surprise).  Reading a solver-internal field through sphx_get must not disturb the mode."""
+    P, fluid, boundary = sphx.scene(12)
+    P.solver = 1; P.dfsph_fixed_div = 1; P.dfsph_fixed_den = 3
+    Po = same_params(oracle.Params(), P)
+    P.reserved[3] = 2
+
+    def run(invalidate):
+        g, o = sphx.System(P, fluid, boundary), oracle.System(Po, fluid, boundary)
+        for _ in range(6):
+            g.step(); o.step()
+        builds0 = g.persistent_stats()[1]
+        alpha = g.get(sphx.F_ALPHA)                              # through the slot map: no flush, no forced rebuild
+        assert _rel(alpha, o.get(oracle.F_ALPHA), float(np.abs(o.get(oracle.F_ALPHA)).max())) <= 5e-3
+        # a caller's own kernel writes into the velocity array in place: sphx_cell_columns with a huge cell length stores n integer
+        # zeros (= +0.0f) behind the pointer it is given -- the velocities of the first n / 3 particles of the API order
+        n = g.n
+        vel = o.get(oracle.F_VEL).copy(); vel.reshape(-1)[:n] = 0.0
+        o.set(oracle.F_VEL, vel)
+        sphx.cell_columns(g.device_ptr(sphx.F_POS), n, 1.0e9, g.device_ptr(sphx.F_VEL)); sphx.sync()
+        if invalidate:
+            g.invalidate_order()
+        g.step(); o.step()
+        assert g.persistent_stats()[1] <= builds0 + 1 + (1 if invalidate else 0), "the sphx_get of a solver field must not have forced a rebuild of its own"
+        dv = _rel(g.get(sphx.F_VEL), o.get(oracle.F_VEL), 1.0)
+        same = np.array_equal(g.get(sphx.F_ID), o.get(oracle.F_ID))
+        g.close(); o.close()
+        return dv, same
+    dv, same = run(True)
+    assert same and dv <= 1e-4, "with sphx_invalidate_order the written velocities are the ones stepped: %.2e" % dv
+    dv_lost, _ = run(False)
+    assert dv_lost > 1e-2, "without it the next export overwrites the write (documented): %.2e" % dv_lost
+
+
 @pytest.mark.parametrize("arith", [1, 2])
 def test_adaptive_loop_tail_equals_gated_launches_in_tolerance_arithmetic(sphx, monkeypatch, arith):
     """adaptive DFSPH under the tolerance arithmetic (rows every step / persistent rows): every iteration beyond the reference's minimum

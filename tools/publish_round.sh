@@ -21,6 +21,7 @@ done
 cp gpurun_out/pcie_$T.txt                     profiles/${T}_pcie_inclusive.txt
 cp gpurun_out/probe_$T.txt                    profiles/${T}_probe_per_kernel_hipevents.txt
 cp gpurun_out/small_$T.txt                    profiles/${T}_reference_scene_step_n.txt
+cp gpurun_out/slab_probe_$T.txt               profiles/${T}_slab_probe_step.txt
 cp gpurun_out/big_$T.txt                      profiles/${T}_big_scenes.txt
 cp gpurun_out/pytest_gpu_tail_$T.txt          profiles/${T}_pytest_gpu_tail.txt
 cp gpurun_out/bench_${T}_1gpu.json profiles/${T}_bench_dfsph10m_1gpu.json      # same box and call as the rocprofv3 summaries above
