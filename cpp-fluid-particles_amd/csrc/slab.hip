@@ -599,6 +599,7 @@ struct sphx_slab_group {
             const int n = nl + m + nr;
             // DFSPH / WCSPH: the rows [from left | kept | from right] ARE the pre-sort order of this step; the SEARCH stage sorts them
             // straight into the engine's arrays (no unpack pass, no copy back, the warm stiffness arrives sorted).  PBD unpacks.
+            if (s.solver != SPHX_PBD) s.sys->system->setCellWindow(s.x0 - s.ghost - 1, s.x1 + s.ghost + 1);      // held columns + an empty one per side
             if (s.solver != SPHX_PBD)
                 s.sys->system->setStagedInput(SPHSystem::StagedRows{{s.recvL.p, s.own.p, s.recvR.p}, {nl, m, nr}, s.extraFloats, s.extraFloats ? s.extra : nullptr});
             else if (n > 0)

@@ -313,8 +313,10 @@ __device__ __forceinline__ const float* staged_row(const RowSource& r, int t)
     return r.rows[2] + (size_t)(t - r.count[1]) * r.W;
 }
 // k_cell_and_count with the position read from the staged rows (same keys, same run-compressed histogram atomics)
+// (cells outside the window [winLo, winHi) count as out of grid: SPHSystem::setCellWindow)
+__global__ void k_copy_one_int(int* __restrict__ dst, const int* __restrict__ src) { *dst = *src; }
 __global__ void __launch_bounds__(256) k_cell_and_count_rows(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts, RowSource src,
-                                                             GridDesc g, int n)
+                                                             GridDesc g, int n, int winLo, int winHi)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -324,6 +326,7 @@ __global__ void __launch_bounds__(256) k_cell_and_count_rows(int* __restrict__ p
         const float* row = staged_row(src, i);
         const int3 c = cell_of(v3(row[0], row[1], row[2]), g);
         id = cell_id(c.x, c.y, c.z, g);
+        if (id < winLo || id >= winHi) id = g.C;
         p2c[i] = id;
     }
     const int prev = __shfl_up(id, 1, 64);
@@ -657,14 +660,21 @@ void SPHSystem::neighborSearchStaged(const StagedRows& staged)
     int* perm = _fluids->getSortPerm();
     DArray<int>& cellStart = _fluidCellStart;
     const RowSource src{{staged.rows[0], staged.rows[1], staged.rows[2]}, {staged.count[0], staged.count[1], staged.count[2]}, 7 + staged.extraFloats};
-    HIP_CALL(hipMemsetAsync(cellStart.addr(), 0, sizeof(int) * cellsPlusOne, st));
+    // the window of the cell table this step touches: cells [a, b), element b receiving the in-window total (b = C: the sentinel itself)
+    const int cells = cellsPlusOne - 1, perColumn = _sc.cells.y * _sc.cells.z;
+    const bool windowed = _winLo >= 0 && _winHi > _winLo;
+    const int a = windowed ? std::min(std::max(_winLo, 0), _sc.cells.x) * perColumn : 0;
+    const int b = windowed ? std::min(std::max(_winHi, 0), _sc.cells.x) * perColumn : cells;
+    HIP_CALL(hipMemsetAsync(cellStart.addr(a), 0, sizeof(int) * (size_t)(b - a + 1), st));
+    if (b < cells) HIP_CALL(hipMemsetAsync(cellStart.addr(cells), 0, sizeof(int), st));
     if (num > 0) {
         ScopedKernel t("grid_cell_count");
-        k_cell_and_count_rows<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), src, g, num);
+        k_cell_and_count_rows<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), src, g, num, a, b);
     }
     {
         ScopedKernel t("grid_scan");
-        device_exclusive_scan(cellStart.addr(), cellsPlusOne, _grid->blockSums.addr());
+        device_exclusive_scan(cellStart.addr(a), b - a + 1, _grid->blockSums.addr());
+        if (b < cells) k_copy_one_int<<<1, 1, 0, st>>>(cellStart.addr(cells), cellStart.addr(b));      // where the out-of-grid bucket starts
     }
     if (num <= 0) return;
     {

@@ -84,6 +84,12 @@ public:
     // (r05; same bits as unpacking and sorting in place).  One-shot: consumed by that stage.
     struct StagedRows { const float* rows[3]; int count[3]; int extraFloats; float* extraOut; };
     void setStagedInput(const StagedRows& staged) { _staged = staged; _hasStaged = true; }
+    // ... and the cell columns [colLo, colHi) its held particles can lie in, plus an empty column on either side for the 27-cell
+    // walks: the staged sort then clears, counts and scans only that window of the whole-grid cell table (every slab's engine works
+    // on the global grid: 7.5 M cells at 10 M particles, of which a slab of an 8-GPU run touches a sixth).  Cells outside the window
+    // keep stale values and are never read; a particle found outside it is filed in the out-of-grid bucket (the driver's layer check
+    // then reports it).  colLo < 0: the whole grid.
+    void setCellWindow(int colLo, int colHi) { _winLo = colLo; _winHi = colHi; }
     // Persistent neighbour rows (opt-in; tolerance arithmetic, WCSPH / DFSPH, whole-domain systems; C ABI: reserved[3] = 2).
     // The solver steps a working copy of the fluid arrays that stays in the order of the last row build, the rows carry a skin
     // and are rebuilt only when a device-side check finds that some particle has moved more than 0.49 skin relative to the
@@ -141,6 +147,7 @@ private:
     std::function<void()> _afterSort;
     StagedRows _staged{};
     bool _hasStaged = false;
+    int _winLo = -1, _winHi = -1;
     int _cellOffsetX = 0;     // slab decompositions: global x index of local cell column 0
     bool _slab = false;
 };
