@@ -566,7 +566,11 @@ struct sphx_slab_group {
             k_slab_verdict<<<1, 64, 0, st>>>(s.counts.p, s.violation.p, (long long)s.capacity, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, inject,
                                              reinterpret_cast<unsigned long long*>(dBad.p));
         }
-        if (world > (int)slabs.size()) transport->allreduce_device(dBad.p, dBad.p + 1);
+        // (the RCCL transport reduces even when this process drives every slab -- a one-rank ncclAllReduce: the runs over the installed
+        // librccl on the one-GPU box then exercise the same calls, events and stream order a node would)
+        int kind = 0, ranks = 0, rk = 0;
+        transport->describe(kind, ranks, rk);
+        if (world > (int)slabs.size() || kind == 1) transport->allreduce_device(dBad.p, dBad.p + 1);
         else hip_ok(hipMemcpyAsync(dBad.p + 1, dBad.p, sizeof(long long), hipMemcpyDeviceToDevice, st), "failure word");
         for (auto& sp : slabs) {
             Slab& s = *sp;

@@ -22,5 +22,6 @@ for A in tolerance strict; do for s in 1 8; do python bench.py --force-slab --sl
 python bench.py --force-slab --slabs 8 --arith tolerance --slab-transport rccl --steps 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_${TAG}_rcclself_8slabs.json
 (python tools/slab_probe_step.py 190 1 1; python tools/slab_probe_step.py 190 8 1) 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/slab_probe_$TAG.txt
 python tools/big_probe.py 190,320,400 0 2>/dev/null | grep "^nx" > gpurun_out/big_${TAG}.txt
+bash tools/stress_round.sh $TAG > gpurun_out/stress_$TAG.log 2>&1
 python -m pytest tests -m gpu -q 2>&1 | grep -v "PBD:\|amdgpu\|Could not read\|iommu" | tail -4 > gpurun_out/pytest_gpu_tail_$TAG.txt
 cat gpurun_out/pytest_gpu_tail_$TAG.txt; cat gpurun_out/pcie_$TAG.txt; grep "ms/step" gpurun_out/probe_$TAG.txt; cat gpurun_out/small_$TAG.txt

@@ -23,6 +23,7 @@ cp gpurun_out/probe_$T.txt                    profiles/${T}_probe_per_kernel_hip
 cp gpurun_out/small_$T.txt                    profiles/${T}_reference_scene_step_n.txt
 cp gpurun_out/slab_probe_$T.txt               profiles/${T}_slab_probe_step.txt
 cp gpurun_out/big_$T.txt                      profiles/${T}_big_scenes.txt
+for k in parity tolerance persistent slab slab_tolerance; do [ -s gpurun_out/stress_${T}_$k.txt ] && cp gpurun_out/stress_${T}_$k.txt profiles/${T}_stress_$k.txt; done
 cp gpurun_out/pytest_gpu_tail_$T.txt          profiles/${T}_pytest_gpu_tail.txt
 cp gpurun_out/bench_${T}_1gpu.json profiles/${T}_bench_dfsph10m_1gpu.json      # same box and call as the rocprofv3 summaries above
 echo "published $T"
