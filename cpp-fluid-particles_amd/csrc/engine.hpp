@@ -112,6 +112,13 @@ struct SweepCache {
     int quadMaskTol = 15;                    // tolerance arithmetic, quad walks with per-lane partial sums + one DPP reduction (r03, 10.3 M particles):
                                              // head -11 %, viscosity+colour -26 %, corrections -2..4 %; the surface sweeps (3 gathers, ~100 VGPRs)
                                              // lose 5x and stay lane-per-particle.  Below 4 M particles the corrections stay lane-per-particle too (mask & 7)
+    // Small scenes (r05): below `smallBelow` particles a lane-per-particle launch has fewer waves than the device has SIMDs (20,736
+    // particles: 324 waves for 1024 SIMDs) and a sweep takes as long as ONE wave's row walk; four lanes per particle cut that walk to a
+    // quarter.  Measured (tools/quad_size_probe.py, free fall, strict): PBD(20) 0.787 -> 0.481 ms per step at 20,736 particles, 0.958 ->
+    // 0.804 at 96,000, break-even near 130,000; adaptive DFSPH 0.228 -> 0.203; WCSPH 0.116 -> 0.109.  Every sweep that has the variant
+    // then walks quad-per-particle (strict: same bits -- the schedule tests run all-quads; the surface sweeps stay lane-per-particle).
+    int smallBelow = 131072;
+    int quadMaskSmall = 255, quadMaskTolSmall = 255;
     // bumped whenever a host-side change invalidates launches recorded in a captured hipGraph (boundary
     // repack pending, arrays reallocated, engine switches changed); SPHSystem::stepN compares it
     unsigned int generation = 0;

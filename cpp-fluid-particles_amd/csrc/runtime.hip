@@ -508,9 +508,9 @@ SweepCache::SweepCache(int num)
     flags = T.engine_flags;
     if (T.range_order >= 0) rangeOrder = T.range_order != 0;
     if (T.range_order_min > 0) rangeOrderMin = T.range_order_min;
-    if (T.quad_mask >= 0) quadMask = T.quad_mask;                  // experiments: which sweeps run quad-per-particle
-    if (T.duo_mask >= 0) { duoMask = T.duo_mask; duoMaskLarge = 0; }   // ... and which with two lanes per particle
-    if (T.quad_mask_tol >= 0) quadMaskTol = T.quad_mask_tol;       // ... quad walks under the tolerance arithmetic
+    if (T.quad_mask >= 0) quadMask = quadMaskSmall = T.quad_mask;  // experiments: which sweeps run quad-per-particle (at every size)
+    if (T.duo_mask >= 0) { duoMask = T.duo_mask; duoMaskLarge = 0; quadMaskSmall = quadMask; }   // ... and which with two lanes per particle
+    if (T.quad_mask_tol >= 0) quadMaskTol = quadMaskTolSmall = T.quad_mask_tol;       // ... quad walks under the tolerance arithmetic
     brickWanted = T.brick != 0;                                    // compact-brick LDS stage under the tolerance arithmetic
     if (brickWanted) {      //  the stage needs ~74 KB of dynamic LDS per block: parts with 64 KB (gfx942) cannot run it
         int dev = 0, ldsMax = 0;
@@ -626,7 +626,11 @@ SweepCtx SweepCache::ctx(const DArray<int>& csF, const DArray<int>& csB) const
     c.tileFmt = (use && allowTiles && (flags & kFlagTiles)) ? tileFmt.addr() : nullptr;
     // (strict: the surface sweeps add TWO terms per entry to one accumulator, (a + t1) + t2, which the ordered one-term-per-lane
     // accumulation of the quad walk cannot reproduce: they stay lane-per-particle whatever the mask says)
-    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (tolerance ? (n >= 4000000 ? quadMaskTol : (quadMaskTol & 7)) : (quadMask & ~kQuadSurfaceBit)) : 0;
+    // (small scenes: every sweep that has the variant, see SweepCache::smallBelow)
+    const bool small = n < smallBelow;
+    c.quad = (use && !c.tileFmt && !(flags & kFlagNoQuad))
+                 ? (tolerance ? (n >= 4000000 ? quadMaskTol : (small ? quadMaskTolSmall : (quadMaskTol & 7))) : ((small ? quadMaskSmall : quadMask) & ~kQuadSurfaceBit))
+                 : 0;
     // two lanes per particle: from 4 M particles on the head and the viscosity+colour sweep gain 7-8 % (r03: 1.10 -> 1.02 ms and
     // 1.18 -> 1.09 ms at 10.3 M; below, where they are not bound by the L1, they lose 10-25 %: r02)
     c.duo = (use && !c.tileFmt && !(flags & kFlagNoQuad)) ? (n >= 4000000 ? (duoMask | duoMaskLarge) : duoMask) : 0;

@@ -6,7 +6,7 @@ import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirnam
 import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables -> sphx_tuning (the library reads none itself)
 for name, solver, dt in (("wcsph", sphx.WCSPH, 0.001), ("dfsph", sphx.DFSPH, 0.002), ("pbd20", sphx.PBD, 0.002)):
     P, f, b = sphx.scene(24)
-    P.solver = solver; P.dt = dt
+    P.solver = solver; P.dt = dt; P.reserved[3] = int(os.environ.get("TOL", "0"))
     s = sphx.System(P, f, b)
     s.step_n(10)
     out = []
