@@ -73,6 +73,12 @@ struct SweepCache {
     DArray<float> vel4;                      // float4 mirror of vel, kept in step by every velocity writer
     DArray<float> cg4;                       // float4 mirror of the colour gradient
     DArray<float> posf;                      // float4 (x, y, z, scalar neighbour field): one-gather sweeps
+    // PBD (r05): the other halves of posm / posf for Jacobi iterations that store the moved positions from inside the delta-p sweep;
+    // swapped with the live ones behind such a launch.  Copies of the live arrays when made (boundary tail included), dropped whenever
+    // the boundary part is repacked or regrown.
+    std::unique_ptr<DArray<float>> posmAlt, posfAlt;
+    void ensureAltPositions();
+    void swapAltPositions() { posm.swap(*posmAlt); posf.swap(*posfAlt); }
     DArray<int> massUniform;                 // device flag set by the pack pass: all fluid masses equal
     bool allowPacked = true;                 // one-gather sweeps allowed (slab drivers refresh posf next to the scalar's own array)
     DArray<int> nbrCount;

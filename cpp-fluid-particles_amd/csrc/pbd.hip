@@ -105,6 +105,12 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
     c.packBoundary(*boundaries);
     const int num = (int)fluids->size();
     auto iter = 0;
+    // r05: the delta-p sweep of an iteration also applies it (OpDeltaPos::apply: the moved positions go into the other half of the
+    // double-buffered posm / posf, which then becomes the live one) -- one launch and one pass per iteration less.  An EVEN number of
+    // iterations is run that way, so that a step ends on the buffers it began with (a captured step graph holds their addresses); a last
+    // odd iteration applies in place with the separate pass.  Whole-domain steps only (slabs apply range by range behind their halos).
+    const int fusedIters = (c.isSlab || c.rangeLo >= 0 || num <= 0) ? 0 : (maxIterations / 2) * 2;
+    if (fusedIters > 0) c.ensureAltPositions();
     while (iter < maxIterations) {
         c.ensureList(cellStartFluid, cellStartBoundary);
         if (iter > 0) c.rebuildIfStale(cellStartFluid, cellStartBoundary);
@@ -114,12 +120,27 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
             OpLambda lam{ctx, fluids->getDensityPtr(), bufferFloat.addr(), rho0, (rho0 != 0.0f) ? 1.0f : 0.0f, relaxation};
             launch_op(lam, num);
         }
-        {
+        if (iter < fusedIters) {
             ScopedKernel t("pbd_delta_pos");
+            const bool skin = c.skinRows && c.skin > 0.0f && c.listValid && c.posBuild;
             OpDeltaPos dp{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true};
+            dp.apply.pos = fluids->getPosPtr();
+            dp.apply.posmNext = reinterpret_cast<float4*>(c.posmAlt->addr());
+            dp.apply.posfNext = reinterpret_cast<float4*>(c.posfAlt->addr());
+            dp.apply.space = spaceSize;
+            if (skin) {
+                dp.apply.posBuild = reinterpret_cast<const float4*>(c.posBuild->addr()); dp.apply.rowCell = c.rowCell->addr();
+                dp.apply.stale = c.staleFlag.addr(c.activeFlag); dp.apply.limit2 = c.staleLimit2();
+            }
             launch_op(dp, num);
-        }
-        {
+            c.swapAltPositions();
+            if (!skin) c.listValid = false;
+        } else {
+            {
+                ScopedKernel t("pbd_delta_pos");
+                OpDeltaPos dp{ctx, bufferFloat.addr(), bufferFloat3.addr(), rho0, true};
+                launch_op(dp, num);
+            }
             ScopedKernel t("pbd_apply_clamp");   // keeps the packed position view in step with pos
             applyDelta(fluids, spaceSize, num);
         }

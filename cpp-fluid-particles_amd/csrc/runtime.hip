@@ -588,10 +588,21 @@ void SweepCache::reserveBoundary(int count)
         a.swap(t);
     };
     grow(posm); grow(posf); grow(vel4); grow(cg4);
+    posmAlt.reset(); posfAlt.reset();
     nbCap = count;
     boundaryValid = false;
     listValid = false;
     ++generation;      // the four arrays moved: a captured graph holds stale pointers
+}
+
+void SweepCache::ensureAltPositions()
+{
+    if (posmAlt && posmAlt->length() == posm.length() && posfAlt && posfAlt->length() == posf.length()) return;
+    posmAlt.reset(new DArray<float>(posm.length()));
+    posfAlt.reset(new DArray<float>(posf.length()));
+    ew_copy(posmAlt->addr(), posm.addr(), sizeof(float) * (size_t)posm.length());      // (the boundary tail is what matters)
+    ew_copy(posfAlt->addr(), posf.addr(), sizeof(float) * (size_t)posf.length());
+    ++generation;
 }
 
 void SweepCache::packBoundary(const SPHParticles& boundaries)
@@ -600,6 +611,7 @@ void SweepCache::packBoundary(const SPHParticles& boundaries)
     if (boundaryValid && boundaryKey == (const void*)boundaries.getPosPtr() && nb == count) return;
     reserveBoundary(count);
     nb = count;
+    posmAlt.reset(); posfAlt.reset();          // (made again, with this boundary tail, by the next PBD step that wants them)
     ScopedKernel t("pack_boundary");
     if (count > 0) {
         // (x, y, z, mass) into the boundary tail of both position arrays (plain and one-gather view)

@@ -1026,11 +1026,20 @@ struct OpLambda {
 };
 
 // computeDeltaPos_CUDA, PBDSolver.cu:170-210 (boundaries: lambda_j = +0)
+// r05: the sweep can also APPLY its delta-p (PBDSolver.cu:247-253: pos += delta-p, box clamp) in its store.  A Jacobi iteration may
+// not move a position before every delta-p has been formed from the old ones, and the sweep gathers neighbour positions
+// from posm / posf -- so the moved positions go into the OTHER half of a double-buffered pair (SweepCache::posmAlt / posfAlt), which
+// becomes the live one behind the launch.  The API position array is only ever read for the particle's own entry: updated in place.
+struct DeltaApply {
+    float3* pos = nullptr; float4* posmNext = nullptr; float4* posfNext = nullptr; float3 space = {0.0f, 0.0f, 0.0f};
+    const float4* posBuild = nullptr; const int* rowCell = nullptr; int* stale = nullptr; float limit2 = 0.0f;      // skin rows: k_apply_delta_clamp's watch
+};
 struct OpDeltaPos {
     SweepCtx c;
     const float* lambda; float3* deltaPos;
     float rho0;
     bool packedScalar;      // posf.w holds lambda
+    DeltaApply apply{};
     using Field = float;    // neighbour lambda
     __device__ __forceinline__ Field stage(bool isB, int j) const { return fluid_only(lambda, isB, j); }
     struct Body {
@@ -1054,7 +1063,19 @@ struct OpDeltaPos {
         Body b{*this, valid ? lambda[i] : 0.0f, v3(0, 0, 0)};
         sweep_any<QUAD, true>(*this, c, lp, lf, i, valid, own_pos(c, i, valid), b);
         if (!stores_results<QUAD>(valid)) return;
-        deltaPos[i] = div3s(b.a, rho0);
+        const float3 dp = div3s(b.a, rho0);
+        if (!apply.pos) { deltaPos[i] = dp; return; }
+        float3 p = add3(apply.pos[i], dp);                      // exactly k_apply_delta_clamp
+        float3 unused = v3(0, 0, 0);
+        clamp_box<false>(p, unused, apply.space);
+        apply.pos[i] = p;
+        apply.posmNext[i] = make_float4(p.x, p.y, p.z, c.posm[i].w);
+        apply.posfNext[i] = make_float4(p.x, p.y, p.z, 0.0f);
+        if (apply.posBuild) {
+            const float3 dd = sub3(p, xyz(apply.posBuild[i]));
+            const int3 cNow = cell_of(p, c.g);
+            if (!(dot3(dd, dd) <= apply.limit2) || cell_id(cNow.x, cNow.y, cNow.z, c.g) != apply.rowCell[i]) *apply.stale = 1;
+        }
     }
 };
 
