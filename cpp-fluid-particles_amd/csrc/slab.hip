@@ -671,15 +671,31 @@ struct sphx_slab_group {
         for (auto& sp : slabs) sp->sys->system->phase(phase);
     }
 
+    // The layers of a DFSPH / WCSPH stage.  An edge layer exists where a neighbour reads it (it goes first, its halo is posted while the
+    // interior is swept); on a side WITHOUT a neighbour the first owned columns are ordinary interior particles.  (Until r05 both edge
+    // layers of every slab were launched apart whether anyone waited for them or not: two launches, a fork and a join per stage for a
+    // slab on its own -- +1.1 % per step at 10.3 M, profiles/r05_slab_one_slab_probe.txt.)
+    struct StageParts { int e0, e1, e20, e21, in0, in1; };
+    static StageParts stageParts(const Slab& s)
+    {
+        const int* l = s.layer;
+        StageParts p{-1, -1, -1, -1, s.hasLeft ? l[1] : l[0], s.hasRight ? l[2] : l[3]};
+        if (s.hasLeft) { p.e0 = l[0]; p.e1 = l[1]; if (s.hasRight) { p.e20 = l[2]; p.e21 = l[3]; } }
+        else if (s.hasRight) { p.e0 = l[2]; p.e1 = l[3]; }
+        return p;
+    }
+
     // A sweep stage of DFSPH / WCSPH: only owned particles are swept (ghost values arrive by halo).  With overlap the
-    // two edge layers go first, the halo of the stage's output starts, the interior follows.
+    // edge layers go first, the halo of the stage's output starts, the interior follows.
     // reduce: the stage accumulates the exact |error| total of the owned particles (adaptive DFSPH).
     void sweepStage(int phase, const std::vector<int>& halo, bool reduce = false)
     {
         SLAB_TRACE("stage", phase);
         transport->wait();                      // the edges read ghost values written by the previous stage's halo
         const bool sweepGhosts = !overlap() && (flags & SPHX_SLAB_SWEEP_GHOSTS);
-        if (!overlap()) {
+        bool anyEdge = false;
+        for (auto& sp : slabs) anyEdge = anyEdge || sp->hasLeft || sp->hasRight;
+        if (!overlap() || !anyEdge) {           // (no neighbour anywhere: one launch per slab, nothing to post)
             for (auto& sp : slabs) {
                 Slab& s = *sp;
                 if (sweepGhosts) s.sys->system->phaseEx(phase, -1, -1, reduce, s.o0, s.o1, false);
@@ -702,28 +718,30 @@ struct sphx_slab_group {
                 ScopedStream onEdges(edgeStream);
                 for (auto& sp : slabs) {
                     Slab& s = *sp;
-                    const int* l = s.layer;
-                    s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, true, l[2], l[3]);
+                    const StageParts p = stageParts(s);
+                    if (p.e0 >= 0) s.sys->system->phaseEx(phase, p.e0, p.e1, reduce, s.o0, s.o1, true, p.e20, p.e21);
                 }
                 postHalo(halo, true);
                 hip_ok(hipEventRecord(joinEvent, edgeStream), "event record");
             }
             for (auto& sp : slabs) {
                 Slab& s = *sp;
-                s.sys->system->phaseEx(phase, s.layer[1], s.layer[2], reduce, s.o0, s.o1, true);
+                const StageParts p = stageParts(s);
+                s.sys->system->phaseEx(phase, p.in0, p.in1, reduce, s.o0, s.o1, true);
             }
             hip_ok(hipStreamWaitEvent(main, joinEvent, 0), "stream wait");
             return;
         }
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            const int* l = s.layer;
-            s.sys->system->phaseEx(phase, l[0], l[1], reduce, s.o0, s.o1, false, l[2], l[3]);       // both edge layers in one launch
+            const StageParts p = stageParts(s);
+            if (p.e0 >= 0) s.sys->system->phaseEx(phase, p.e0, p.e1, reduce, s.o0, s.o1, false, p.e20, p.e21);       // both edge layers in one launch
         }
         postHalo(halo, true);
         for (auto& sp : slabs) {
             Slab& s = *sp;
-            s.sys->system->phaseEx(phase, s.layer[1], s.layer[2], reduce, s.o0, s.o1, true);
+            const StageParts p = stageParts(s);
+            s.sys->system->phaseEx(phase, p.in0, p.in1, reduce, s.o0, s.o1, p.e0 >= 0);
         }
     }
 

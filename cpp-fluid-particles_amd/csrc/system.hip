@@ -468,6 +468,15 @@ void device_exclusive_scan3(int* a, int* b, int* c, int count, int* blockSums)
 
 // a stage restricted to particles [lo, hi) (lo < 0: all), optionally accumulating the |error| total of
 // particles [sumLo, sumHi) (DFSPH error stages); keepAccum: add to the running total (a later part of a split stage)
+// Behind the last stage of a step taken stage by stage: a whole-domain system tunes its solver; a slab's engine only
+// lets its neighbour rows grow (BasicSPHSolver::tune -> SweepCache::tuneRowCapacity) -- the loop windows and PBD skins of the derived
+// solvers belong to whole-domain stepping, a slab's loops are its driver's.
+static void tune_after_stages(bool slab, BaseSolver* solver)
+{
+    if (!slab) { solver->tune(1); return; }
+    if (auto* basic = dynamic_cast<BasicSPHSolver*>(solver)) basic->BasicSPHSolver::tune(1);
+}
+
 void SPHSystem::phaseEx(int p, int lo, int hi, bool reduce, int sumLo, int sumHi, bool keepAccum, int lo2, int hi2)
 {
     auto* basic = dynamic_cast<BasicSPHSolver*>(_solver.get());
@@ -527,7 +536,7 @@ void SPHSystem::phase(int p)
         if (p == SPHX_PH_P_SEARCH) { neighborSearch(_fluids, _fluidCellStart); if (_afterSort) _afterSort(); }
         pbd->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                       _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.gravity, _sc.surfaceTension, _sc.airPressure);
-        if (p == SPHX_PH_P_TAIL) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }
+        if (p == SPHX_PH_P_TAIL) { _graph->stepsRun++; tune_after_stages(_slab, _solver.get()); }
         return;
     }
     if ((p >= SPHX_PH_W_SEARCH && p <= SPHX_PH_W_PRESSURE) || (p == SPHX_PH_ADVECT && !dynamic_cast<DFSPHSolver*>(_solver.get()))) {
@@ -540,7 +549,7 @@ void SPHSystem::phase(int p)
         w->runWcsphPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                          _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.stiff, _sc.visc, _sc.gravity,
                          _sc.surfaceTension, _sc.airPressure);
-        if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }
+        if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; tune_after_stages(_slab, _solver.get()); }
         return;
     }
     auto* dfsph = dynamic_cast<DFSPHSolver*>(_solver.get());
@@ -556,7 +565,7 @@ void SPHSystem::phase(int p)
     dfsph->runPhase(p, _fluids, _boundaries, _fluidCellStart, _wallCellStart, _sc.space, _sc.cells, _sc.cellLength,
                     _sc.radius, _sc.dt, _sc.rho0, _sc.rhoBoundary, _sc.visc, _sc.gravity, _sc.surfaceTension,
                     _sc.airPressure, false);
-    if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; if (!_slab) _solver->tune(1); }      // (whole-domain systems stepped stage by stage: ADVICE r03)
+    if (p == SPHX_PH_ADVECT) { _graph->stepsRun++; tune_after_stages(_slab, _solver.get()); }      // (whole-domain systems stepped stage by stage: ADVICE r03)
 }
 
 // the constructor sequence of SPHSystem.cu:68-76

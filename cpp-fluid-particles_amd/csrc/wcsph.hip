@@ -75,7 +75,8 @@ void BasicSPHSolver::permuteState(const int* perm, int n)
 void BasicSPHSolver::setCellOffsetX(int cellOffsetX)
 {
     _cache->cellOffsetX = cellOffsetX; _cache->cellKey = -1.0f; _cache->isSlab = true;
-    if (_cache->capAuto) { _cache->capAuto = false; _cache->cap = 96; }      // slabs are stepped stage by stage (no tune() calls): fixed rows
+    // (until r05 a slab's rows were fixed at 96 entries; now they start at 48 and grow like a whole-domain system's -- SPHSystem::phase
+    // calls BasicSPHSolver::tune behind a slab's last stage: half the row store, 0.2-0.6 % per step at 10.3 M)
 }
 
 // BasicSPHSolver::force, BasicSPHSolver.cu:227-235: vel += dt * G

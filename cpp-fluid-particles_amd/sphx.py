@@ -444,6 +444,14 @@ class SlabGroup:
         _check(lib().sphx_slab_iters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def row_capacity(self, index=0):
+        """entries per neighbour row of local slab `index`'s engine (sphx_slab_system + sphx_row_capacity)"""
+        sys_h, cap = C.c_void_p(), C.c_int()
+        _check(lib().sphx_slab_system(self._h, index, C.byref(sys_h)))
+        lib().sphx_row_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _check(lib().sphx_row_capacity(sys_h, C.byref(cap)))
+        return cap.value
+
     def comm_info(self):
         """the transport as it reports itself: kind, ranks and own rank of the communicator (ncclCommCount / ncclCommUserRank),
         payload bytes sent / received, exchanges and all-reduces posted by this process"""

@@ -79,6 +79,55 @@ def test_native_slab_layer_matches_single_domain_oracle(sphx, oracle, world, sol
         assert moved > 0, "the test must exercise migration across cuts"
 
 
+def _dense_splash(n, P, seed):
+    """the slab tests' splash squeezed to half its height: rows of up to ~70 entries in the first steps (WCSPH relaxes it gently:
+    |v| stays below 12, far from the one-column-per-step limit of the exchange)"""
+    pos, vel = slab_worker.splash(n, P, seed)
+    lo = np.float32(0.03 * P.space[0])
+    pos[:, 1] = (lo + (pos[:, 1] - lo) * np.float32(0.5)).astype(np.float32)
+    return pos, vel
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_slab_rows_grow_like_a_whole_domain_systems(sphx, oracle, world):
+    """r05: a slab's neighbour rows start at 48 entries and grow behind the last stage of a step (SPHSystem::phase ->
+    BasicSPHSolver::tune; until r05 they were fixed at 96).  A splash whose rows pass 48 entries, long enough for two capacity
+    checks (every 8 steps): before the growth the overflowing particles walk the cells, afterwards their rows hold them -- the
+    strict result equals the single-domain ORACLE bit for bit throughout, and the rows grew as the whole-domain engine's did
+    (the slab that owns the particle with the longest row asks for the same capacity)."""
+    nx, steps, seed = 12, 18, 17
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, "wcsph", False)
+    pos, vel = _dense_splash(len(fluid), P, seed)
+    g = sphx.SlabGroup(P, pos, boundary, world, velocity=vel)
+    assert all(g.row_capacity(i) == 48 for i in range(world))
+    g.step(steps)
+    caps = [g.row_capacity(i) for i in range(world)]
+    ids, gp, gv, gd = g.gather_all()
+    g.close()
+    s = sphx.System(P, pos, boundary, ctor_step=False)
+    s.set(sphx.F_VEL, vel[s.get(sphx.F_ID)])
+    for _ in range(steps):
+        s.step()
+    single_cap = sphx.row_capacity(s)
+    sp, sv = (s.get(f)[np.argsort(s.get(sphx.F_ID))] for f in (sphx.F_POS, sphx.F_VEL))
+    s.close()
+    assert single_cap > 48, "the scene must make the whole-domain engine grow its rows"
+    assert max(caps) == single_cap and all(48 <= c <= single_cap and c % 4 == 0 for c in caps), (caps, single_cap)
+    Q, _, _ = oracle.scene(nx)
+    slab_worker.configure(Q, oracle, "wcsph", False)
+    o = oracle.System(Q, pos, boundary, ctor_step=False)
+    o.set(oracle.F_VEL, vel[o.get(oracle.F_ID)])
+    for _ in range(steps):
+        o.step()
+    order = np.argsort(o.get(oracle.F_ID))
+    rp, rv, rd = o.get(oracle.F_POS)[order], o.get(oracle.F_VEL)[order], o.get(oracle.F_DENSITY)[order]
+    o.close()
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32))
+    assert_bit_equal(sp, rp, "whole-domain engine pos"); assert_bit_equal(sv, rv, "whole-domain engine vel")
+    assert_bit_equal(gp, rp, "slab pos"); assert_bit_equal(gv, rv, "slab vel"); assert_bit_equal(gd, rd, "slab density")
+
+
 def _single_engine(sphx, nx, steps, seed, solver, adaptive, arith, tweak=None):
     """the single-device ENGINE in the given arithmetic on the slab tests' splash state, ordered by particle id"""
     P, fluid, boundary = sphx.scene(nx)

@@ -18,6 +18,8 @@ for A in tolerance strict; do
   cp gpurun_out/bench_${T}_loopback_8slabs_$A.json profiles/${T}_bench_dfsph10m_loopback_8slabs_one_gpu_$A.json
 done
 [ -s gpurun_out/bench_${T}_rcclself_8slabs.json ] && cp gpurun_out/bench_${T}_rcclself_8slabs.json profiles/${T}_bench_dfsph10m_rccl_self_8slabs_one_gpu.json
+[ -s gpurun_out/bench_${T}_rcclself_8slabs_edgehigh.json ] && cp gpurun_out/bench_${T}_rcclself_8slabs_edgehigh.json profiles/${T}_bench_dfsph10m_rccl_self_8slabs_one_gpu_edge_high.json
+for A in tolerance strict; do [ -s gpurun_out/bench_${T}_plain_$A.json ] && cp gpurun_out/bench_${T}_plain_$A.json profiles/${T}_bench_dfsph10m_plain_${A}_same_call.json; done
 cp gpurun_out/pcie_$T.txt                     profiles/${T}_pcie_inclusive.txt
 cp gpurun_out/probe_$T.txt                    profiles/${T}_probe_per_kernel_hipevents.txt
 cp gpurun_out/small_$T.txt                    profiles/${T}_reference_scene_step_n.txt
