@@ -159,7 +159,7 @@ def test_native_slab_layer_in_tolerance_arithmetic(sphx, oracle, monkeypatch, wo
     on the first steps while differing from it (the tolerance kernels really ran).  PBD: the single-device engine keeps its skin rows
     off here (slabs rebuild their rows per Jacobi iteration, and under the tolerance contract the order of a row decides the bits)."""
     monkeypatch.setenv("SPHX_PBD_SKIN", "0")
-    # (and rows of the slabs' fixed capacity on both sides: a particle whose row overflows walks the cells with the plain operators,
+    # (and rows of one fixed capacity on both sides -- no growth at different moments: a particle whose row overflows walks the cells with the plain operators,
     # which is the same bits under the strict contract only -- the splash has rows beyond the single engine's initial 48 entries)
     monkeypatch.setenv("SPHX_NBR_CAP", "96")
     steps, seed = 6, 17
@@ -534,7 +534,7 @@ def test_native_slab_layer_tolerance_arithmetic_over_the_rccl_transport(sphx, tm
     ONE process driving 4 slabs through the installed librccl (grouped sends to self) -- each bit-identical to the single-device
     tolerance engine, iteration counts included, with moving cuts"""
     nx, steps, seed = (32 if world == 8 else (24 if library.startswith("installed") else 16)), 6, 41
-    monkeypatch.setenv("SPHX_NBR_CAP", "96")          # the slabs' fixed row capacity for the single-device reference too (see above)
+    monkeypatch.setenv("SPHX_NBR_CAP", "96")          # one fixed row capacity for the slabs and the single-device reference (see above)
     if library.startswith("installed"):
         parts = _run_ranks(tmp_path, 1, nx, steps, seed, solver, adaptive, True, None, {"SPHX_TEST_SLABS_PER_PROCESS": str(world), "SPHX_TEST_ARITH": "1"})
         assert "mock" not in str(parts[0]["rccl_library"]) and "librccl" in str(parts[0]["rccl_library"])

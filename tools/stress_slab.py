@@ -2,7 +2,7 @@
 fixed DFSPH, overlap on/off, re-balancing cadence, splash state -- the gathered result must equal the single-domain oracle bit
 for bit.  python tools/stress_slab.py [cases=100] [first_seed=0] [report file]
 ARITH=1: the same cases under the TOLERANCE contract; the reference is then the single-device tolerance ENGINE (bit for bit as well: a
-tolerance result is a function of a particle's row and inputs alone), both sides with the slabs' 96-entry rows and PBD skin rows off."""
+tolerance result is a function of a particle's row and inputs alone), both sides with fixed 96-entry rows (sphx_tuning.row_capacity) and PBD skin rows off."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cpp-fluid-particles_amd"))
