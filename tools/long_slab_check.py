@@ -29,7 +29,7 @@ while done < steps:
     same = np.array_equal(ids, np.arange(len(fluid), dtype=np.int32)) and all(
         np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in ((p, ref.get(sphx.F_POS)[order]), (v, ref.get(sphx.F_VEL)[order]), (d, ref.get(sphx.F_DENSITY)[order])))
     info = [g.info(i) for i in range(world)]
-    print("nx %d %s world %d step %d: %s | rho_max %.3f iters %s cuts %s owned %s" % (nx, solver, world, done, "identical" if same else "DIFFERENT", d.max(), g.iters(),
-          [a for a, _, _, _ in info], [o for _, _, o, _ in info]), flush=True)
+    print("nx %d %s world %d step %d: %s | rho_max %.3f iters %s cuts %s owned %s | row capacity: slabs %s, plain engine %d" % (nx, solver, world, done, "identical" if same else "DIFFERENT", d.max(), g.iters(),
+          [a for a, _, _, _ in info], [o for _, _, o, _ in info], [g.row_capacity(i) for i in range(world)], sphx.row_capacity(ref)), flush=True)
     if not same:
         sys.exit(1)
