@@ -1,5 +1,5 @@
 """Long runs of the native slab layer (loopback, one GPU) against the plain single-device system, through the impact of the column:
-python tools/long_slab_check.py nx world steps [solver=dfsph] [adaptive=1]   -> prints 'identical' per checkpoint or the first difference"""
+python tools/long_slab_check.py nx world steps [solver=dfsph] [adaptive=1] [arith=0]   -> prints 'identical' per checkpoint or the first difference"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-fluid-particles_amd"))
 import numpy as np, sphx
@@ -8,11 +8,13 @@ import tuning_env; tuning_env.install(sphx)      # SPHX_* environment variables 
 nx, world, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 solver = sys.argv[4] if len(sys.argv) > 4 else "dfsph"
 adaptive = (sys.argv[5] if len(sys.argv) > 5 else "1") == "1"
+arith = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # 1: tolerance arithmetic on both sides (pin the rows: SPHX_NBR_CAP=96 SPHX_PBD_SKIN=0, see tests/test_gpu_slab.py)
 P, fluid, boundary = sphx.scene(nx)
 P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver]
 if solver == "wcsph": P.dt = 0.001
 if not adaptive: P.dfsph_fixed_div, P.dfsph_fixed_den = 1, 4
 P.pbd_iters = 4
+P.reserved[3] = arith
 ref = sphx.System(P, fluid, boundary)                      # constructor step = step 1
 g = sphx.SlabGroup(P, fluid, boundary, world)
 g.set_rebalance(4, 0.05)
@@ -29,7 +31,7 @@ while done < steps:
     same = np.array_equal(ids, np.arange(len(fluid), dtype=np.int32)) and all(
         np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in ((p, ref.get(sphx.F_POS)[order]), (v, ref.get(sphx.F_VEL)[order]), (d, ref.get(sphx.F_DENSITY)[order])))
     info = [g.info(i) for i in range(world)]
-    print("nx %d %s world %d step %d: %s | rho_max %.3f iters %s cuts %s owned %s | row capacity: slabs %s, plain engine %d" % (nx, solver, world, done, "identical" if same else "DIFFERENT", d.max(), g.iters(),
+    print(("tolerance arithmetic: " if arith else "") + "nx %d %s world %d step %d: %s | rho_max %.3f iters %s cuts %s owned %s | row capacity: slabs %s, plain engine %d" % (nx, solver, world, done, "identical" if same else "DIFFERENT", d.max(), g.iters(),
           [a for a, _, _, _ in info], [o for _, _, o, _ in info], [g.row_capacity(i) for i in range(world)], sphx.row_capacity(ref)), flush=True)
     if not same:
         sys.exit(1)
