@@ -108,9 +108,10 @@ def run_slab_bench(args, rank, world, local_rank):
         sphx.kernel_timer(False)
         if span in spans and spans[span][1] > 0:
             tot_ms, launches = spans[span]
-            # a stage is launched on the two edge layers (ONE two-range launch) and on the interior: one logical launch = 2 timed
-            # spans per slab (an empty edge range still opens its span)
-            logical = launches / (1.0 if flags else 2.0)              # logical launches of ALL local slabs; each works on `owned` particles
+            # a stage is launched on the edge layers of the sides that have a neighbour (ONE launch) and on the interior: one logical
+            # launch = 2 timed spans per slab; a slab on its own (and the stage-then-exchange schedule) sweeps its particles in one
+            alone = world == 1 and slabs_here == 1
+            logical = launches / (1.0 if (flags or alone) else 2.0)   # logical launches of ALL local slabs; each works on `owned` particles
             avg_ms = tot_ms / logical
             owned = sum(o for _, _, o, _ in infos) / float(slabs_here)
             per_launch = 44.0 * owned                                   # bytes: bench.py RATE_KERNEL_BYTES_PER_PARTICLE
