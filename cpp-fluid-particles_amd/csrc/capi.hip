@@ -514,7 +514,7 @@ int sphx_get(const sphx_system* h, int field, void* dst, size_t bytes)
         std::unique_ptr<DArray<float>> scratch;
         if (slotMap && n > 0 && (sz == 4 * n || sz == 12 * n)) {
             const int live = (int)h->system->getFluids()->size();
-            scratch.reset(new DArray<float>((unsigned)(sz / 4)));
+            scratch.reset(new DArray<float>((unsigned)(sz / 4)));      // zero-filled by DArray: slots past a lowered active count read 0
             if (sz == 4 * n) ew_gather_float(scratch->addr(), static_cast<const float*>(p), slotMap, live);
             else ew_gather_float3(reinterpret_cast<float3*>(scratch->addr()), static_cast<const float3*>(p), slotMap, live);
             p = scratch->addr();

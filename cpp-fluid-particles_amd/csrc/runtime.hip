@@ -611,12 +611,20 @@ void SweepCache::packBoundary(const SPHParticles& boundaries)
     if (boundaryValid && boundaryKey == (const void*)boundaries.getPosPtr() && nb == count) return;
     reserveBoundary(count);
     nb = count;
-    posmAlt.reset(); posfAlt.reset();          // (made again, with this boundary tail, by the next PBD step that wants them)
+    // PBD's second halves of posm / posf (ensureAltPositions) carry the boundary tail too.  They are repacked in place, not dropped:
+    // this runs inside a stream capture when a boundary invalidation made the step re-capture, and a capture may contain neither
+    // hipFree nor hipMalloc.  Halves of another length (reserveBoundary grew the arrays) are already gone.
+    const bool alt = posmAlt && posfAlt && posmAlt->length() == posm.length() && posfAlt->length() == posf.length();
+    if (!alt) { posmAlt.reset(); posfAlt.reset(); }
     ScopedKernel t("pack_boundary");
     if (count > 0) {
         // (x, y, z, mass) into the boundary tail of both position arrays (plain and one-gather view)
         k_pack4<<<blocks_for(count), 256, 0, stream()>>>(fluid4w() + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
         k_pack4<<<blocks_for(count), 256, 0, stream()>>>(posfw() + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
+        if (alt) {
+            k_pack4<<<blocks_for(count), 256, 0, stream()>>>(reinterpret_cast<float4*>(posmAlt->addr()) + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
+            k_pack4<<<blocks_for(count), 256, 0, stream()>>>(reinterpret_cast<float4*>(posfAlt->addr()) + capN, boundaries.getPosPtr(), boundaries.getMassPtr(), count);
+        }
     }
     boundaryKey = (const void*)boundaries.getPosPtr();
     boundaryValid = true;

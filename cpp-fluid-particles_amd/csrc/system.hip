@@ -1069,6 +1069,7 @@ float SPHSystem::stepN(int n)
                 if (gph) (void)hipGraphDestroy(gph);
                 _graph->exec = nullptr;
                 (void)hipGetLastError();
+                _solver->captureFailed();         // the recorded launches never ran: their "valid" marks must not survive
             }
         } else if (say) std::cout << "sphx: capture: could not begin\n";
     };
@@ -1081,6 +1082,14 @@ float SPHSystem::stepN(int n)
     // The hook may invalidate the capture (regrown rows); the next chunk then re-captures.
     const int kChunk = std::max(1, _solver->tuneInterval());
     for (int done = 0; done < n;) {
+        // the persistent mode may have been resumed by the controller between two chunks (256 steps after a suspension): the step
+        // that primes the working copy -- host-side copies, a stream sync in the rebuild request -- must run eagerly, outside
+        // any capture, exactly as in front of the loop
+        if (_persist && !_persist->primed && persistentActive()) {
+            try { enqueueStep(); } catch (const char* msg) { std::cout << msg << "\n"; }
+            ++done; _graph->stepsRun++;
+            continue;
+        }
         ensureGraph();
         const int chunk = std::min(n - done, kChunk);
         for (int s = 0; s < chunk; ++s) {

@@ -27,6 +27,8 @@ void BasicSPHSolver::invalidatePositions() { _cache->invalidatePositions(); }
 void BasicSPHSolver::setEngineFlags(int flags) { _cache->flags = flags; _cache->listValid = false; ++_cache->generation; }
 unsigned int BasicSPHSolver::graphGeneration() const { return _cache->generation; }
 void BasicSPHSolver::prepareForCapture() { _cache->orderAge = 1 << 20; _cache->orderValid = false; }
+// the packs / row build of a discarded capture never ran: the flags they set are taken back
+void BasicSPHSolver::captureFailed() { _cache->boundaryValid = false; _cache->fluidValid = false; _cache->listValid = false; _cache->orderValid = false; }
 void BasicSPHSolver::tune(int stepsSinceLastCall) { _cache->tuneRowCapacity(stepsSinceLastCall); }
 void BasicSPHSolver::setToleranceArithmetic(bool on) { _cache->tolerance = on; ++_cache->generation; }
 void* BasicSPHSolver::engineVel4() const { return _cache->vel4.addr(); }

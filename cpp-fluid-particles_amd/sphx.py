@@ -148,6 +148,9 @@ def device_count():
 def default_tuning():
     t = Tuning()
     _check(lib().sphx_tuning_defaults(C.byref(t)))
+    # the library writes ITS sizeof into struct_size: a layout drift between this binding and sphx_tuning must not pass silently
+    if t.struct_size != C.sizeof(Tuning):
+        raise SphxError("sphx_tuning layout mismatch between sphx.py (%d bytes) and libsphx.so (%d bytes)" % (C.sizeof(Tuning), t.struct_size))
     return t
 
 
@@ -162,6 +165,8 @@ def set_tuning(tuning=None, **fields):
         if not hasattr(t, k):
             raise SphxError("sphx_tuning has no field %r" % k)
         setattr(t, k, v)
+    if tuning is None:
+        t.struct_size = C.sizeof(Tuning)       # (a block the caller built keeps what it says about itself: the library checks it)
     _check(lib().sphx_set_tuning(C.byref(t)))
 
 

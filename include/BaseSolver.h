@@ -29,6 +29,9 @@ public:
     // called right before a step is captured into a hipGraph: anything the solver refreshes only every few steps
     // must be part of the captured step (a replay repeats exactly what was recorded)
     virtual void prepareForCapture() {}
+    // called when that capture was thrown away (the step then runs eagerly): whatever the recorded-but-never-run launches were
+    // meant to refresh is stale and must be redone by the next eager step
+    virtual void captureFailed() {}
     // called between steps (never inside a captured graph) with the number of steps run since the last call: a place
     // for host-side adaptation from device-side statistics; may change graphGeneration()
     virtual void tune(int stepsSinceLastCall) { (void)stepsSinceLastCall; }

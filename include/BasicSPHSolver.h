@@ -30,6 +30,7 @@ public:
     bool graphSafe() const override { return true; }
     unsigned int graphGeneration() const override;
     void prepareForCapture() override;
+    void captureFailed() override;
     void tune(int stepsSinceLastCall) override;      // engine: adaptive neighbour-row capacity
     // engine extensions: the colour gradient left by handleSurface(), and engine switches used by
     // the tests (bit 0: run the reference-structure, unfused sequence of building blocks;

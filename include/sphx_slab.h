@@ -82,7 +82,9 @@ int sphx_slab_gather(sphx_slab_group *g, int index, int capacity, int *ids, floa
                      float *density, int *count);
 /* iteration counts of the last DFSPH step (identical on every rank) */
 int sphx_slab_iters(const sphx_slab_group *g, int *divergence_iters, int *density_iters);
-/* the engine system of local slab `index` (for sphx_kernel_timer / sphx_device_ptr); owned by the group */
+/* the engine system of local slab `index` (for sphx_kernel_timer / sphx_device_ptr); owned by the group.
+ * A slab's system sorts inside the window of cell columns it holds: SPHX_F_CELLSTART_F read from it is defined for the cells of
+ * the held columns (ghost columns included) only; cells outside that window keep whatever an earlier step left there.        */
 int sphx_slab_system(const sphx_slab_group *g, int index, sphx_system **sys);
 /* The transport as it reports itself (bench.py --gpus N puts this into its line so that a scaling run can be checked):
  * transport_kind 0 = loopback copies, 1 = RCCL; comm_ranks / comm_rank = ncclCommCount / ncclCommUserRank of the
