@@ -582,6 +582,153 @@ __global__ void __launch_bounds__(T, MINW) k_self(Consts c, const float4* __rest
     if (PROF && lane == 0) { atomicAdd(&prof[0], tTop); atomicAdd(&prof[1], tPoll); atomicAdd(&prof[2], tComp); atomicAdd(&prof[3], tStage); atomicAdd(&prof[4], (unsigned long long)nIter); atomicAdd(&prof[5], (unsigned long long)nDuty); }
 }
 
+
+// ---- PARK: r03's block-per-brick walk made persistent, the NEXT brick's stage parked in registers while this one is walked ------
+// One stage per block (two 512-thread blocks per CU), one barrier pair per brick.  While brick k is walked, every thread holds the
+// records it will write into the stage for brick k + 1 (NS slots per thread, two fields: 8 NS registers), its own index / slot / row
+// chunks for brick k + 1, and the source indices of brick k + 2's slots.  Nothing a thread needs at the start of a brick is still
+// in flight: no second LDS stage, no loader wave, no flags.
+template <int T, bool TWO, int NS, int NR, int mode = 0, int MINW = 4>
+__global__ void __launch_bounds__(T, MINW) k_park(Consts c, const float4* __restrict__ posm, const float4* __restrict__ vel4,
+                                            const BrickDesc* __restrict__ bricks, const int* __restrict__ stageBase, const int* __restrict__ srcIdx,
+                                            const int* __restrict__ ownIndex, const unsigned short* __restrict__ ownSlot, const float4* __restrict__ ownVel,
+                                            const uint4* __restrict__ rows, const int* __restrict__ waveChunks,
+                                            const int2* __restrict__ blockRanges, float* __restrict__ out, int slots)
+{
+    extern __shared__ float4 lds[];
+    float4* lpos = lds;
+    float4* lvel = lds + slots;
+    const int2 Rg = blockRanges[logical_block()];
+    const int kFirst = Rg.x, kLast = Rg.y;
+    if (kFirst >= kLast) return;
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float4 far = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-thread state of a brick: own particle (round 0), first NR row chunks, the wave's chunk count
+    struct Own { int i, self, chunks, chunksRound; float4 sv; uint4 r[NR]; };
+    auto loadOwn = [&](const BrickDesc& B, int blk, Own& o) {
+        const bool has = t < B.own;
+        o.i = has ? ownIndex[B.ownFirst + t] : -1;
+        o.self = has ? (int)ownSlot[B.ownFirst + t] : B.staged;
+        o.chunks = waveChunks[(size_t)(blk * 8) * 17 + wave];
+        o.chunksRound = waveChunks[(size_t)(blk * 8) * 17 + 16];
+        o.sv = (!TWO && has) ? ownVel[B.ownFirst + t] : make_float4(0.f, 0.f, 0.f, 0.f);      // (one-field form only: the engine's own fields sit in the stage)
+        const uint4* row = rows + (size_t)B.rowBase * T + t;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) o.r[u] = row[(size_t)u * T];          // (the rows array is padded: chunks past this brick's belong to the next)
+    };
+    BrickDesc B = bricks[kFirst];
+    {   // the block's first brick goes straight into the stage
+        const int sb = stageBase[kFirst];
+        for (int s = t; s < B.staged; s += T) {
+            const int src = srcIdx[sb + s];
+            lpos[s] = posm[src];
+            if (TWO) lvel[s] = vel4[src];
+        }
+        if (t == 0) { lpos[B.staged] = far; if (TWO) lvel[B.staged] = zero; }
+    }
+    Own cur; loadOwn(B, kFirst, cur);
+    int S[NS];                                                      // source indices of the NEXT brick's slots t, t + T, ...
+    {
+        const BrickDesc Bn = bricks[min(kFirst + 1, kLast)];      // (bricks[] has one entry past the end)
+        const int sb = stageBase[min(kFirst + 1, kLast)];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { const int s = t + T * j; S[j] = (kFirst + 1 < kLast && s < Bn.staged) ? srcIdx[sb + s] : -1; }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = kFirst; k < kLast; ++k) {
+        const bool more = k + 1 < kLast;
+        const BrickDesc Bn = bricks[min(k + 1, kLast)];
+        // 1. the next brick's records (parked until the walk is over) ...
+        float4 P[NS], V[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            P[j] = zero; V[j] = zero;
+            if (S[j] >= 0) { P[j] = posm[S[j]]; if (TWO) V[j] = vel4[S[j]]; }
+        }
+        // ... its own / row words, and the source indices of the brick after it
+        Own nxt; nxt.i = -1; nxt.self = 0; nxt.chunks = 0; nxt.chunksRound = 0; nxt.sv = zero;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) nxt.r[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (more) loadOwn(Bn, k + 1, nxt);
+        int Sn[NS];
+        {
+            const BrickDesc Bnn = bricks[min(k + 2, kLast)];
+            const int sb = stageBase[min(k + 2, kLast)];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { const int s = t + T * j; Sn[j] = (k + 2 < kLast && s < Bnn.staged) ? srcIdx[sb + s] : -1; }
+        }
+        // 2. walk this brick.  Round 0 (every brick; its inputs are in registers: no memory instruction in the loop) ...
+        auto pairs8 = [&](const uint4 curw, const float4 sp, const float4 sv, float& e) {
+            const unsigned int w[4] = {curw.x, curw.y, curw.z, curw.w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 pj[4], vj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned int word = w[h * 2 + (u >> 1)];
+                    unsigned int slot = (u & 1) ? (word >> 16) : (word & 0xffffu);
+                    if (mode == 1) slot = (slot & 0x7c0u) + (t & 63);                 // ablation: conflict-free slots (one record per lane, consecutive)
+                    if (mode == 3) { pj[u] = make_float4(sp.x + slot * 1e-3f, sp.y, sp.z, sp.w); vj[u] = sv; continue; }      // ablation: no LDS reads
+                    pj[u] = lpos[slot];
+                    vj[u] = TWO ? lvel[slot] : make_float4(pj[u].w, 0.f, 0.f, 0.f);
+                }
+                if (mode == 2) { for (int u = 0; u < 4; ++u) e += pj[u].x + vj[u].y; continue; }               // ablation: no pair arithmetic
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e += pair_tol(c, sp.x, sp.y, sp.z, sv.x, sv.y, sv.z, pj[u], vj[u]);
+            }
+        };
+        {
+            const float4 sp = lpos[cur.self];
+            const float4 sv = TWO ? lvel[cur.self] : cur.sv;
+            float e = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < NR; ++ch) if (ch < cur.chunks) pairs8(cur.r[ch], sp, sv, e);
+            if (__builtin_expect(cur.chunks > NR, 0)) {
+                const uint4* row = rows + (size_t)B.rowBase * T + t;
+#pragma unroll 1
+                for (int ch = NR; ch < cur.chunks; ++ch) pairs8(row[(size_t)ch * T], sp, sv, e);
+            }
+            if (cur.i >= 0) out[cur.i] = e;
+        }
+        // ... further rounds (bricks with more than T own particles): unpipelined
+        if (__builtin_expect(B.rounds > 1, 0)) {
+            int rowAt = B.rowBase + cur.chunksRound;
+#pragma unroll 1
+            for (int rd = 1; rd < B.rounds; ++rd) {
+                const int p = rd * T + t;
+                const bool has = p < B.own;
+                const int i = has ? ownIndex[B.ownFirst + p] : -1;
+                const int self = has ? (int)ownSlot[B.ownFirst + p] : B.staged;
+                const int chunks = waveChunks[(size_t)(k * 8 + rd) * 17 + wave], chunksRound = waveChunks[(size_t)(k * 8 + rd) * 17 + 16];
+                const float4 sp = lpos[self];
+                const float4 sv = TWO ? lvel[self] : ((!TWO && has) ? ownVel[B.ownFirst + p] : zero);
+                const uint4* row = rows + (size_t)rowAt * T + t;
+                float e = 0.0f;
+#pragma unroll 1
+                for (int ch = 0; ch < chunks; ++ch) pairs8(row[(size_t)ch * T], sp, sv, e);
+                if (i >= 0) out[i] = e;
+                rowAt += chunksRound;
+            }
+        }
+        // 3. everyone is done reading: the parked records become the stage
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) if (S[j] >= 0) { lpos[t + T * j] = P[j]; if (TWO) lvel[t + T * j] = V[j]; }
+            if (Bn.staged > NS * T) {                               // (a stage beyond NS slots per thread: the rest unpipelined)
+                const int sb = stageBase[k + 1];
+                for (int s = t + NS * T; s < Bn.staged; s += T) { const int src = srcIdx[sb + s]; lpos[s] = posm[src]; if (TWO) lvel[s] = vel4[src]; }
+            }
+            if (t == 0) { lpos[Bn.staged] = far; if (TWO) lvel[Bn.staged] = zero; }
+        }
+        __syncthreads();
+        B = Bn; cur = nxt;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) S[j] = Sn[j];
+    }
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------------
 int main(int argc, char** argv)
 {
@@ -794,6 +941,61 @@ int main(int argc, char** argv)
                 run(nm, two, [&] { hipLaunchKernelGGL((k_brick<512, true>), dim3(grid), dim3(512), ldsBytes, st, c, dPos, dVel, dDesc, dRuns, dOwnIdx, dOwnSlot, dRowsB, dWch, dOut, numBricks, slots); }); }
             else { CK(hipFuncSetAttribute((const void*)k_brick<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
                 run(nm, two, [&] { hipLaunchKernelGGL((k_brick<512, false>), dim3(grid), dim3(512), ldsBytes, st, c, dPos, dVel, dDesc, dRuns, dOwnIdx, dOwnSlot, dRowsB, dWch, dOut, numBricks, slots); }); }
+        }
+
+        {   // ---- PARK ----
+            std::vector<int> stageBaseH(numBricks + 1, 0), srcIdxH;
+            for (int blk = 0; blk < numBricks; ++blk) {
+                stageBaseH[blk] = (int)srcIdxH.size();
+                for (auto& r : HB[blk].runs) for (int j = 0; j < r.len; ++j) srcIdxH.push_back(r.start + j);
+            }
+            stageBaseH[numBricks] = (int)srcIdxH.size();
+            srcIdxH.resize(srcIdxH.size() + 8192, 0);
+            descs.push_back(BrickDesc{0, 0, 0, 0, 0, (int)rowChunkRows, 0});
+            int *dStageBase, *dSrcIdx; int2* dRangesP; BrickDesc* dDescP; uint4* dRowsP; int* dWchP; float4* dOwnVel;
+            { std::vector<float4> ov(ownIdx.size() + 1024); for (size_t q2 = 0; q2 < ownIdx.size(); ++q2) ov[q2] = vel4[ownIdx[q2]];
+              CK(hipMalloc(&dOwnVel, sizeof(float4) * ov.size())); CK(hipMemcpy(dOwnVel, ov.data(), sizeof(float4) * ov.size(), hipMemcpyHostToDevice)); }
+            std::vector<uint4> rowsPad(rowsFlat); rowsPad.resize(rowsPad.size() + (size_t)8 * T, make_uint4(0, 0, 0, 0));
+            std::vector<int> wchPad(wch.begin(), wch.end()); wchPad.resize(wchPad.size() + 8 * 17, 0);      // (int, not byte: hipcc converts a byte right behind its load, i.e. waits for it)
+            CK(hipMalloc(&dStageBase, 4 * stageBaseH.size())); CK(hipMalloc(&dSrcIdx, 4 * srcIdxH.size())); CK(hipMalloc(&dDescP, sizeof(BrickDesc) * descs.size()));
+            CK(hipMalloc(&dRowsP, sizeof(uint4) * rowsPad.size())); CK(hipMalloc(&dWchP, 4 * wchPad.size()));
+            CK(hipMemcpy(dStageBase, stageBaseH.data(), 4 * stageBaseH.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dSrcIdx, srcIdxH.data(), 4 * srcIdxH.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dDescP, descs.data(), sizeof(BrickDesc) * descs.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dRowsP, rowsPad.data(), sizeof(uint4) * rowsPad.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dWchP, wchPad.data(), 4 * wchPad.size(), hipMemcpyHostToDevice));
+            auto ranges = [&](int nblk) {
+                std::vector<int2> rg(nblk); long long tot = 0; for (auto& Bk : HB) tot += (long long)Bk.own.size();
+                int kk = 0; long long acc = 0;
+                for (int b = 0; b < nblk; ++b) {
+                    const long long target = tot * (b + 1) / nblk; const int first = kk;
+                    while (kk < numBricks && acc + (long long)HB[kk].own.size() <= target) { acc += (long long)HB[kk].own.size(); ++kk; }
+                    if (b == nblk - 1) kk = numBricks;
+                    rg[b] = make_int2(first, kk);
+                }
+                CK(hipMalloc(&dRangesP, sizeof(int2) * nblk));
+                CK(hipMemcpy(dRangesP, rg.data(), sizeof(int2) * nblk, hipMemcpyHostToDevice));
+            };
+#define PARK(TW, NSS, NRR, BPC, MODE)                                                                                                 \
+    do {                                                                                                                        \
+        const size_t ldsBytes = (size_t)slots * 16 * ((TW) ? 2 : 1);                                                            \
+        const int nblk = numCUs * (BPC);                                                                                        \
+        ranges(nblk);                                                                                                           \
+        char nm[96]; snprintf(nm, sizeof(nm), "PARK T=512 NS=%d NR=%d x%d/CU tol %s%s (%zu KB)", NSS, NRR, BPC, (TW) ? "2f" : "1f", MODE == 0 ? "" : (MODE == 1 ? " CONFLICT-FREE" : (MODE == 2 ? " NO-ARITH" : " NO-LDS")), ldsBytes / 1024); \
+        CK(hipFuncSetAttribute((const void*)k_park<512, TW, NSS, NRR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        run(nm, (TW) ? 1 : 0, [&] { hipLaunchKernelGGL((k_park<512, TW, NSS, NRR, MODE>), dim3(nblk), dim3(512), ldsBytes, st, c, dPos, dVel, dDescP, dStageBase, dSrcIdx, dOwnIdx, dOwnSlot, dOwnVel, dRowsP, dWchP, dRangesP, dOut, slots); }); \
+        CK(hipFree(dRangesP));                                                                                                  \
+    } while (0)
+            PARK(true, 4, 2, 2, 0);
+            PARK(true, 4, 2, 2, 1);
+            PARK(true, 4, 2, 2, 2);
+            PARK(true, 4, 2, 2, 3);
+            PARK(false, 4, 4, 2, 0);
+            PARK(false, 4, 4, 2, 1);
+            PARK(false, 4, 4, 2, 2);
+            PARK(false, 4, 4, 2, 3);
+#undef PARK
+            CK(hipFree(dStageBase)); CK(hipFree(dSrcIdx)); CK(hipFree(dDescP)); CK(hipFree(dRowsP)); CK(hipFree(dWchP));
         }
         CK(hipFree(dDesc)); CK(hipFree(dRuns)); CK(hipFree(dOwnIdx)); CK(hipFree(dOwnSlot)); CK(hipFree(dRowsB)); CK(hipFree(dWch));
     }
