@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -257,15 +258,16 @@ struct RcclTransport final : Transport {
 // and scan arrays (24 bytes written, 48 scanned, 24 read back per particle): a counting pass leaves three counts per BLOCK of 256
 // particles, the scan runs over those, and the packing pass recomputes the flags and ranks them inside the block with ballots.
 struct SlabClass {
-    float cellLength; int x0, x1, g, hasLeft, hasRight, slackL, slackR;
+    float cellLength; int x0, x1, g, hasLeft, hasRight, loOK, hiOK;
     __device__ __forceinline__ int column(const float3 p) const { return (int)(p.x / cellLength); }
     __device__ __forceinline__ int left(int col) const { return (hasLeft && col <= x0 + g - 1) ? 1 : 0; }
     __device__ __forceinline__ int right(int col) const { return (hasRight && col >= x1 - g) ? 1 : 0; }
     // still inside this slab's ghost range?  (after a cut moved, a former owner may hold particles two columns out:
     // they travel to the neighbour like every migrant and are dropped here)
     __device__ __forceinline__ int kept(int col) const { return (col >= x0 - g && col <= x1 + g - 1) ? 1 : 0; }
-    // moved more than one column in one step (a cut that itself moved this step widens the allowance by its shift)
-    __device__ __forceinline__ bool crossed(int col) const { return col < x0 - 1 - slackL || col > x1 + slackR; }
+    // travelled farther than ONE exchange reaches (columns [loOK, hiOK] are fine: sphx_slab_group::reach): the step then takes the
+    // hop-by-hop path (sphx_slab_group::forwardFarFlyers)
+    __device__ __forceinline__ bool crossed(int col) const { return col < loOK || col > hiOK; }
 };
 constexpr int kSlabBlock = 256;
 // exclusive rank of this thread among the threads of its block with flag set, and the block's total (all threads call it; the
@@ -307,14 +309,15 @@ __global__ void k_slab_prepare(long long* __restrict__ counts, int* __restrict__
     if (t == 13) *violation = 0;
 }
 
-// the failure word of a slab for this step, formed on the device once the neighbours' size messages have arrived: crossed = 1,
-// capacity = 1 << 20 (the encoding the host reports from); added to the process's word, which is all-reduced on the stream
+// the failure word of a slab for this step, formed on the device once the neighbours' size messages have arrived: capacity = 1 << 20
+// (the encoding the host reports from), a particle beyond the reach of one exchange = 1 << 40 (not a failure: every rank then takes
+// the hop-by-hop path of this step together); added to the process's word, which is all-reduced on the stream
 __global__ void k_slab_verdict(const long long* __restrict__ counts, const int* __restrict__ violation, long long capacity, int hasLeft,
                                int hasRight, long long inject, unsigned long long* __restrict__ processBad)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long bad = inject;
-    if (*violation != 0) bad += 1;
+    if (*violation != 0) bad += 1LL << 40;
     const long long rl = hasLeft ? counts[6] : 0, rr = hasRight ? counts[9] : 0;
     if (counts[12] + rl + rr > capacity) bad += 1LL << 20;
     if (bad) atomicAdd(processBad, (unsigned long long)bad);
@@ -366,6 +369,41 @@ __global__ void k_slab_unpack(float3* __restrict__ pos, float3* __restrict__ vel
     for (int e = 0; e < E; ++e) extra[(size_t)t * E + e] = row[7 + e];
 }
 
+// ---- rows that arrived from a neighbour in a hop-by-hop step: which stay here (owned or ghost), which travel on --------------------
+// dir 0: the rows came from the LEFT neighbour (they travel right), dir 1: from the right.  Stable, like k_slab_count / k_slab_pack.
+__global__ void __launch_bounds__(kSlabBlock) k_rows_count(const float* __restrict__ rows, int n, int W, SlabClass c, int dir,
+                                                           int* __restrict__ blockK, int* __restrict__ blockF)
+{
+    const int k = blockIdx.x * kSlabBlock + threadIdx.x;
+    int fk = 0, ff = 0;
+    if (k < n) {
+        const int col = c.column(make_float3(rows[(size_t)k * W], 0.0f, 0.0f));
+        fk = c.kept(col); ff = dir == 0 ? c.right(col) : c.left(col);
+    }
+    int tk, tf;
+    (void)block_rank_256(fk, 0, &tk); (void)block_rank_256(ff, 1, &tf);
+    if (threadIdx.x == 0) { blockK[blockIdx.x] = tk; blockF[blockIdx.x] = tf; }
+}
+__global__ void __launch_bounds__(kSlabBlock) k_rows_pack(const float* __restrict__ rows, int n, int W, SlabClass c, int dir,
+                                                          const int* __restrict__ blockK, const int* __restrict__ blockF,
+                                                          float* __restrict__ keep, float* __restrict__ fwd, long long* __restrict__ outCounts)
+{
+    const int k = blockIdx.x * kSlabBlock + threadIdx.x;
+    int fk = 0, ff = 0;
+    if (k < n) {
+        const int col = c.column(make_float3(rows[(size_t)k * W], 0.0f, 0.0f));
+        fk = c.kept(col); ff = dir == 0 ? c.right(col) : c.left(col);
+    }
+    int tk, tf;
+    const int rk = blockK[blockIdx.x] + block_rank_256(fk, 0, &tk), rf = blockF[blockIdx.x] + block_rank_256(ff, 1, &tf);
+    if (k < n) {
+        const float* src = rows + (size_t)k * W;
+        if (fk) { float* d = keep + (size_t)rk * W; for (int t = 0; t < W; ++t) d[t] = src[t]; }
+        if (ff) { float* d = fwd + (size_t)rf * W; for (int t = 0; t < W; ++t) d[t] = src[t]; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { outCounts[0] = blockK[blockIdx.x] + tk; outCounts[1] = blockF[blockIdx.x] + tf; }
+}
+
 __global__ void k_slab_pick6(const int* __restrict__ cellStart, int i0, int i1, int i2, int i3, int i4, int i5, int* __restrict__ out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -401,6 +439,9 @@ struct Slab {
     // scratch
     DevBuf<int> blockL, blockR, blockK, blockSums, violation, layerOut;      // per block of 256 owned particles: rows for the left / right neighbour / kept
     DevBuf<float> own, sendL, sendR, recvL, recvR;
+    DevBuf<float> farBuf;                     // hop-by-hop steps: rows in transit and the kept rows of the later hops (allocated by the first such step)
+    DevBuf<long long> farCounts;              // [0,1] kept / forwarded of the rows from the left, [2,3] from the right, [4] to left [5] to right [6] from left [7] from right
+    long long* hFar = nullptr;                // pinned copy
     // size messages, 3 x int64 each: {payload particles, owned particles, width in columns}
     //   [0..2] to left  [3..5] to right  [6..8] from left  [9..11] from right   [12] owned particles kept here
     DevBuf<long long> counts;
@@ -413,6 +454,7 @@ struct Slab {
         if (sys) sphx_destroy(sys);
         if (hCounts) (void)hipHostFree(hCounts);
         if (hInts) (void)hipHostFree(hInts);
+        if (hFar) (void)hipHostFree(hFar);
         if (layersReady) (void)hipEventDestroy(layersReady);
     }
     int width() const { return 7 + extraFloats; }
@@ -506,6 +548,29 @@ struct sphx_slab_group {
         if (-diff > (double)ownedA * tol && -diff > (double)ownedB / (double)std::max(widthB, 1) && widthB >= minShrinkable) return +1;
         return 0;
     }
+    // How far an owned particle may travel in one step.  A migrant goes to the ADJACENT slab, and the exchange is complete as long as
+    // (a) the column it lands in is owned by that neighbour and (b) is not one of the neighbour's FAR edge columns -- those are ghost
+    // columns of the slab beyond, which takes its ghosts from what the neighbour owned BEFORE this step.  Everything nearer is
+    // handled by the one exchange there is: the pre-sort order [from left | kept | from right] is the global order of the last
+    // step for any displacement, the sender keeps what stays in its own ghost range, the receiver sorts what it is handed.
+    // So the reach is the neighbour's width minus its ghost width (minus one column for a far cut that moves in this very step),
+    // not one column (r02-r05): 20+ columns at 8 slabs of the 10.3 M scene, i.e. |v| dt of most of a slab.  The end slabs own the
+    // rest of the domain on their outer side: no limit there.  Widths are the ones exchanged with the last size messages (the
+    // planned ones before the first step); [x0b, x1b) is this slab's range before this step's own cut moves.
+    static void reach(const Slab& s, int x0b, int x1b, int slackL, int slackR, int& loOK, int& hiOK)
+    {
+        loOK = INT_MIN / 2; hiOK = INT_MAX / 2;
+        if (s.hasLeft) {
+            const int oneColumn = s.x0 - 1 - slackL;                                  // (the r02 rule: always safe)
+            loOK = s.rank >= 2 ? std::min(oneColumn, x0b - s.widthLeft + s.ghost + 1) : (s.widthLeft > 0 ? INT_MIN / 2 : oneColumn);
+            if (s.widthLeft <= 0) loOK = oneColumn;
+        }
+        if (s.hasRight) {
+            const int oneColumn = s.x1 + slackR;
+            hiOK = s.rank + 2 < s.world ? std::max(oneColumn, x1b + s.widthRight - s.ghost - 2) : (s.widthRight > 0 ? INT_MAX / 2 : oneColumn);
+            if (s.widthRight <= 0) hiOK = oneColumn;
+        }
+    }
     void rebalance(Slab& s, int& slackL, int& slackR)
     {
         slackL = slackR = 0;
@@ -527,13 +592,16 @@ struct sphx_slab_group {
         for (auto& sp : slabs) {
             Slab& s = *sp;
             int slackL = 0, slackR = 0;
+            const int x0b = s.x0, x1b = s.x1;
             rebalance(s, slackL, slackR);
+            int loOK = 0, hiOK = 0;
+            reach(s, x0b, x1b, slackL, slackR, loOK, hiOK);
             const int m = s.o1 - s.o0;
             // size words that do not come from the device: owned count and width, for both neighbours
             s.sentOwned = m; s.sentWidth = s.x1 - s.x0;
             k_slab_prepare<<<1, 64, 0, st>>>(s.counts.p, s.violation.p, (long long)m, (long long)(s.x1 - s.x0));
             if (m > 0) {
-                const SlabClass cls{s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, slackL, slackR};
+                const SlabClass cls{s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, loOK, hiOK};
                 const int blocks = (m - 1) / kSlabBlock + 1;
                 k_slab_count<<<blocks, kSlabBlock, 0, st>>>(s.pos + s.o0, m, cls, s.blockL.p, s.blockR.p, s.blockK.p, s.violation.p);
                 device_exclusive_scan3(s.blockL.p, s.blockR.p, s.blockK.p, blocks, s.blockSums.p);      // over the BLOCK counts: a few thousand words
@@ -582,9 +650,9 @@ struct sphx_slab_group {
         SLAB_TRACE("size exchange: synchronised", 0);
         const long long bad = hBad[0], anyBad = hBad[1];
         SLAB_TRACE("failure word reduced", anyBad);
-        if (anyBad) {
-            const char* here = bad ? "this process" : "another rank";
-            if (anyBad & ((1LL << 20) - 1)) die(std::string("slab: a particle crossed more than one cell column in one step (") + here + ")");
+        const bool farStep = (anyBad >> 40) != 0;            // somewhere a particle flew past the reach of one exchange
+        if ((anyBad >> 20) & ((1LL << 20) - 1)) {
+            const char* here = ((bad >> 20) & ((1LL << 20) - 1)) ? "this process" : "another rank";
             die(std::string("slab: capacity exceeded (particles piled up in one slab; ") + here + ")");
         }
         for (auto& sp : slabs) {
@@ -597,9 +665,15 @@ struct sphx_slab_group {
             if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.sendR.p, (size_t)sr * rowBytes}); recvs.push_back({s.rank + 1, s.rank, s.recvR.p, (size_t)rr * rowBytes}); }
         }
         transport->exchange(sends, recvs, false);
-        for (auto& sp : slabs) {
-            Slab& s = *sp;
-            const int m = (int)s.hCounts[12], nl = s.hasLeft ? (int)s.hCounts[6] : 0, nr = s.hasRight ? (int)s.hCounts[9] : 0;   // m: kept
+        std::vector<int> nlv(slabs.size()), nrv(slabs.size());
+        for (size_t i = 0; i < slabs.size(); ++i) {
+            nlv[i] = slabs[i]->hasLeft ? (int)slabs[i]->hCounts[6] : 0;
+            nrv[i] = slabs[i]->hasRight ? (int)slabs[i]->hCounts[9] : 0;
+        }
+        if (farStep) forwardFarFlyers(nlv, nrv);
+        for (size_t i = 0; i < slabs.size(); ++i) {
+            Slab& s = *slabs[i];
+            const int m = (int)s.hCounts[12], nl = nlv[i], nr = nrv[i];   // m: kept
             const int n = nl + m + nr;
             // DFSPH / WCSPH: the rows [from left | kept | from right] ARE the pre-sort order of this step; the SEARCH stage sorts them
             // straight into the engine's arrays (no unpack pass, no copy back, the warm stiffness arrives sorted).  PBD unpacks.
@@ -610,6 +684,118 @@ struct sphx_slab_group {
                 k_slab_unpack<<<blocks_for(n), 256, 0, st>>>(s.pos, s.vel, s.ids, s.extra, s.extraFloats, s.recvL.p, nl, s.own.p, m, s.recvR.p, nr);
             s.sys->system->getFluids()->setActiveCount((unsigned)n);
             s.held = n;
+        }
+    }
+
+    // ---- hop by hop: a step in which some particle flew past the reach of one exchange (r06) -----------------------------------------
+    // The first exchange has delivered every owned particle that left its slab to the ADJACENT slab, whatever column it landed in.
+    // Now the rows a slab received are looked at with the same two questions the owned particles were asked: does this slab hold the
+    // column (as owner or as ghost) -> keep a copy; does the neighbour on the far side need it (owner or ghost) -> send it on.  Rows
+    // keep their direction, every hop is one grouped send/recv with both neighbours, and the hops end when no rank has sent anything
+    // on (one all-reduce per hop).  Order: rows that arrive from the left in a LATER hop come from slabs farther left, i.e. from lower
+    // global indices of the last step: the pre-sort order is [kept of hop J | ... | kept of hop 1 | own | kept of hop 1 | ... | hop J],
+    // each part in its sender's order -- the global order of the last step again, so the stable cell sort still reproduces the
+    // single-device permutation (/root/reference/src/SPHSystem.cu:114-127 re-bins any displacement).
+    // Cost: two small kernels per side and hop, one host wait and one blocking all-reduce per hop -- in steps that need it only
+    // (a particle beyond the reach of one exchange: |v| dt of most of a slab).
+    void forwardFarFlyers(std::vector<int>& nlv, std::vector<int>& nrv)
+    {
+        hipStream_t st = sphx::stream();
+        struct Chunk { const float* p; long long rows; };
+        const size_t S = slabs.size();
+        std::vector<std::vector<Chunk>> keptL(S), keptR(S);
+        std::vector<const float*> curL(S), curR(S);       // the rows that arrived in the last hop
+        std::vector<long long> curNl(S), curNr(S), farUsed(S, 0);
+        for (size_t i = 0; i < S; ++i) {
+            Slab& s = *slabs[i];
+            if (!s.farBuf.p) s.farBuf.alloc((size_t)s.capacity * (size_t)s.width());
+            curL[i] = s.recvL.p; curR[i] = s.recvR.p; curNl[i] = nlv[i]; curNr[i] = nrv[i];
+        }
+        for (int hop = 1; hop <= world + 1; ++hop) {
+            if (hop > world) die("slab: rows still in transit after as many hops as there are slabs");
+            // classify what arrived: kept rows and rows to send on.  Hop 1 keeps into the (now idle) send buffers of the first
+            // exchange, later hops into the transit buffer; forwarded rows always go into the transit buffer.
+            std::vector<float*> fwdL(S, nullptr), fwdR(S, nullptr);
+            for (size_t i = 0; i < S; ++i) {
+                Slab& s = *slabs[i];
+                const int W = s.width();
+                const SlabClass cls{s.cellLength, s.x0, s.x1, s.ghost, s.hasLeft ? 1 : 0, s.hasRight ? 1 : 0, 0, 0};
+                hip_ok(hipMemsetAsync(s.farCounts.p, 0, 8 * sizeof(long long), st), "memset");
+                auto take = [&](long long rows) {
+                    if ((farUsed[i] + rows) * W > (long long)s.farBuf.count) die("slab: too many rows in transit in one step (hop-by-hop buffer)");
+                    float* p = s.farBuf.p + (size_t)farUsed[i] * W; farUsed[i] += rows; return p;
+                };
+                float* keepLp = hop == 1 ? s.sendL.p : take(curNl[i]);
+                float* keepRp = hop == 1 ? s.sendR.p : take(curNr[i]);
+                fwdR[i] = take(curNl[i]); fwdL[i] = take(curNr[i]);          // rows from the left travel right and the other way round
+                if (curNl[i] > 0) {
+                    const int blocks = (int)((curNl[i] - 1) / kSlabBlock + 1);
+                    k_rows_count<<<blocks, kSlabBlock, 0, st>>>(curL[i], (int)curNl[i], W, cls, 0, s.blockK.p, s.blockR.p);
+                    device_exclusive_scan3(s.blockL.p, s.blockR.p, s.blockK.p, blocks, s.blockSums.p);
+                    k_rows_pack<<<blocks, kSlabBlock, 0, st>>>(curL[i], (int)curNl[i], W, cls, 0, s.blockK.p, s.blockR.p, keepLp, fwdR[i], s.farCounts.p + 0);
+                }
+                if (curNr[i] > 0) {
+                    const int blocks = (int)((curNr[i] - 1) / kSlabBlock + 1);
+                    k_rows_count<<<blocks, kSlabBlock, 0, st>>>(curR[i], (int)curNr[i], W, cls, 1, s.blockK.p, s.blockL.p);
+                    device_exclusive_scan3(s.blockL.p, s.blockR.p, s.blockK.p, blocks, s.blockSums.p);
+                    k_rows_pack<<<blocks, kSlabBlock, 0, st>>>(curR[i], (int)curNr[i], W, cls, 1, s.blockK.p, s.blockL.p, keepRp, fwdL[i], s.farCounts.p + 2);
+                }
+                keptL[i].push_back({keepLp, 0}); keptR[i].push_back({keepRp, 0});
+                // what goes on: [4] to the left = forwarded rows that came from the right, [5] to the right = those that came from the left
+                hip_ok(hipMemcpyAsync(s.farCounts.p + 4, s.farCounts.p + 3, sizeof(long long), hipMemcpyDeviceToDevice, st), "count");
+                hip_ok(hipMemcpyAsync(s.farCounts.p + 5, s.farCounts.p + 1, sizeof(long long), hipMemcpyDeviceToDevice, st), "count");
+                if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, s.farCounts.p + 4, 8}); recvs.push_back({s.rank - 1, s.rank, s.farCounts.p + 6, 8}); }
+                if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, s.farCounts.p + 5, 8}); recvs.push_back({s.rank + 1, s.rank, s.farCounts.p + 7, 8}); }
+            }
+            transport->exchange(sends, recvs, false);
+            for (auto& sp : slabs) hip_ok(hipMemcpyAsync(sp->hFar, sp->farCounts.p, 8 * sizeof(long long), hipMemcpyDeviceToHost, st), "far counts");
+            sync("particle exchange (hop by hop)");
+            long long inTransit = 0;
+            for (size_t i = 0; i < S; ++i) {
+                Slab& s = *slabs[i];
+                keptL[i].back().rows = s.hFar[0]; keptR[i].back().rows = s.hFar[2];
+                if (!s.hasLeft) s.hFar[4] = s.hFar[6] = 0;
+                if (!s.hasRight) s.hFar[5] = s.hFar[7] = 0;
+                inTransit += s.hFar[4] + s.hFar[5];
+            }
+            int kind = 0, ranks = 0, rk = 0;
+            transport->describe(kind, ranks, rk);
+            if (world > (int)slabs.size() || kind == 1) inTransit = transport->allreduce_sum(inTransit);
+            SLAB_TRACE("hop: rows sent on", inTransit);
+            if (inTransit == 0) break;
+            for (size_t i = 0; i < S; ++i) {
+                Slab& s = *slabs[i];
+                const int W = s.width();
+                const size_t rowBytes = sizeof(float) * (size_t)W;
+                auto take = [&](long long rows) {
+                    if ((farUsed[i] + rows) * W > (long long)s.farBuf.count) die("slab: too many rows in transit in one step (hop-by-hop buffer)");
+                    float* p = s.farBuf.p + (size_t)farUsed[i] * W; farUsed[i] += rows; return p;
+                };
+                float* inL = take(s.hFar[6]); float* inR = take(s.hFar[7]);
+                if (s.hasLeft) { sends.push_back({s.rank, s.rank - 1, fwdL[i], (size_t)s.hFar[4] * rowBytes}); recvs.push_back({s.rank - 1, s.rank, inL, (size_t)s.hFar[6] * rowBytes}); }
+                if (s.hasRight) { sends.push_back({s.rank, s.rank + 1, fwdR[i], (size_t)s.hFar[5] * rowBytes}); recvs.push_back({s.rank + 1, s.rank, inR, (size_t)s.hFar[7] * rowBytes}); }
+                curL[i] = inL; curR[i] = inR; curNl[i] = s.hFar[6]; curNr[i] = s.hFar[7];
+            }
+            transport->exchange(sends, recvs, false);
+        }
+        // the kept rows of all hops, in the global order of the last step, back into the receive buffers of the first exchange
+        for (size_t i = 0; i < S; ++i) {
+            Slab& s = *slabs[i];
+            const size_t rowBytes = sizeof(float) * (size_t)s.width();
+            long long nl = 0, nr = 0, total = (long long)s.hCounts[12];
+            for (auto& c : keptL[i]) total += c.rows;
+            for (auto& c : keptR[i]) total += c.rows;
+            if (total > s.capacity) die("slab: capacity exceeded (particles piled up in one slab; this process)");
+            for (size_t h = keptL[i].size(); h-- > 0;) {           // farthest hop first
+                const Chunk& c = keptL[i][h];
+                if (c.rows) hip_ok(hipMemcpyAsync(s.recvL.p + (size_t)nl * s.width(), c.p, (size_t)c.rows * rowBytes, hipMemcpyDeviceToDevice, st), "kept rows");
+                nl += c.rows;
+            }
+            for (const Chunk& c : keptR[i]) {
+                if (c.rows) hip_ok(hipMemcpyAsync(s.recvR.p + (size_t)nr * s.width(), c.p, (size_t)c.rows * rowBytes, hipMemcpyDeviceToDevice, st), "kept rows");
+                nr += c.rows;
+            }
+            nlv[i] = (int)nl; nrv[i] = (int)nr;
         }
     }
 
@@ -1065,6 +1251,7 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             std::unique_ptr<Slab> S(new Slab());
             Slab& s = *S;
             s.rank = r; s.world = world; s.x0 = cuts[r]; s.x1 = cuts[r + 1]; s.ghost = ghost;
+            s.widthLeft = r > 0 ? cuts[r] - cuts[r - 1] : 0; s.widthRight = r + 1 < world ? cuts[r + 2] - cuts[r + 1] : 0;      // (the planned widths: the reach of the first exchange)
             s.cellsPerColumn = gy * gz; s.gx = gx; s.cellLength = P.cell_length;
             s.solver = P.solver; s.hasLeft = r > 0; s.hasRight = r + 1 < world;
             s.extraFloats = P.solver == SPHX_DFSPH ? 1 : (P.solver == SPHX_PBD ? 3 : 0);
@@ -1093,7 +1280,8 @@ int sphx_slab_create(const sphx_params* params, const float* fluid_xyz, const fl
             const size_t cap = (size_t)s.capacity, W = (size_t)s.width();
             const size_t blocks = cap / kSlabBlock + 2;
             s.blockL.alloc(blocks); s.blockR.alloc(blocks); s.blockK.alloc(blocks); s.blockSums.alloc(3 * (blocks / 2048 + 2));
-            s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(13);
+            s.violation.alloc(1); s.layerOut.alloc(8); s.counts.alloc(13); s.farCounts.alloc(8);
+            hip_ok(hipHostMalloc((void**)&s.hFar, 8 * sizeof(long long), hipHostMallocDefault), "pinned far counts");
             s.own.alloc(cap * W); s.sendL.alloc(cap * W); s.sendR.alloc(cap * W); s.recvL.alloc(cap * W); s.recvR.alloc(cap * W);
             hip_ok(hipHostMalloc((void**)&s.hCounts, 13 * sizeof(long long), hipHostMallocDefault), "pinned counts");
             hip_ok(hipHostMalloc((void**)&s.hInts, 8 * sizeof(int), hipHostMallocDefault), "pinned ints");

@@ -25,6 +25,8 @@ def main():
     slab_worker.configure(P, sphx, solver, adaptive)
     P.reserved[3] = int(os.environ.get("SPHX_TEST_ARITH", "0"))          # arithmetic contract of the slabs (0 strict, 1 tolerance, 2 persistent)
     pos, vel = slab_worker.splash(len(fluid), P, seed)
+    if os.environ.get("SPHX_TEST_FAST_EVERY"):           # flights across whole slabs (hop-by-hop exchange)
+        slab_worker.make_fast(pos, vel, P, int(os.environ["SPHX_TEST_FAST_EVERY"]), float(os.environ.get("SPHX_TEST_FAST_COLUMNS", "7.2")))
     token_file = os.path.join(outdir, "token")
     if rank == 0:
         token = sphx.rccl_unique_id()

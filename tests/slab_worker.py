@@ -28,6 +28,14 @@ def splash(n, P, seed):
     return pos, vel
 
 
+def make_fast(pos, vel, P, every, columns):
+    """every `every`-th particle flies `columns` cell columns per step along x, towards the middle of the box (r06: flights past
+    the reach of one slab exchange).  In place; the same fp32 arithmetic in every process"""
+    fast = np.arange(len(pos)) % every == 0
+    vel[fast, 0] = np.where(pos[fast, 0] < 0.5 * P.space[0], 1.0, -1.0).astype(np.float32) * np.float32(columns * P.cell_length / P.dt)
+    return vel
+
+
 def pbd_last_positions(pos, vel, P):
     """PBD derives velocities from displacements: give the particles the splash velocities by moving
     the recorded last positions back by dt * vel (same fp32 arithmetic in every process)"""

@@ -413,6 +413,126 @@ def test_native_slab_layer_moving_cuts(sphx, oracle, solver, adaptive):
         assert it == rit
 
 
+@pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("pbd", False), ("dfsph", True)])
+def test_native_slab_layer_jumps_of_several_columns(sphx, oracle, solver, adaptive):
+    """r06: the exchange reaches as far as the neighbouring slab is wide (minus its far edge columns), not one column.
+    Every fifth particle of a splash flies 2.5 cell columns per step along x (|v| dt = 2.5 cell lengths), the others slosh as usual:
+    owners change two and three columns behind the cuts, ghosts appear and vanish within one step -- positions, velocities,
+    densities and iteration counts still equal the single-domain ORACLE bit for bit (3 slabs, the middle one with neighbours on
+    both sides).  /root/reference/src/SPHSystem.cu:114-127 re-bins any displacement; so does the slab layer within that reach."""
+    nx, steps, seed, world = 24, 4, 41, 3
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, adaptive)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    slab_worker.make_fast(pos, vel, P, 5, 2.5)
+    g = sphx.SlabGroup(P, pos, boundary, world, velocity=vel)
+    cuts = [g.info(i)[:2] for i in range(world)]
+    far = 0
+    prev_col = prev_own = None
+    for _ in range(steps):
+        g.step()
+        parts = [g.gather(i) for i in range(world)]
+        ids = np.concatenate([q[0] for q in parts]); xs = np.concatenate([q[1][:, 0] for q in parts])
+        owners = np.concatenate([np.full(len(q[0]), i) for i, q in enumerate(parts)])
+        col = np.empty(len(ids), np.int64); own = np.empty(len(ids), np.int64)
+        col[ids] = (xs / np.float32(P.cell_length)).astype(np.int64); own[ids] = owners
+        if prev_col is not None:
+            far += int(np.count_nonzero((np.abs(col - prev_col) >= 2) & (own != prev_own)))
+        prev_col, prev_own = col, own
+    ids, p, v, d = g.gather_all()
+    it = g.iters()
+    g.close()
+    assert far > 20, "the test must move particles two and more columns across a cut (cuts %s, %d such moves)" % (cuts, far)
+    Po, _, bo = oracle.scene(nx)
+    slab_worker.configure(Po, oracle, solver, adaptive)
+    o = oracle.System(Po, pos, bo, ctor_step=False)
+    oid = o.get(oracle.F_ID)
+    o.set(oracle.F_VEL, vel[oid])
+    for k in range(steps):
+        o.step()
+        if solver == "pbd" and k == 0:
+            o.set(oracle.F_POS_LAST, slab_worker.pbd_last_positions(pos, vel, Po)[o.get(oracle.F_ID)])
+    order = np.argsort(o.get(oracle.F_ID))
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    assert_bit_equal(p, o.get(oracle.F_POS)[order], "far jumps pos"); assert_bit_equal(v, o.get(oracle.F_VEL)[order], "far jumps vel")
+    assert_bit_equal(d, o.get(oracle.F_DENSITY)[order], "far jumps density")
+    if solver == "dfsph":
+        assert it == o.iters()
+
+
+@pytest.mark.parametrize("solver,adaptive,world", [("dfsph", False, 4), ("wcsph", False, 5), ("pbd", False, 4), ("dfsph", True, 5)])
+def test_native_slab_layer_flights_across_whole_slabs(sphx, oracle, solver, adaptive, world):
+    """... and beyond that reach the rows travel hop by hop inside the step (sphx_slab_group::forwardFarFlyers): every 40th particle of the
+    splash flies 7.2 columns per step -- across slabs of 5-6 columns, into their far edge columns, two slabs away, against the walls --
+    and the run still equals the single-domain ORACLE bit for bit: ownership, ghosts of every slab on the way, the pre-sort order of the
+    stable cell sort, adaptive iteration counts.  The under-resolved impact of the 10.3 M scene does exactly this (|v| to 1700 m/s under
+    the reference's adaptive control: profiles/r06_vmax_probe.txt); the plain engine never cared, now the slab layer does not either."""
+    nx, steps, seed = 24, 4, 43
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, solver, adaptive)
+    pos, vel = slab_worker.splash(len(fluid), P, seed)
+    slab_worker.make_fast(pos, vel, P, 40, 7.2)
+    g = sphx.SlabGroup(P, pos, boundary, world, velocity=vel)
+    cuts = [g.info(i)[:2] for i in range(world)]
+    hops = 0
+    prev_own = None
+    for _ in range(steps):
+        g.step()
+        parts = [g.gather(i) for i in range(world)]
+        ids = np.concatenate([q[0] for q in parts])
+        owners = np.concatenate([np.full(len(q[0]), i) for i, q in enumerate(parts)])
+        own = np.empty(len(ids), np.int64); own[ids] = owners
+        if prev_own is not None:
+            hops += int(np.count_nonzero(np.abs(own - prev_own) >= 2))
+        prev_own = own
+    ids, p, v, d = g.gather_all()
+    it = g.iters()
+    g.close()
+    assert hops > 10, "the test must send particles two and more slabs away in one step (cuts %s, %d such moves)" % (cuts, hops)
+    Po, _, bo = oracle.scene(nx)
+    slab_worker.configure(Po, oracle, solver, adaptive)
+    o = oracle.System(Po, pos, bo, ctor_step=False)
+    o.set(oracle.F_VEL, vel[o.get(oracle.F_ID)])
+    for k in range(steps):
+        o.step()
+        if solver == "pbd" and k == 0:
+            o.set(oracle.F_POS_LAST, slab_worker.pbd_last_positions(pos, vel, Po)[o.get(oracle.F_ID)])
+    order = np.argsort(o.get(oracle.F_ID))
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    assert_bit_equal(p, o.get(oracle.F_POS)[order], "far flights pos"); assert_bit_equal(v, o.get(oracle.F_VEL)[order], "far flights vel")
+    assert_bit_equal(d, o.get(oracle.F_DENSITY)[order], "far flights density")
+    if solver == "dfsph":
+        assert it == o.iters()
+
+
+@pytest.mark.parametrize("world,solver,adaptive,library", [(4, "dfsph", True, "mock-deferred"), (5, "wcsph", False, "mock"), (4, "pbd", False, "mock-deferred")])
+def test_far_flights_over_the_rccl_transport(oracle, tmp_path, world, solver, adaptive, library):
+    """the hop-by-hop exchange between PROCESSES (one per slab, the stand-in RCCL, transfers landing 300 us late in the deferred form):
+    grouped send/recv per hop, the blocking all-reduce that ends the hops, moving cuts -- oracle-identical"""
+    nx, steps, seed = 24, 4, 43
+    env = {"SPHX_TEST_FAST_EVERY": "40", "SPHX_TEST_FAST_COLUMNS": "7.2"}
+    if library == "mock-deferred":
+        env["SPHX_MOCK_RCCL_DEFER_US"] = "300"
+    parts = _run_ranks(tmp_path, world, nx, steps, seed, solver, adaptive, True, _mock_library(), env)
+    ids = np.concatenate([q["ids"] for q in parts]); order = np.argsort(ids)
+    assert np.array_equal(ids[order], np.arange(len(ids), dtype=np.int32)), "every particle owned exactly once"
+    Po, fluid, bo = oracle.scene(nx)
+    slab_worker.configure(Po, oracle, solver, adaptive)
+    pos, vel = slab_worker.splash(len(fluid), Po, seed)
+    slab_worker.make_fast(pos, vel, Po, 40, 7.2)
+    o = oracle.System(Po, pos, bo, ctor_step=False)
+    o.set(oracle.F_VEL, vel[o.get(oracle.F_ID)])
+    for k in range(steps):
+        o.step()
+        if solver == "pbd" and k == 0:
+            o.set(oracle.F_POS_LAST, slab_worker.pbd_last_positions(pos, vel, Po)[o.get(oracle.F_ID)])
+    oo = np.argsort(o.get(oracle.F_ID))
+    for name, f in (("pos", oracle.F_POS), ("vel", oracle.F_VEL), ("density", oracle.F_DENSITY)):
+        assert_bit_equal(np.concatenate([q[name] for q in parts])[order], o.get(f)[oo], "far flights over the transport: " + name)
+    if solver == "dfsph":
+        assert all(tuple(q["iters"]) == o.iters() for q in parts)
+
+
 def test_native_slab_layer_config3_size_matches_single_system(sphx):
     """BASELINE config 3's size (1,022,208 particles, DFSPH v=1 d=4) over 8 loopback slabs with cuts re-balanced every
     step: bit-identical to the plain single-device system (itself oracle-identical at small sizes)"""
@@ -596,7 +716,7 @@ def test_a_missing_transport_wait_is_detected(oracle, tmp_path, solver):
         parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
         same, _ = _compare_with_oracle(oracle, parts, nx, steps, seed, solver, False)
         assert not same, "a dropped wait() went unnoticed under deferred completion"
-    else:                        # ... or the garbage tripped the layer's own checks ("crossed more than one cell column"): detected as well
+    else:                        # ... or the garbage tripped the layer's own checks ("farther in one step than the exchange reaches"): detected as well
         assert all(c in (0, 3) for c in codes), codes
     blind = tmp_path / "immediate"; blind.mkdir()
     parts = _run_ranks(blind, 2, nx, steps, seed, solver, False, False, _mock_library(), {"SPHX_SLAB_FAULT": "skipwait", "SPHX_LIB": _hooks_library()})
