@@ -83,7 +83,9 @@ def parse():
     ap.add_argument("--tuning", default="", help="engine tuning for experiments: comma-separated sphx_tuning fields, e.g. row_capacity=64,dfsph_no_tail=1 "
                                                   "(include/sphx_c.h; the library reads no SPHX_* environment variables)")
     ap.add_argument("--cpu-nx", type=int, default=88, help="bounded CPU sample: nx of the oracle run (88 -> 1,022,208)")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-full-steps", type=int, default=2,
+                    help="steps of the CPU oracle at the BENCH size itself (10.3 M particles: ~17 s per step on 128 threads); 0: extrapolate from --cpu-nx")
     return ap.parse_args()
 
 
@@ -93,8 +95,8 @@ def cpu_baseline(args, n_bench):
       * BASELINE config 1 as stated (20,736-particle WCSPH dam break, dt = 0.001) and the same scene under the reference's
         default DFSPH and PBD(20), each with ONE thread (the north star's "serial kernels") and with all cores -- measured,
         nothing extrapolated (timer position: SPHSystem.cu:131-157, one step() per frame; README.md:6-9 quotes GPU frame times);
-      * the headline solver at 1 M particles on all cores, whose steps/s is EXTRAPOLATED linearly in the particle count to
-        the bench size for `value` (labelled; the measured figure is given beside it)."""
+      * the headline solver at the bench size itself on all cores (r06: --cpu-full-steps steps behind the constructor step; measured,
+        not extrapolated), with the 1 M sample of the earlier rounds beside it (`configs`)."""
     from oracle import oracle as O
     cores = O.lib().oracle_max_threads()
     configs = []
@@ -128,6 +130,27 @@ def cpu_baseline(args, n_bench):
     n_s = len(fluid)
     configs.append({"workload": "%s dam-break nx=%d, %d particles (the headline solver settings)" % (args.solver, args.cpu_nx, n_s),
                     "threads": cores, "steps": args.cpu_steps, "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "extrapolated": False})
+    if args.cpu_full_steps > 0 and args.nx != args.cpu_nx:
+        P, fluid, boundary = O.scene(args.nx)
+        P.solver = {"wcsph": O.WCSPH, "dfsph": O.DFSPH, "pbd": O.PBD}[args.solver]
+        P.dfsph_fixed_div, P.dfsph_fixed_den, P.pbd_iters = args.div_iters, args.den_iters, args.pbd_iters
+        note("cpu baseline: oracle at the bench size, nx=%d (%d particles): constructor step + %d steps" % (args.nx, len(fluid), args.cpu_full_steps))
+        s = O.System(P, fluid, boundary, threads=cores)
+        t0 = time.time()
+        for _ in range(args.cpu_full_steps):
+            s.step()
+        dtf = (time.time() - t0) / args.cpu_full_steps
+        s.close()
+        note("cpu baseline: %.2f s/step at the bench size" % dtf)
+        configs.append({"workload": "%s dam-break nx=%d, %d particles (the bench size, the headline solver settings)" % (args.solver, args.nx, len(fluid)),
+                        "threads": cores, "steps": args.cpu_full_steps, "ms_per_step": dtf * 1e3, "steps_per_s": 1.0 / dtf, "extrapolated": False})
+        return {"value": 1.0 / dtf, "unit": "steps/s", "cores": cores, "kind": "port",
+                "measured_steps_per_s": 1.0 / dtf, "measured_particles": len(fluid),
+                "note": "port = oracle/sph_oracle.c, this repo's CPU restatement (OpenMP over particles); the reference is not buildable here",
+                "sample": "%s dam-break nx=%d (%d particles = the bench size), %d steps behind the constructor step at %.2f s/step on %d OpenMP threads; "
+                          "nothing extrapolated (1 M sample beside it: %.3f s/step, x %.2f per particle)" % (
+                              args.solver, args.nx, len(fluid), args.cpu_full_steps, dtf, cores, dt, (dtf / len(fluid)) / (dt / n_s)),
+                "configs": configs}
     steps_per_s_at_bench = (1.0 / dt) * (n_s / float(n_bench))
     return {"value": steps_per_s_at_bench, "unit": "steps/s", "cores": cores, "kind": "port",
             "extrapolated": "value = measured %.4f steps/s at %d particles x (%d / %d): linear in the particle count" % (1.0 / dt, n_s, n_s, n_bench),

@@ -88,9 +88,8 @@ int sphx_set_tuning(const sphx_tuning* t)
 {
     if (!t) { sphx::install_tuning(sphx::default_tuning()); return SPHX_OK; }
     if (t->struct_size != (int)sizeof(sphx_tuning)) return fail(SPHX_ERR_INVALID, "sphx_set_tuning: struct_size does not match this library's sphx_tuning");
-    if ((t->row_capacity != 0 && (t->row_capacity < 8 || t->row_capacity > 1024)) || t->slab_comm_priority < 0 || t->slab_comm_priority > 2 ||
-        t->slab_edge_priority < 0 || t->slab_edge_priority > 1)
-        return fail(SPHX_ERR_INVALID, "sphx_set_tuning: a field is out of range (row_capacity 0 or 8..1024, slab_comm_priority 0..2, slab_edge_priority 0..1)");
+    if ((t->row_capacity != 0 && (t->row_capacity < 8 || t->row_capacity > 1024)) || t->slab_comm_priority < 0 || t->slab_comm_priority > 2)
+        return fail(SPHX_ERR_INVALID, "sphx_set_tuning: a field is out of range (row_capacity 0 or 8..1024, slab_comm_priority 0..2)");
     sphx::install_tuning(*t);
     return SPHX_OK;
 }

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(kErrorSlots) k_loop_reset(int* __restrict__ st
 {
     accum[(size_t)threadIdx.x * kErrorSlotStride] = 0ull;
     if (threadIdx.x == 0) { st[kLoopDone] = 0; st[kLoopIter] = 0; st[kLoopBarrier] = 0; }
+    for (int w = kLoopXcd + (int)threadIdx.x; w < kLoopWords; w += kErrorSlots) st[w] = 0;      // the XCD barrier's counters
 }
 __global__ void __launch_bounds__(kErrorSlots) k_loop_decide(int* __restrict__ st, unsigned long long* __restrict__ accum, float threshold,
                                                              int minIter, int maxIter, int which)
@@ -410,7 +411,7 @@ bool DFSPHSolver::runLoopTail(bool densityLoop, std::shared_ptr<SPHParticles>& f
     const int num = (int)fluids->size();
     const SweepCtx ctx = c.ctx(cellStartFluid, cellStartBoundary);
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(errorAccum.addr());
-    const LoopTail tail{loopState.addr(), accum, threshold, minIter, maxIter, which};
+    const LoopTail tail{loopState.addr(), accum, threshold, minIter, maxIter, which, tuning().dfsph_tail_flat};
     ScopedKernel t(densityLoop ? "density_loop_tail" : "divergence_loop_tail");
     if (densityLoop)
         return launch_dfsph_loop_tail<true, 2>(OpCorrect<true>{ctx, bufferFloat.addr(), fluids->getVelPtr(), dt, true},

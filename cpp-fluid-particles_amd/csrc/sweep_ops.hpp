@@ -831,8 +831,12 @@ struct LoopTail {
     int* st;                          // DFSPHSolver::loopState: done flag, iterations so far, divergence count, density count, fault, barrier word
     unsigned long long* accum;        // kErrorSlots partial totals (zero on entry; cumulative inside the tail)
     float threshold; int minIter, maxIter, which;
+    int flatBarrier;                  // 1: the r04 barrier (one counter, a fence pair per block) -- sphx_tuning.dfsph_tail_flat, for measurements
 };
-enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3, kLoopFault = 4, kLoopBarrier = 5, kLoopWords = 8 };
+// kLoopXcd: the state of the XCD-hierarchical barrier, one word per 128-byte line: blocks per XCD [0,8), arrivals per XCD [8,16),
+// generation per XCD [16,24), arrivals of the XCD leaders [24]
+enum { kLoopDone = 0, kLoopIter = 1, kLoopDiv = 2, kLoopDen = 3, kLoopFault = 4, kLoopBarrier = 5, kLoopXcd = 32, kLoopXcdLine = 32,
+       kLoopWords = 32 + 25 * 32 };
 // false: the other blocks did not arrive within seconds (the grid was not resident at once after all -- a profiler or a partition
 // the occupancy query does not know of): the block raises st[kLoopFault] and leaves; the host reports it with the iteration counts
 // (DFSPHSolver::fetchIterations) and goes back to gated launches.  A hang here would take the whole device with it.
@@ -861,6 +865,64 @@ __device__ __forceinline__ bool grid_barrier(unsigned int* word, unsigned int& t
     __syncthreads();
     return gaveUp == 0;
 }
+// r06: the barrier between the sweeps of an iteration, XCD-hierarchical (MI355X_MICROARCH.md "barrier-xcd": 4-10 us where the flat counter
+// with a release / acquire pair per BLOCK costs ~35 us at this kernel's 4+ blocks per CU).  The blocks of one XCD share its L2: a block's
+// stores are there once its waves have passed __syncthreads (vmcnt(0)), so a block only ARRIVES on its XCD's counter; the last block of
+// an XCD writes that L2 back ONCE (release, agent scope), arrives on the top counter, waits for the other XCDs' leaders, and publishes the
+// XCD's generation; every block ends with an agent-scope acquire (its CU's L1 and the non-local lines of the L2).  Which XCD a block
+// runs on is read from the hardware (HW_REG_XCC_ID), how many blocks each XCD got is counted at the start of the launch behind ONE flat
+// barrier: nothing is assumed about the dispatcher's placement.  Spins are bounded and report like grid_barrier's.
+struct XcdBarrier { int* base; int xcc; unsigned int g; unsigned int mine, groups; };
+__device__ __forceinline__ bool xcd_barrier_begin(XcdBarrier& B, int* st, unsigned int* flatWord, unsigned int& flatTarget)
+{
+    B.base = st + kLoopXcd; B.g = 0u;
+    B.xcc = (int)(__builtin_amdgcn_s_getreg(6164) & 7u);                // hwreg(HW_REG_XCC_ID, 0, 4)
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned int*>(B.base) + B.xcc * kLoopXcdLine, 1u);
+    if (!grid_barrier(flatWord, flatTarget, st + kLoopFault)) return false;
+    B.mine = 0u; B.groups = 0u;
+    if (threadIdx.x == 0) {
+        for (int x = 0; x < 8; ++x) {
+            const unsigned int cnt = (unsigned int)__hip_atomic_load(B.base + x * kLoopXcdLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x == B.xcc) B.mine = cnt;
+            B.groups += cnt ? 1u : 0u;
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ bool xcd_barrier(XcdBarrier& B, int* fault)
+{
+    __shared__ int gaveUpX;
+    if (threadIdx.x == 0) gaveUpX = 0;
+    __syncthreads();                                                     // every wave's stores have left for the L2
+    if (threadIdx.x == 0) {
+        ++B.g;
+        unsigned int* const arrive = reinterpret_cast<unsigned int*>(B.base) + (8 + B.xcc) * kLoopXcdLine;
+        int* const gen = B.base + (16 + B.xcc) * kLoopXcdLine;
+        unsigned int* const top = reinterpret_cast<unsigned int*>(B.base) + 24 * kLoopXcdLine;
+        unsigned int spins = 0;
+        const unsigned int old = atomicAdd(arrive, 1u);
+        if (old + 1u == B.mine * B.g) {                                  // the last block of this XCD
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // buffer_wbl2 sc1: this XCD's dirty lines, once
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAdd(top, 1u);
+            while ((unsigned int)__hip_atomic_load(reinterpret_cast<int*>(top), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B.groups * B.g) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { gaveUpX = 1; *fault = 1; __threadfence(); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(gen, (int)B.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while ((unsigned int)__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B.g) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { gaveUpX = 1; *fault = 1; __threadfence(); break; }
+                if ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gaveUpX = 1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    return gaveUpX == 0;
+}
 // CM: the correction sweep's launch shape, 0 lane per particle (a block takes four tiles), 1 quad per particle (one tile)
 template <bool DENSITY_MODE, int WARM, int CM, int TOLC, int TOLR>
 __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<DENSITY_MODE> corr, const OpRate rate, const LoopTail t)
@@ -873,6 +935,9 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
     unsigned int target = 0;
     int iter = t.st[kLoopIter];
     unsigned long long before = 0;
+    XcdBarrier xb;
+    const bool flat = t.flatBarrier != 0;
+    if (!flat && !xcd_barrier_begin(xb, t.st, word, target)) return;
     for (;;) {
         if constexpr (CM == 1) {
             for (int lt = (int)blockIdx.x; lt < corr.c.numTiles; lt += (int)gridDim.x) {
@@ -888,7 +953,7 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
                 corr(i, in_range(corr.c, i), nullptr, nullptr);
             }
         }
-        if (!grid_barrier(word, target, t.st + kLoopFault)) return;
+        if (!(flat ? grid_barrier(word, target, t.st + kLoopFault) : xcd_barrier(xb, t.st + kLoopFault))) return;
         for (int lt = (int)blockIdx.x; lt < rate.c.numTiles; lt += (int)gridDim.x) {
             assume_arith<TOLR>(rate.c);
             const int i = quad_particle_of(rate.c, lt);
@@ -901,7 +966,7 @@ __global__ void __launch_bounds__(kWideBlock) k_dfsph_loop_tail(const OpCorrect<
             if (stores_results<1>(valid)) fixed = finish_rate<DENSITY_MODE, WARM>(rate.out, i, b.e, rate.density[i], rate.alpha[i]);
             accumulate_error(fixed, rate.out.accum);
         }
-        if (!grid_barrier(word, target, t.st + kLoopFault)) return;
+        if (!(flat ? grid_barrier(word, target, t.st + kLoopFault) : xcd_barrier(xb, t.st + kLoopFault))) return;
         unsigned long long v = t.accum[(size_t)threadIdx.x * kErrorSlotStride];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -27,10 +27,8 @@ def run_slab_bench(args, rank, world, local_rank):
     import sphx
     torch.cuda.set_device(local_rank)
     sphx.set_device(local_rank)
-    # The edge stream of the slab layer is a default-priority stream everywhere: a highest-priority one made ranks of the
-    # 8-process test fail when several PROCESSES shared one device (profiles/r05_slab_edge_stream.txt: the fault sits below the engine
-    # but is not named).  Measurements of the old setting: bench.py --tuning slab_edge_priority=1 (worth ~10 % with 8 slabs on ONE device
-    # over the installed RCCL, nothing over loopback copies).
+    # The edge stream of the slab layer is a default-priority stream (r06: the switch for a highest-priority one is gone
+    # from the product -- profiles/r06_slab_edge_stream.txt names what made ranks of the 8-process test fail with it).
     P, fluid, boundary = sphx.scene(args.nx)
     solver_name = getattr(args, "solver", "dfsph")
     P.solver = {"wcsph": sphx.WCSPH, "dfsph": sphx.DFSPH, "pbd": sphx.PBD}[solver_name]

@@ -142,8 +142,8 @@ typedef struct sphx_tuning {
     int   pbd_skin_fixed;     /* 1: no controller that drops the skin in violent phases */
     int   persist_controller; /* persistent rows: leave the mode for 256 steps while (nearly) every step rebuilds its rows (-1: yes) */
     int   slab_edge_stream;   /* slab layer: edge layers of a DFSPH / WCSPH stage on a stream of their own beside the interior (-1: yes) */
-    int   slab_edge_priority; /* ... 1: that stream at the highest priority (0) */
     int   slab_comm_priority; /* RCCL transport's communication stream: 0 highest priority (default), 1 default priority, 2 lowest */
+    int   dfsph_tail_flat;    /* (live) 1: the loop tail's sweeps are separated by the r04 barrier (one counter, a fence pair per block) instead of the XCD-hierarchical one */
     int   reserved[7];
 } sphx_tuning;
 int  sphx_tuning_defaults(sphx_tuning *out);

@@ -212,9 +212,9 @@ def test_tuning_block_round_trip_and_validation(sphx):
         with pytest.raises(sphx.SphxError):
             sphx.set_tuning(no_such_field=1)
         assert sphx.get_tuning().row_capacity == 64, "a refused block changes nothing"
-        t = tuning_env.from_environment(sphx, {"SPHX_NBR_CAP": "12", "SPHX_DFSPH_NO_TAIL": "1", "SPHX_COMM_PRIORITY": "low", "SPHX_EDGE_PRIORITY": "high",
+        t = tuning_env.from_environment(sphx, {"SPHX_NBR_CAP": "12", "SPHX_DFSPH_NO_TAIL": "1", "SPHX_COMM_PRIORITY": "low",
                                                "SPHX_SLAB_EDGE_STREAM": "0", "SPHX_PBD_SKIN": "0.3", "SPHX_DFSPH_WINDOW": "0"})
-        assert (t.row_capacity, t.dfsph_no_tail, t.slab_comm_priority, t.slab_edge_priority, t.slab_edge_stream, t.dfsph_window) == (12, 1, 2, 1, 0, 0)
+        assert (t.row_capacity, t.dfsph_no_tail, t.slab_comm_priority, t.slab_edge_stream, t.dfsph_window) == (12, 1, 2, 0, 0)
         assert abs(t.pbd_skin - 0.3) < 1e-7
     finally:
         sphx.set_tuning()

@@ -908,14 +908,16 @@ def test_trajectory_bit_exact_through_landing(sphx, oracle, solver, dt, first, l
         assert gs.get(sphx.F_PRESSURE).max() > 0, "Tait pressures must be active"
 
 
-@pytest.mark.parametrize("mode", ["tail_only", "gated_only", "windows"])
+@pytest.mark.parametrize("mode", ["tail_only", "tail_only_flat_barrier", "gated_only", "windows"])
 def test_adaptive_loops_tail_and_gated_launches_bit_exact(sphx, oracle, monkeypatch, mode):
     """adaptive DFSPH through the landing (counts 1 -> 20) with every iteration beyond the reference's minimum inside the persistent
     tail launch (SPHX_DFSPH_WINDOW=0), with gated launches only (SPHX_DFSPH_NO_TAIL=1) and with the default adaptive windows:
     every field bit-identical to the oracle, same iteration counts (DFSPHSolver.cu:187-208, :347-361); the counts read after a
     replayed batch are those of its last step"""
-    if mode == "tail_only":
+    if mode.startswith("tail_only"):          # (r06: the tail's sweeps are separated by the XCD-hierarchical barrier; _flat_barrier: the r04 one)
         monkeypatch.setenv("SPHX_DFSPH_WINDOW", "0")
+    if mode == "tail_only_flat_barrier":
+        monkeypatch.setenv("SPHX_DFSPH_TAIL_FLAT", "1")
     if mode == "gated_only":
         monkeypatch.setenv("SPHX_DFSPH_NO_TAIL", "1")
     gs, os_, _ = make_pair(sphx, oracle, 24, 1)

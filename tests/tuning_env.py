@@ -35,12 +35,12 @@ ENV = {
     "SPHX_DFSPH_HOST_LOOP": ("dfsph_host_loop", _PRESENT),
     "SPHX_DFSPH_WINDOW": ("dfsph_window", lambda v: max(0, int(v))),
     "SPHX_DFSPH_NO_TAIL": ("dfsph_no_tail", _PRESENT),
+    "SPHX_DFSPH_TAIL_FLAT": ("dfsph_tail_flat", _PRESENT),
     "SPHX_NO_KICK_FUSION": ("no_kick_fusion", _PRESENT),
     "SPHX_PBD_SKIN": ("pbd_skin", float),
     "SPHX_PBD_SKIN_FIXED": ("pbd_skin_fixed", _PRESENT),
     "SPHX_PERSIST_CONTROLLER": ("persist_controller", lambda v: int(int(v) != 0)),
     "SPHX_SLAB_EDGE_STREAM": ("slab_edge_stream", lambda v: int(v != "0")),
-    "SPHX_EDGE_PRIORITY": ("slab_edge_priority", lambda v: int(v == "high")),
     "SPHX_COMM_PRIORITY": ("slab_comm_priority", _comm_priority),
 }
 

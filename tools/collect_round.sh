@@ -24,7 +24,6 @@ python tools/small_probe.py 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/sm
 python tools/pcie_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/pcie_$TAG.txt
 for A in tolerance strict; do for s in 1 8; do python bench.py --force-slab --slabs $s --arith $A --steps 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_${TAG}_loopback_${s}slabs_$A.json; done; done
 python bench.py --force-slab --slabs 8 --arith tolerance --slab-transport rccl --steps 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_${TAG}_rcclself_8slabs.json
-python bench.py --force-slab --slabs 8 --arith tolerance --slab-transport rccl --steps 20 --no-cpu-baseline --tuning slab_edge_priority=1 2>/dev/null > gpurun_out/bench_${TAG}_rcclself_8slabs_edgehigh.json
 for A in tolerance strict; do python bench.py --arith $A --steps 20 --no-cpu-baseline --no-extra-legs 2>/dev/null > gpurun_out/bench_${TAG}_plain_$A.json; done
 (python tools/slab_probe_step.py 190 1 1; python tools/slab_probe_step.py 190 8 1) 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/slab_probe_$TAG.txt
 python tools/big_probe.py 190,320,400 0 2>/dev/null | grep "^nx" > gpurun_out/big_${TAG}.txt
