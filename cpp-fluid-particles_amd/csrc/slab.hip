@@ -568,6 +568,15 @@ struct sphx_slab_group {
     static void reach(const Slab& s, int x0b, int x1b, int slackL, int slackR, int& loOK, int& hiOK)
     {
         loOK = INT_MIN / 2; hiOK = INT_MAX / 2;
+        if (s.solver == SPHX_PBD) {
+            // PBD is different: its sweeps run on positions that moved INSIDE the step over the cell table of the step's start
+            // (PBDSolver.cu:139-141), so a slab's neighbourhoods are complete only while a particle stays within
+            // (ghost - 1) = one column of the column it was binned in.  The travel of a step is the solver's own result (constraint
+            // projection), not known before the exchange: a farther move is found by the NEXT exchange and ends the run, as in r02-r05.
+            if (s.hasLeft) loOK = s.x0 - 1 - slackL;
+            if (s.hasRight) hiOK = s.x1 + slackR;
+            return;
+        }
         if (s.hasLeft) {
             const int oneColumn = s.x0 - 1 - slackL;                                  // (the r02 rule: always safe)
             loOK = s.rank >= 2 ? std::min(oneColumn, x0b - s.widthLeft + s.ghost + 1) : (s.widthLeft > 0 ? INT_MIN / 2 : oneColumn);
@@ -659,6 +668,9 @@ struct sphx_slab_group {
         const long long bad = hBad[0], anyBad = hBad[1];
         SLAB_TRACE("failure word reduced", anyBad);
         const bool farStep = (anyBad >> 40) != 0;            // somewhere a particle flew past the reach of one exchange
+        if (farStep && global.solver == SPHX_PBD)
+            die(std::string("slab: PBD: a particle moved more than one cell column within a step -- the sweeps of that step ran on positions outside "
+                            "the two ghost columns (") + ((bad >> 40) ? "this process" : "another rank") + ")");
         if ((anyBad >> 20) & ((1LL << 20) - 1)) {
             const char* here = ((bad >> 20) & ((1LL << 20) - 1)) ? "this process" : "another rank";
             die(std::string("slab: capacity exceeded (particles piled up in one slab; ") + here + ")");

@@ -399,7 +399,7 @@ def test_native_slab_layer_moving_cuts(sphx, oracle, solver, adaptive):
         assert it == rit
 
 
-@pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("pbd", False), ("dfsph", True)])
+@pytest.mark.parametrize("solver,adaptive", [("dfsph", False), ("wcsph", False), ("dfsph", True)])
 def test_native_slab_layer_jumps_of_several_columns(sphx, oracle, solver, adaptive):
     """r06: the exchange reaches as far as the neighbouring slab is wide (minus its far edge columns), not one column.
     Every fifth particle of a splash flies 2.5 cell columns per step along x (|v| dt = 2.5 cell lengths), the others slosh as usual:
@@ -446,7 +446,7 @@ def test_native_slab_layer_jumps_of_several_columns(sphx, oracle, solver, adapti
         assert it == o.iters()
 
 
-@pytest.mark.parametrize("solver,adaptive,world", [("dfsph", False, 4), ("wcsph", False, 5), ("pbd", False, 4), ("dfsph", True, 5)])
+@pytest.mark.parametrize("solver,adaptive,world", [("dfsph", False, 4), ("wcsph", False, 5), ("dfsph", True, 5), ("wcsph", False, 8)])
 def test_native_slab_layer_flights_across_whole_slabs(sphx, oracle, solver, adaptive, world):
     """... and beyond that reach the rows travel hop by hop inside the step (sphx_slab_group::forwardFarFlyers): every 40th particle of the
     splash flies 7.2 columns per step -- across slabs of 5-6 columns, into their far edge columns, two slabs away, against the walls --
@@ -491,7 +491,7 @@ def test_native_slab_layer_flights_across_whole_slabs(sphx, oracle, solver, adap
         assert it == o.iters()
 
 
-@pytest.mark.parametrize("world,solver,adaptive,library", [(4, "dfsph", True, "mock-deferred"), (5, "wcsph", False, "mock"), (4, "pbd", False, "mock-deferred")])
+@pytest.mark.parametrize("world,solver,adaptive,library", [(4, "dfsph", True, "mock-deferred"), (5, "wcsph", False, "mock"), (4, "dfsph", False, "mock-deferred")])
 def test_far_flights_over_the_rccl_transport(oracle, tmp_path, world, solver, adaptive, library):
     """the hop-by-hop exchange between PROCESSES (one per slab, the stand-in RCCL, transfers landing 300 us late in the deferred form):
     grouped send/recv per hop, the blocking all-reduce that ends the hops, moving cuts -- oracle-identical"""
@@ -517,6 +517,22 @@ def test_far_flights_over_the_rccl_transport(oracle, tmp_path, world, solver, ad
         assert_bit_equal(np.concatenate([q[name] for q in parts])[order], o.get(f)[oo], "far flights over the transport: " + name)
     if solver == "dfsph":
         assert all(tuple(q["iters"]) == o.iters() for q in parts)
+
+
+def test_pbd_slabs_still_refuse_travel_beyond_their_ghost_columns(sphx):
+    """PBD sweeps run on positions that moved inside the step over the cell table of the step's start (PBDSolver.cu:139-141): a slab's
+    two ghost columns cover one column of travel.  A particle that moved farther is found by the next exchange and ends the run on
+    every slab together -- hop-by-hop delivery would not repair the sweeps that already ran"""
+    nx, world = 24, 3
+    P, fluid, boundary = sphx.scene(nx)
+    slab_worker.configure(P, sphx, "pbd", False)
+    pos, vel = slab_worker.splash(len(fluid), P, 7)
+    slab_worker.make_fast(pos, vel, P, 50, 2.5)
+    g = sphx.SlabGroup(P, pos, boundary, world, velocity=vel)
+    with pytest.raises(sphx.SphxError, match="PBD: a particle moved more than one cell column"):
+        for _ in range(4):
+            g.step()
+    g.close()
 
 
 def test_native_slab_layer_config3_size_matches_single_system(sphx):
