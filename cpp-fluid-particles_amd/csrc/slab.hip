@@ -445,7 +445,7 @@ struct Slab {
     // size messages, 3 x int64 each: {payload particles, owned particles, width in columns}
     //   [0..2] to left  [3..5] to right  [6..8] from left  [9..11] from right   [12] owned particles kept here
     DevBuf<long long> counts;
-    long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 12 size words; 6 layer offsets + violation
+    long long* hCounts = nullptr; int* hInts = nullptr;   // pinned: 13 size words; 6 layer offsets
     hipEvent_t layersReady = nullptr;                      // the layer offsets of this step have arrived in hInts
     long long sentOwned = 0; int sentWidth = 0;            // what this slab reported with its last size message
 
@@ -660,7 +660,6 @@ struct sphx_slab_group {
         for (auto& sp : slabs) {
             Slab& s = *sp;
             hip_ok(hipMemcpyAsync(s.hCounts, s.counts.p, 13 * sizeof(long long), hipMemcpyDeviceToHost, st), "counts");
-            hip_ok(hipMemcpyAsync(s.hInts + 6, s.violation.p, sizeof(int), hipMemcpyDeviceToHost, st), "flag");
         }
         hip_ok(hipMemcpyAsync(hBad, dBad.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st), "failure word");
         sync("particle exchange (sizes)");

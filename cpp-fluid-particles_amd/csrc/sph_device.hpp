@@ -1309,6 +1309,103 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     }
 }
 
+// Small scenes (r06): the same rows from 16 lanes per particle.  The lane-per-particle walk above is a chain of ~70 dependent
+// load rounds (9 columns x (cell tables, then candidates four at a time)); with fewer waves than the device has SIMDs that latency
+// IS the builder's time (42 us at the reference scene's 20,736 particles: 40 % of a WCSPH step, and what PBD pays per Jacobi
+// iteration once the fluid has landed).  Here lane q < 9 of a group of 16 walks column q = 3 (dx + 1) + (dy + 1) of the particle's
+// 3 x 3 x 3 cells -- the order of the single-lane walk -- keeping what it would append in LDS, and stores it behind a prefix sum
+// over the group's counts.  Same entries in the same order (entry k of a row lives at row_entry_offset(k) whoever writes it).
+template <int AHEAD, class Emit>
+__device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float3 pi, const int i, const int X, const int Y, const int zlo,
+                                                  const int zhi, const bool wantPlain, Emit emit)
+{
+    const int base = (X * c.g.gy + Y) * c.g.gz;
+    const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
+    const int step = noWall ? (zhi - zlo + 1) : 1;
+    for (int z = zlo; z <= zhi; z += step) {
+        const int cell = base + z;
+        const int e = c.csF[cell + step];
+        int j = c.csF[cell];
+        for (; j + AHEAD <= e; j += AHEAD) {
+            float4 pj[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) pj[u] = c.posm[j + u];
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) {
+                const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
+                const float r2 = dot3(d, d);
+                if (r2 > c.buildCut || j + u == i) continue;
+                emit((unsigned int)(j + u) | ((wantPlain && pair_needs_plain_ops(d, r2)) ? kPlainBit : 0u));
+            }
+        }
+        for (; j < e; ++j) {
+            const float4 pj = c.posm[j];
+            const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+            const float r2 = dot3(d, d);
+            if (r2 > c.buildCut || j == i) continue;
+            emit((unsigned int)j | ((wantPlain && pair_needs_plain_ops(d, r2)) ? kPlainBit : 0u));
+        }
+        if (!noWall) {
+            const int eb = c.csB[cell + 1];
+            for (int jb = c.csB[cell]; jb < eb; ++jb) {
+                const float4 pj = c.bposm[jb];
+                const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
+                const float r2 = dot3(d, d);
+                if (r2 > c.buildCut) continue;
+                emit((unsigned int)(jb + c.bOff) | kBoundaryBit | ((wantPlain && pair_needs_plain_ops(d, r2)) ? kPlainBit : 0u));
+            }
+        }
+    }
+}
+#ifndef SPHX_GROUP_AHEAD
+#define SPHX_GROUP_AHEAD 2      // candidates in flight per lane: 2 keep the kernel at 56 VGPRs (8 waves per SIMD); 4 need 95
+#endif
+constexpr int kGroupAhead = SPHX_GROUP_AHEAD;
+constexpr int kBuildGroup = 16;            // lanes per particle (9 walk a column each)
+constexpr int kGroupStash = 16;            // entries a lane keeps in LDS between counting and storing (16 KB per block of 256: 8 blocks per CU)
+__device__ __forceinline__ void build_neighbor_rows_group(const SweepCtx& c, unsigned int* nbr, int* nbrCount, const int i, const bool valid,
+                                                          unsigned int* stash)
+{
+    const int q = (int)(threadIdx.x & (kBuildGroup - 1));
+    const float4 self = valid ? c.posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float3 pi = v3(self.x, self.y, self.z);
+    const int3 c0 = cell_of(pi, c.g);
+    const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
+    const bool wantPlain = c.k.tol == 0 || c.plainBits != 0;
+    const int X = c0.x + q / 3 - 1, Y = c0.y + q % 3 - 1;
+    const bool column = valid && q < 9 && X >= 0 && X < c.g.gx && Y >= 0 && Y < c.g.gy && zlo <= zhi;
+    unsigned int* row = nbr + row_base_offset(valid ? i : 0, c.cap);
+    // a lane keeps the first kGroupStash entries of its column in LDS (slot k of thread t at stash[k * blockDim + t]: no bank
+    // conflicts); a column with more -- compressed states -- is walked a second time for the rest
+    int mine = 0;
+    if (column) walk_build_column<kGroupAhead>(c, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
+        if (mine < kGroupStash) stash[mine * kWideBlock + (int)threadIdx.x] = e;
+        ++mine;
+    });
+    int upTo = mine;                         // inclusive prefix over the group's lanes
+#pragma unroll
+    for (int off = 1; off < kBuildGroup; off <<= 1) {
+        const int t = __shfl_up(upTo, off, kBuildGroup);
+        if (q >= off) upTo += t;
+    }
+    const int total = __shfl(upTo, kBuildGroup - 1, kBuildGroup);
+    const int first = upTo - mine;
+    const int kept = min(mine, kGroupStash);
+    for (int k = 0; k < kept; ++k)
+        if (first + k < c.cap) row[row_entry_offset(first + k)] = stash[k * kWideBlock + (int)threadIdx.x];
+    if (mine > kGroupStash) {
+        int at = first;
+        walk_build_column<kGroupAhead>(c, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
+            if (at >= first + kGroupStash && at < c.cap) row[row_entry_offset(at)] = e;
+            ++at;
+        });
+    }
+    if (valid && q == 0) {
+        nbrCount[i] = total;
+        if (total > c.cap && c.overflowMax) atomicMax(c.overflowMax, total);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------------------
 // Compact-brick LDS stage (r03; tolerance arithmetic only; the north star's "LDS-staged neighbour cells").

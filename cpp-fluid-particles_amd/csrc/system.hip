@@ -13,6 +13,7 @@
 #include "SPHSystem.h"
 #include "sphx_c.h"
 #include "engine.hpp"
+#include "scan_chain.hpp"
 
 using namespace sphx;
 
@@ -66,7 +67,8 @@ struct GridScratch {
     explicit GridScratch(int maxParticles, int cells)
         : slot((unsigned)maxParticles), order((unsigned)maxParticles), tmp3((unsigned)maxParticles),
           tmpi((unsigned)maxParticles), blockSums((unsigned)(std::max(cells, maxParticles) / 2048 + 2)),
-          posm(4u * (unsigned)maxParticles), outRank((unsigned)maxParticles + 1u)
+          posm(4u * (unsigned)maxParticles), outRank((unsigned)maxParticles + 1u),
+          chain(std::max(cells, maxParticles) / 2048 + 2, 1)
     {
     }
     DArray<int> slot;       // arrival slot of particle i inside its cell (atomic order, arbitrary)
@@ -76,6 +78,7 @@ struct GridScratch {
     DArray<int> blockSums;  // scan scratch
     DArray<float> posm;     // packed boundary positions for the boundary-mass sweep
     DArray<int> outRank;    // stable rank of each out-of-grid particle inside the sentinel bucket
+    ChainScratch chain;     // tile states of the single-launch scans (scan_chain.hpp)
 };
 
 // SPHSystem's persistent mode (SPHSystem.h): the map from API slots (the reference's order) to the working arrays
@@ -168,10 +171,8 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total)
     return base + incl - v;
 }
 
-// (guard: when given and *guard == guardEq the launch has nothing to do -- the out-of-grid ranks of a step without out-of-grid particles)
-__global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int* __restrict__ blockSums, int n, const int* __restrict__ guard = nullptr, int guardEq = 0)
+__global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int* __restrict__ blockSums, int n)
 {
-    if (guard && *guard == guardEq) return;
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int v[kScanItems];
     int sum = 0;
@@ -184,9 +185,8 @@ __global__ void __launch_bounds__(256) k_scan_tiles(int* __restrict__ data, int*
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 // one block walks all tile totals with a running carry (any length)
-__global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ blockSums, int m, const int* __restrict__ guard = nullptr, int guardEq = 0)
+__global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ blockSums, int m)
 {
-    if (guard && *guard == guardEq) return;
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -202,11 +202,54 @@ __global__ void __launch_bounds__(256) k_scan_block_sums(int* __restrict__ block
         __syncthreads();
     }
 }
-__global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict__ blockSums, int n, const int* __restrict__ guard = nullptr, int guardEq = 0)
+__global__ void k_scan_add_offsets(int* __restrict__ data, const int* __restrict__ blockSums, int n, int* __restrict__ last = nullptr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = data[i] + blockSums[i / kScanTile];
+    data[i] = v;
+    if (last && i == n - 1) *last = v;
+}
+
+// The same exclusive scan as ONE launch (scan_chain.hpp): a tile's block scans its 2048 items, looks back for the sum of the tiles
+// before it and writes.  FLAGS: the items are not read from `data` but formed on the fly -- item i = 1 when particle i sits in the
+// out-of-grid bucket (the flag pass and the three scan launches of the sentinel ranks in one).  `last`, when given, also receives
+// the final item (the total of a windowed cell table goes where the out-of-grid bucket starts).
+template <bool FLAGS>
+__global__ void __launch_bounds__(256) k_scan_chain(int* __restrict__ data, int n, ScanChain c, const int* __restrict__ guard, int guardEq,
+                                                    const int* __restrict__ p2c, int sentinel, int live, int* __restrict__ last)
 {
     if (guard && *guard == guardEq) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) data[i] += blockSums[i / kScanTile];
+    unsigned int gen;
+    const int tile = chain_enter(c, gen);
+    const int base = tile * kScanTile + threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) {
+        const int i = base + t;
+        if (FLAGS) v[t] = (i < live && p2c[i] == sentinel) ? 1 : 0;
+        else v[t] = i < n ? data[i] : 0;
+        sum += v[t];
+    }
+    int total;
+    int run = block_exclusive_scan_256(sum, &total);
+    __shared__ int before;
+    if (threadIdx.x < 64) {
+        const int b = chain_exclusive(c, 0, gen, tile, total);
+        if (threadIdx.x == 0) before = b;
+    }
+    __syncthreads();
+    run += before;
+#pragma unroll
+    for (int t = 0; t < kScanItems; ++t) {
+        if (base + t < n) {
+            data[base + t] = run;
+            if (last && base + t == n - 1) *last = run;
+        }
+        run += v[t];
+    }
+    chain_leave(c, gen, (int)gridDim.x);
 }
 
 // three independent scans of equal length in the same three launches (blockIdx.y = channel; the slab layer's three stable compactions)
@@ -259,14 +302,8 @@ __global__ void k_place(int* __restrict__ order, const int* __restrict__ p2c, co
     if (i < n) order[cellStart[p2c[i]] + slot[i]] = i;
 }
 // The out-of-grid sentinel bucket can hold any number of particles (a blown-up run, parked slots),
-// so its stable rank comes from an exclusive scan of the "is out of grid" flags instead of the
+// so its stable rank comes from an exclusive scan of the "is out of grid" flags (k_scan_chain<true>) instead of the
 // quadratic bucket loop.
-__global__ void k_flag_out_of_grid(int* __restrict__ flag, const int* __restrict__ p2c, int sentinel, int n, const int* __restrict__ guard, int guardEq)
-{
-    if (*guard == guardEq) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n) flag[i] = (i < n && p2c[i] == sentinel) ? 1 : 0;
-}
 __global__ void k_stable_rank(int* __restrict__ perm, const int* __restrict__ order, const int* __restrict__ p2c,
                               const int* __restrict__ cellStart, const int* __restrict__ outRank, int n, int cellsPlusOne)
 {
@@ -314,7 +351,6 @@ __device__ __forceinline__ const float* staged_row(const RowSource& r, int t)
 }
 // k_cell_and_count with the position read from the staged rows (same keys, same run-compressed histogram atomics)
 // (cells outside the window [winLo, winHi) count as out of grid: SPHSystem::setCellWindow)
-__global__ void k_copy_one_int(int* __restrict__ dst, const int* __restrict__ src) { *dst = *src; }
 __global__ void __launch_bounds__(256) k_cell_and_count_rows(int* __restrict__ p2c, int* __restrict__ slot, int* __restrict__ counts, RowSource src,
                                                              GridDesc g, int n, int winLo, int winHi)
 {
@@ -378,6 +414,37 @@ __global__ void k_pack_pos_only(float4* __restrict__ dst, const float3* __restri
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) { const float3 p = pos[q]; dst[q] = make_float4(p.x, p.y, p.z, 0.0f); }
+}
+
+// The scan of a cell table.  Up to kChainTiles tiles (262,144 cells: the reference scene, BASELINE config 2) as one launch: every
+// block is resident at once and a look-back ends within two rounds.  Beyond that the look-back is what a tile waits for (measured:
+// ~3 us per round of 64 tiles, 0.19 ms instead of 0.06 at 7.5 M cells), so large tables keep the three passes.
+constexpr int kChainTiles = 128;
+static void chain_scan(GridScratch& gs, int* data, int count, int* last)
+{
+    if (count <= 0) return;
+    hipStream_t st = sphx::stream();
+    const int tiles = (count - 1) / kScanTile + 1;
+    if (tiles <= kChainTiles) {
+        k_scan_chain<false><<<tiles, 256, 0, st>>>(data, count, gs.chain.chain(), nullptr, 0, nullptr, 0, 0, last);
+        return;
+    }
+    k_scan_tiles<<<tiles, 256, 0, st>>>(data, gs.blockSums.addr(), count);
+    k_scan_block_sums<<<1, 256, 0, st>>>(gs.blockSums.addr(), tiles);
+    k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(data, gs.blockSums.addr(), count, last);
+}
+// a look-back that gave up (scan_chain.hpp) left a wrong cell table behind: reported where the solver's own faults are, behind the step
+static void grid_fault_check(GridScratch& gs)
+{
+    if (!gs.chain.faulted()) return;
+    *gs.chain.fault = 0;
+    throw "SPHSystem: a scan of the grid pass gave up waiting for the tiles in front of it: the cell table of that step and everything computed from it are NOT valid";
+}
+// outRank[i] = number of out-of-grid particles in front of particle i (nothing to do while *guard == num: no such particle)
+static void chain_rank_out_of_grid(GridScratch& gs, const int* p2c, int sentinel, int num, const int* guard)
+{
+    const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
+    k_scan_chain<true><<<tiles, 256, 0, sphx::stream()>>>(gs.outRank.addr(), count, gs.chain.chain(), guard, num, p2c, sentinel, num, nullptr);
 }
 
 // ================================================================================ SPHSystem
@@ -614,33 +681,16 @@ void SPHSystem::neighborSearch(const std::shared_ptr<SPHParticles>& particles, D
         ScopedKernel t("grid_cell_count");
         k_cell_and_count<<<blocks_for(num), 256, 0, st>>>(p2c, _grid->slot.addr(), cellStart.addr(), particles->getPosPtr(), g, num);
     }
-    auto exclusiveScan = [&](int* data, int count) {
-        const int tiles = (count - 1) / kScanTile + 1;
-        k_scan_tiles<<<tiles, 256, 0, st>>>(data, _grid->blockSums.addr(), count);
-        if (tiles > 1) {
-            k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles);
-            k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(data, _grid->blockSums.addr(), count);
-        }
-    };
     {
         ScopedKernel t("grid_scan");
-        exclusiveScan(cellStart.addr(), cellsPlusOne);
+        chain_scan(*_grid, cellStart.addr(), cellsPlusOne, nullptr);
     }
     if (num <= 0) return;
     {
         ScopedKernel t("grid_stable_rank");
         // the sentinel bucket's ranks: after the scan cellStart[C] = num - (out-of-grid particles), so "== num" means there are
-        // none and the flag + scan launches (4 passes over num + 1 words) return at once
-        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
-        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
-        {
-            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
-            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            if (tiles > 1) {
-                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
-                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            }
-        }
+        // none and the launch returns at once
+        chain_rank_out_of_grid(*_grid, p2c, cellsPlusOne - 1, num, cellStart.addr() + (cellsPlusOne - 1));
         k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
         k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(),
                                                        num, cellsPlusOne);
@@ -682,22 +732,13 @@ void SPHSystem::neighborSearchStaged(const StagedRows& staged)
     }
     {
         ScopedKernel t("grid_scan");
-        device_exclusive_scan(cellStart.addr(a), b - a + 1, _grid->blockSums.addr());
-        if (b < cells) k_copy_one_int<<<1, 1, 0, st>>>(cellStart.addr(cells), cellStart.addr(b));      // where the out-of-grid bucket starts
+        // (the in-window total also goes where the out-of-grid bucket starts)
+        chain_scan(*_grid, cellStart.addr(a), b - a + 1, b < cells ? cellStart.addr(cells) : nullptr);
     }
     if (num <= 0) return;
     {
         ScopedKernel t("grid_stable_rank");
-        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
-        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
-        {
-            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
-            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            if (tiles > 1) {
-                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
-                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            }
-        }
+        chain_rank_out_of_grid(*_grid, p2c, cellsPlusOne - 1, num, cellStart.addr() + (cellsPlusOne - 1));
         k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
         k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(), num, cellsPlusOne);
     }
@@ -935,21 +976,12 @@ void SPHSystem::persistentSearch()
     }
     {
         ScopedKernel t("grid_scan");
-        device_exclusive_scan(cellStart.addr(), cellsPlusOne, _grid->blockSums.addr());
+        chain_scan(*_grid, cellStart.addr(), cellsPlusOne, nullptr);
     }
     if (num <= 0) return;
     {
         ScopedKernel t("grid_stable_rank");
-        const int* guard = cellStart.addr() + (cellsPlusOne - 1);
-        k_flag_out_of_grid<<<blocks_for(num + 1), 256, 0, st>>>(_grid->outRank.addr(), p2c, cellsPlusOne - 1, num, guard, num);
-        {
-            const int count = num + 1, tiles = (count - 1) / kScanTile + 1;
-            k_scan_tiles<<<tiles, 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            if (tiles > 1) {
-                k_scan_block_sums<<<1, 256, 0, st>>>(_grid->blockSums.addr(), tiles, guard, num);
-                k_scan_add_offsets<<<blocks_for(count), 256, 0, st>>>(_grid->outRank.addr(), _grid->blockSums.addr(), count, guard, num);
-            }
-        }
+        chain_rank_out_of_grid(*_grid, p2c, cellsPlusOne - 1, num, cellStart.addr() + (cellsPlusOne - 1));
         k_place<<<blocks_for(num), 256, 0, st>>>(_grid->order.addr(), p2c, _grid->slot.addr(), cellStart.addr(), num);
         k_stable_rank<<<blocks_for(num), 256, 0, st>>>(perm, _grid->order.addr(), p2c, cellStart.addr(), _grid->outRank.addr(), num, cellsPlusOne);
     }
@@ -1024,6 +1056,7 @@ float SPHSystem::step()
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
     _graph->stepsRun++;
+    grid_fault_check(*_grid);
     _solver->tune(1);
     persistentController(1);
     return milliseconds;
@@ -1101,7 +1134,7 @@ float SPHSystem::stepN(int n)
         }
         done += chunk;
         _graph->stepsRun += chunk;
-        if (done < n) { _solver->tune(chunk); persistentController(chunk); }
+        if (done < n) { grid_fault_check(*_grid); _solver->tune(chunk); persistentController(chunk); }
     }
     HIP_CALL(hipEventRecord(stop, st));
     HIP_CALL(hipEventSynchronize(stop));
@@ -1110,6 +1143,7 @@ float SPHSystem::stepN(int n)
     HIP_CALL(hipEventElapsedTime(&milliseconds, start, stop));
     HIP_CALL(hipEventDestroy(start));
     HIP_CALL(hipEventDestroy(stop));
+    grid_fault_check(*_grid);
     _solver->tune(n % kChunk == 0 ? kChunk : n % kChunk);
     persistentController(n % kChunk == 0 ? kChunk : n % kChunk);
     return milliseconds + extra;

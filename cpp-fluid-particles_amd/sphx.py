@@ -68,7 +68,7 @@ class Tuning(C.Structure):
         ("range_order_min", C.c_int), ("force_tile_order", C.c_int), ("no_fastmath", C.c_int), ("no_graph", C.c_int), ("graph_debug", C.c_int),
         ("dfsph_host_loop", C.c_int), ("dfsph_window", C.c_int), ("dfsph_no_tail", C.c_int), ("no_kick_fusion", C.c_int),
         ("pbd_skin", C.c_float), ("pbd_skin_fixed", C.c_int), ("persist_controller", C.c_int), ("slab_edge_stream", C.c_int),
-        ("slab_comm_priority", C.c_int), ("dfsph_tail_flat", C.c_int), ("reserved", C.c_int * 7),
+        ("slab_comm_priority", C.c_int), ("dfsph_tail_flat", C.c_int), ("group_build_max", C.c_int), ("reserved", C.c_int * 6),
     ]
 
 

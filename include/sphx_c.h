@@ -144,7 +144,8 @@ typedef struct sphx_tuning {
     int   slab_edge_stream;   /* slab layer: edge layers of a DFSPH / WCSPH stage on a stream of their own beside the interior (-1: yes) */
     int   slab_comm_priority; /* RCCL transport's communication stream: 0 highest priority (default), 1 default priority, 2 lowest */
     int   dfsph_tail_flat;    /* (live) 1: the loop tail's sweeps are separated by the r04 barrier (one counter, a fence pair per block) instead of the XCD-hierarchical one */
-    int   reserved[7];
+    int   group_build_max;    /* particles up to which the row builder works with 16 lanes per particle (0: 81,920; < 0: never) */
+    int   reserved[6];
 } sphx_tuning;
 int  sphx_tuning_defaults(sphx_tuning *out);
 int  sphx_set_tuning(const sphx_tuning *tuning);       /* NULL: back to the defaults */

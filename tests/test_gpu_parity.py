@@ -130,13 +130,18 @@ def test_trajectory_bit_exact_disordered(sphx, oracle, solver):
 
 
 @pytest.mark.parametrize("solver", [0, 1, 2])
-@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (4, None), (5, None), (0, "8"), (4, "8"), (16, None), (0, "quad-all"), (0, "quad-all-8"), (0, "duo-all"), (0, "duo-all-8")])
+@pytest.mark.parametrize("flags,cap", [(1, None), (2, None), (4, None), (5, None), (0, "8"), (4, "8"), (16, None), (0, "quad-all"), (0, "quad-all-8"), (0, "duo-all"), (0, "duo-all-8"),
+                                       (0, "lane-builder"), (0, "lane-builder-8")])
 def test_engine_schedules_agree(sphx, oracle, solver, flags, cap, monkeypatch):
     """the fused/unfused schedules (bit 0), the neighbour-list vs direct 27-cell walks (bit 1), the
     LDS-staged tiles vs global gathers (bit 2 = on), the per-lane overflow fallback of the list (tiny
     capacity), lane-per-particle walks only (bit 4), quad-per-particle walks in EVERY sweep that has the variant
     (SPHX_QUAD_MASK; the default switches it on for the DFSPH rate sweeps only) and two-lanes-per-particle walks
-    (SPHX_DUO_MASK; off by default) all produce the oracle's bits."""
+    (SPHX_DUO_MASK; off by default) all produce the oracle's bits.  Scenes of this size build their rows with 16 lanes per particle
+    (r06); "lane-builder" switches that off: the lane-per-particle builder of large scenes on the same states."""
+    if cap and cap.startswith("lane-builder"):
+        monkeypatch.setenv("SPHX_GROUP_BUILD_MAX", "-1")
+        cap = cap[13:] or None
     if cap and cap.startswith("quad-all"):
         monkeypatch.setenv("SPHX_QUAD_MASK", "255")
         cap = cap[9:] or None

@@ -36,6 +36,7 @@ ENV = {
     "SPHX_DFSPH_WINDOW": ("dfsph_window", lambda v: max(0, int(v))),
     "SPHX_DFSPH_NO_TAIL": ("dfsph_no_tail", _PRESENT),
     "SPHX_DFSPH_TAIL_FLAT": ("dfsph_tail_flat", _PRESENT),
+    "SPHX_GROUP_BUILD_MAX": ("group_build_max", _INT),
     "SPHX_NO_KICK_FUSION": ("no_kick_fusion", _PRESENT),
     "SPHX_PBD_SKIN": ("pbd_skin", float),
     "SPHX_PBD_SKIN_FIXED": ("pbd_skin_fixed", _PRESENT),
