@@ -389,6 +389,18 @@ int sphx_rows_stale(const sphx_system* h, int* stale)
     return SPHX_OK;
 }
 
+int sphx_rows_partial(const sphx_system* h, int* partial)
+{
+    if (!h || !h->wcsph || !partial) return fail(SPHX_ERR_INVALID, "sphx_rows_partial: bad argument");
+    *partial = 0;
+    const int* flag = h->wcsph->engineStaleFlag();
+    if (!flag) return SPHX_OK;
+    if (hipMemcpyAsync(partial, flag + 3, sizeof(int), hipMemcpyDeviceToHost, sphx::stream()) != hipSuccess ||
+        hipStreamSynchronize(sphx::stream()) != hipSuccess)
+        return fail(SPHX_ERR_HIP, "sphx_rows_partial: copy failed");
+    return SPHX_OK;
+}
+
 int sphx_persistent_stats(const sphx_system* h, int* in_use, int* row_builds, int* steps)
 {
     if (!h || !h->wcsph) return fail(SPHX_ERR_INVALID, "sphx_persistent_stats: bad argument");

@@ -148,8 +148,12 @@ struct SweepCache {
     float skin = 0.0f;                       // absolute length
     std::unique_ptr<DArray<float>> posBuild; // (x, y, z, -) of every fluid particle when the rows were built
     std::unique_ptr<DArray<int>> rowCell;    // ... and the cell its row was built around
-    DArray<int> staleFlag;                   // two flags: [activeFlag] is raised by the coming position updates; [2] counts rebuilds
+    DArray<int> staleFlag;                   // two flags: [activeFlag] is raised by the coming position updates; [2] counts rebuilds;
+                                             // [3 + activeFlag]: particles on the changed-cell list of the coming updates; [5] counts partial rebuilds
     int activeFlag = 0;
+    std::unique_ptr<DArray<int>> changedList; // two lists of changedCap particle indices (SkinWatch)
+    int changedCap = 0;
+    SkinWatch skinWatch() const;
     float staleLimit2() const { return (0.45f * skin) * (0.45f * skin); }
     // persistent rows: a pair's separation changes by at most the sum of the two displacements (relative to the common drift), so
     // 0.49 skin each keeps every pair within R now inside the R + skin of the build; against the static boundary: 0.98 skin in full

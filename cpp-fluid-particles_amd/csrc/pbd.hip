@@ -128,10 +128,7 @@ int PBDSolver::project(std::shared_ptr<SPHParticles>& fluids, const std::shared_
             dp.apply.posmNext = reinterpret_cast<float4*>(c.posmAlt->addr());
             dp.apply.posfNext = reinterpret_cast<float4*>(c.posfAlt->addr());
             dp.apply.space = spaceSize;
-            if (skin) {
-                dp.apply.posBuild = reinterpret_cast<const float4*>(c.posBuild->addr()); dp.apply.rowCell = c.rowCell->addr();
-                dp.apply.stale = c.staleFlag.addr(c.activeFlag); dp.apply.limit2 = c.staleLimit2();
-            }
+            if (skin) dp.apply.watch = c.skinWatch();
             launch_op(dp, num);
             c.swapAltPositions();
             if (!skin) c.listValid = false;
@@ -156,8 +153,7 @@ void PBDSolver::applyDelta(std::shared_ptr<SPHParticles>& fluids, float3 spaceSi
     SweepCache& c = cache();
     const bool skin = c.skinRows && c.skin > 0.0f && c.listValid && c.posBuild;
     launch_apply_delta_clamp(fluids->getPosPtr(), c.fluid4w(), c.posfw(), bufferFloat3.addr(), spaceSize, num,
-                             skin ? reinterpret_cast<const float4*>(c.posBuild->addr()) : nullptr, skin ? c.rowCell->addr() : nullptr, c.g,
-                             skin ? c.staleFlag.addr(c.activeFlag) : nullptr, c.staleLimit2());
+                             skin ? c.skinWatch() : SkinWatch{}, c.g);
     if (!skin) c.listValid = false;
 }
 

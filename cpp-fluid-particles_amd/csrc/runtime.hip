@@ -485,13 +485,32 @@ __global__ void __launch_bounds__(kWideBlock, SPHX_GROUP_WAVES) k_build_list_gro
     __shared__ unsigned int stash[kGroupStash * kWideBlock];
     const int i = (int)((blockIdx.x * kWideBlock + threadIdx.x) / kBuildGroup);
     const bool valid = i < c.n && in_range(c, i);
-    build_neighbor_rows_group(c, nbr, nbrCount, i, valid, stash);
+    const int cell = build_neighbor_rows_group(c, c.posm, nbr, nbrCount, i, valid, stash);
     if (posBuild && valid && (threadIdx.x & (kBuildGroup - 1)) == 0) {
-        const float4 p = c.posm[i];
-        posBuild[i] = p;
-        const int3 c0 = cell_of(xyz4(p), c.g);
-        rowCell[i] = cell_id(c0.x, c0.y, c0.z, c.g);
+        posBuild[i] = c.posm[i];
+        rowCell[i] = cell;
     }
+}
+// Skin rows between two Jacobi iterations (r06): the rows of the particles the last position update found in another cell than
+// the one their row was built around (SkinWatch), rebuilt around the new cell from the positions of the last build of
+// everything -- unless that update also raised `staleNow`: then the launch behind this one rebuilds everything anyway.
+__global__ void __launch_bounds__(kWideBlock, SPHX_GROUP_WAVES) k_build_list_changed(SweepCtx c, unsigned int* nbr, int* nbrCount, const float4* posBuild,
+                                                                   int* rowCell, const int* staleNow, const int* countNow, const int* list,
+                                                                   int listCap, int* countNext, int* partials)
+{
+    __shared__ unsigned int stash[kGroupStash * kWideBlock];
+    const int m = min(*countNow, listCap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *countNext = 0;
+        if (partials && m > 0 && *staleNow == 0) *partials += 1;      // diagnostics
+    }
+    if (*staleNow != 0 || m <= 0) return;      // launch-uniform
+    const int t = (int)((blockIdx.x * kWideBlock + threadIdx.x) / kBuildGroup);
+    if (((int)(blockIdx.x * kWideBlock) / kBuildGroup) >= m) return;      // whole block past the list
+    const bool valid = t < m;
+    const int i = valid ? list[t] : 0;
+    const int cell = build_neighbor_rows_group(c, posBuild, nbr, nbrCount, i, valid, stash);
+    if (valid && (threadIdx.x & (kBuildGroup - 1)) == 0) rowCell[i] = cell;
 }
 
 // The non-empty bricks of this step and their whole-brick tables (one block per brick of the grid; once per step).
@@ -525,7 +544,7 @@ SweepCache::SweepCache(int num)
     : n(num), posm(4u * (unsigned)num), pterm((unsigned)num), aux3((unsigned)num), vel4(4u * (unsigned)num),
       cg4(4u * (unsigned)num), posf(4u * (unsigned)num), massUniform(1u), nbrCount((unsigned)num),
       tileFmt((unsigned)(num / kTile + 2)), tileOrder((unsigned)(num / kTile + 2)), tileKey((unsigned)(num / kTile + 2)), capN(num),
-      rowOverflow(4u), staleFlag(3u), persistFlags(4u)
+      rowOverflow(4u), staleFlag(6u), persistFlags(4u)
 {
     const sphx_tuning& T = tuning();
     capAuto = true; cap = 48;
@@ -834,7 +853,9 @@ void SweepCache::ensureList(const DArray<int>& csF, const DArray<int>& csB)
     const bool skinMode = skinRows && skin > 0.0f;
     if (skinMode) {          // remember where every particle is: the position updates measure against it
         if (!posBuild) { posBuild.reset(new DArray<float>(4u * (unsigned)capN)); rowCell.reset(new DArray<int>((unsigned)capN)); ++generation; }
+        if (!changedList) { changedCap = std::max(1024, capN / 8); changedList.reset(new DArray<int>(2u * (unsigned)changedCap)); ++generation; }
         HIP_CALL(hipMemsetAsync(staleFlag.addr(), 0, 2 * sizeof(int), stream()));
+        HIP_CALL(hipMemsetAsync(staleFlag.addr(3), 0, 2 * sizeof(int), stream()));
         activeFlag = 0;
     }
     listIsBrick = brickMode();
@@ -890,7 +911,19 @@ void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* 
         k_build_list<false><<<xcd_grid(n, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), tileFmt.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
 }
 
-// Skin rows between two Jacobi iterations: rebuild on the device if (and only if) the last position update raised the flag
+SkinWatch SweepCache::skinWatch() const
+{
+    SkinWatch w;
+    w.posBuild = reinterpret_cast<const float4*>(posBuild->addr()); w.rowCell = rowCell->addr();
+    w.stale = staleFlag.addr(activeFlag); w.limit2 = staleLimit2();
+    if (changedList && !tuning().pbd_no_partial) {
+        w.changedCount = staleFlag.addr(3 + activeFlag); w.changedList = changedList->addr(activeFlag * changedCap); w.listCap = changedCap;
+    }
+    return w;
+}
+
+// Skin rows between two Jacobi iterations: the rows of particles that changed their cell are rebuilt, and all of them if (and only
+// if) the last position update raised the flag
 void SweepCache::rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB)
 {
     if (!(skinRows && skin > 0.0f) || !listValid || !nbr || !posBuild || n <= 0) return;
@@ -900,6 +933,10 @@ void SweepCache::rebuildIfStale(const DArray<int>& csF, const DArray<int>& csB)
     rangeLo = keepLo; rangeHi = keepHi; rangeLo2 = keepLo2; rangeHi2 = keepHi2;
     c.nbr = nullptr; c.stale = nullptr; c.overflowMax = rowOverflow.addr();
     ScopedKernel t("rebuild_rows_if_stale");
+    if (changedList && !tuning().pbd_no_partial)
+        k_build_list_changed<<<blocks_for(changedCap * kBuildGroup, kWideBlock), kWideBlock, 0, stream()>>>(
+            c, nbr->rows, nbrCount.addr(), reinterpret_cast<const float4*>(posBuild->addr()), rowCell->addr(), staleFlag.addr(activeFlag),
+            staleFlag.addr(3 + activeFlag), changedList->addr(activeFlag * changedCap), changedCap, staleFlag.addr(3 + (activeFlag ^ 1)), staleFlag.addr(5));
     launchBuild(c, reinterpret_cast<float4*>(posBuild->addr()), staleFlag.addr(activeFlag), staleFlag.addr(activeFlag ^ 1));
     activeFlag ^= 1;
 }

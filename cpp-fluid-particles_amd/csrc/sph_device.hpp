@@ -1309,6 +1309,27 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
     }
 }
 
+// Skin rows: what a position update checks for the particle it moved (SweepCache::skinWatch).  Farther from where the rows were
+// built than the skin allows (also for a NaN) -> every row is stale (`stale`).  In another cell than the one ITS row was built
+// around -> only that row is: the particle goes onto the list of this update (r06; k_build_list_changed rebuilds those rows in
+// front of the next sweep -- after the landing some particle crosses a cell face in nearly every Jacobi iteration, which used to
+// cost a rebuild of ALL rows per iteration).  No list, or a full one: all rows stale, as before.
+struct SkinWatch {
+    const float4* posBuild = nullptr; const int* rowCell = nullptr; int* stale = nullptr; float limit2 = 0.0f;
+    int* changedCount = nullptr; int* changedList = nullptr; int listCap = 0;
+};
+__device__ __forceinline__ void skin_watch(const SkinWatch& w, const float3 p, const int i, const GridDesc& g)
+{
+    const float3 d = sub3(p, xyz4(w.posBuild[i]));
+    if (!(dot3(d, d) <= w.limit2)) { *w.stale = 1; return; }
+    const int3 cNow = cell_of(p, g);
+    if (cell_id(cNow.x, cNow.y, cNow.z, g) == w.rowCell[i]) return;
+    if (!w.changedList) { *w.stale = 1; return; }
+    const int at = atomicAdd(w.changedCount, 1);
+    if (at < w.listCap) w.changedList[at] = i;
+    else *w.stale = 1;
+}
+
 // Small scenes (r06): the same rows from 16 lanes per particle.  The lane-per-particle walk above is a chain of ~70 dependent
 // load rounds (9 columns x (cell tables, then candidates four at a time)); with fewer waves than the device has SIMDs that latency
 // IS the builder's time (42 us at the reference scene's 20,736 particles: 40 % of a WCSPH step, and what PBD pays per Jacobi
@@ -1316,8 +1337,8 @@ __device__ __forceinline__ void build_neighbor_rows(const SweepCtx& c, float4* l
 // 3 x 3 x 3 cells -- the order of the single-lane walk -- keeping what it would append in LDS, and stores it behind a prefix sum
 // over the group's counts.  Same entries in the same order (entry k of a row lives at row_entry_offset(k) whoever writes it).
 template <int AHEAD, class Emit>
-__device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float3 pi, const int i, const int X, const int Y, const int zlo,
-                                                  const int zhi, const bool wantPlain, Emit emit)
+__device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float4* __restrict__ cand, const float3 pi, const int i, const int X,
+                                                  const int Y, const int zlo, const int zhi, const bool wantPlain, Emit emit)
 {
     const int base = (X * c.g.gy + Y) * c.g.gz;
     const bool noWall = c.csB[base + zlo] == c.csB[base + zhi + 1];
@@ -1329,7 +1350,7 @@ __device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float
         for (; j + AHEAD <= e; j += AHEAD) {
             float4 pj[AHEAD];
 #pragma unroll
-            for (int u = 0; u < AHEAD; ++u) pj[u] = c.posm[j + u];
+            for (int u = 0; u < AHEAD; ++u) pj[u] = cand[j + u];
 #pragma unroll
             for (int u = 0; u < AHEAD; ++u) {
                 const float3 d = sub3(pi, v3(pj[u].x, pj[u].y, pj[u].z));
@@ -1339,7 +1360,7 @@ __device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float
             }
         }
         for (; j < e; ++j) {
-            const float4 pj = c.posm[j];
+            const float4 pj = cand[j];
             const float3 d = sub3(pi, v3(pj.x, pj.y, pj.z));
             const float r2 = dot3(d, d);
             if (r2 > c.buildCut || j == i) continue;
@@ -1363,13 +1384,16 @@ __device__ __forceinline__ void walk_build_column(const SweepCtx& c, const float
 constexpr int kGroupAhead = SPHX_GROUP_AHEAD;
 constexpr int kBuildGroup = 16;            // lanes per particle (9 walk a column each)
 constexpr int kGroupStash = 16;            // entries a lane keeps in LDS between counting and storing (16 KB per block of 256: 8 blocks per CU)
-__device__ __forceinline__ void build_neighbor_rows_group(const SweepCtx& c, unsigned int* nbr, int* nbrCount, const int i, const bool valid,
-                                                          unsigned int* stash)
+// `cand`: the fluid positions the distances are taken from -- the live ones (c.posm) for a build of everything; the positions of
+// the LAST such build for the rows of particles that changed their cell since (k_build_list_changed): the row around the new cell
+// that build would have made, so the skin's allowance still counts from there.  The cell is always the one of the live position.
+__device__ __forceinline__ int build_neighbor_rows_group(const SweepCtx& c, const float4* __restrict__ cand, unsigned int* nbr, int* nbrCount,
+                                                         const int i, const bool valid, unsigned int* stash)
 {
     const int q = (int)(threadIdx.x & (kBuildGroup - 1));
-    const float4 self = valid ? c.posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 self = valid ? cand[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float3 pi = v3(self.x, self.y, self.z);
-    const int3 c0 = cell_of(pi, c.g);
+    const int3 c0 = cell_of(valid ? xyz4(c.posm[i]) : pi, c.g);
     const int zlo = max(c0.z - 1, 0), zhi = min(c0.z + 1, c.g.gz - 1);
     const bool wantPlain = c.k.tol == 0 || c.plainBits != 0;
     const int X = c0.x + q / 3 - 1, Y = c0.y + q % 3 - 1;
@@ -1378,7 +1402,7 @@ __device__ __forceinline__ void build_neighbor_rows_group(const SweepCtx& c, uns
     // a lane keeps the first kGroupStash entries of its column in LDS (slot k of thread t at stash[k * blockDim + t]: no bank
     // conflicts); a column with more -- compressed states -- is walked a second time for the rest
     int mine = 0;
-    if (column) walk_build_column<kGroupAhead>(c, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
+    if (column) walk_build_column<kGroupAhead>(c, cand, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
         if (mine < kGroupStash) stash[mine * kWideBlock + (int)threadIdx.x] = e;
         ++mine;
     });
@@ -1395,7 +1419,7 @@ __device__ __forceinline__ void build_neighbor_rows_group(const SweepCtx& c, uns
         if (first + k < c.cap) row[row_entry_offset(first + k)] = stash[k * kWideBlock + (int)threadIdx.x];
     if (mine > kGroupStash) {
         int at = first;
-        walk_build_column<kGroupAhead>(c, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
+        walk_build_column<kGroupAhead>(c, cand, pi, i, X, Y, zlo, zhi, wantPlain, [&](unsigned int e) {
             if (at >= first + kGroupStash && at < c.cap) row[row_entry_offset(at)] = e;
             ++at;
         });
@@ -1404,6 +1428,7 @@ __device__ __forceinline__ void build_neighbor_rows_group(const SweepCtx& c, uns
         nbrCount[i] = total;
         if (total > c.cap && c.overflowMax) atomicMax(c.overflowMax, total);
     }
+    return cell_id(c0.x, c0.y, c0.z, c.g);
 }
 
 

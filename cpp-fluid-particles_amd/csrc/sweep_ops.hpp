@@ -1097,7 +1097,7 @@ struct OpLambda {
 // becomes the live one behind the launch.  The API position array is only ever read for the particle's own entry: updated in place.
 struct DeltaApply {
     float3* pos = nullptr; float4* posmNext = nullptr; float4* posfNext = nullptr; float3 space = {0.0f, 0.0f, 0.0f};
-    const float4* posBuild = nullptr; const int* rowCell = nullptr; int* stale = nullptr; float limit2 = 0.0f;      // skin rows: k_apply_delta_clamp's watch
+    SkinWatch watch{};      // skin rows: k_apply_delta_clamp's watch
 };
 struct OpDeltaPos {
     SweepCtx c;
@@ -1136,11 +1136,7 @@ struct OpDeltaPos {
         apply.pos[i] = p;
         apply.posmNext[i] = make_float4(p.x, p.y, p.z, c.posm[i].w);
         apply.posfNext[i] = make_float4(p.x, p.y, p.z, 0.0f);
-        if (apply.posBuild) {
-            const float3 dd = sub3(p, xyz(apply.posBuild[i]));
-            const int3 cNow = cell_of(p, c.g);
-            if (!(dot3(dd, dd) <= apply.limit2) || cell_id(cNow.x, cNow.y, cNow.z, c.g) != apply.rowCell[i]) *apply.stale = 1;
-        }
+        if (apply.watch.posBuild) skin_watch(apply.watch, p, i, c.g);
     }
 };
 
@@ -1266,12 +1262,10 @@ static __global__ void k_kick_remember_advect(float3* __restrict__ pos, float3* 
     vel[i] = v;
 }
 // pos += deltaPos; enforceBoundary_CUDA(pos): PBDSolver.cu:212-223, :247-253 (also refreshes posm)
-// With skin rows (posBuild != nullptr) the update also checks how far the particle is from where its row was built and
-// whether it is still in the cell the row was built around; if not, `stale` asks for a rebuild before the next sweep.
+// With skin rows (watch.posBuild != nullptr) the update also checks how far the particle is from where its row was built and
+// whether it is still in the cell the row was built around (skin_watch).
 static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __restrict__ posm, float4* __restrict__ posf,
-                                           const float3* __restrict__ dpos, float3 space, int n,
-                                           const float4* __restrict__ posBuild, const int* __restrict__ rowCell, GridDesc g,
-                                           int* __restrict__ stale, float limit2)
+                                           const float3* __restrict__ dpos, float3 space, int n, SkinWatch watch, GridDesc g)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1281,12 +1275,7 @@ static __global__ void k_apply_delta_clamp(float3* __restrict__ pos, float4* __r
     pos[i] = p;
     posm[i] = make_float4(p.x, p.y, p.z, posm[i].w);
     posf[i] = make_float4(p.x, p.y, p.z, 0.0f);
-    if (posBuild) {
-        const float3 d = sub3(p, xyz(posBuild[i]));
-        const int3 cNow = cell_of(p, g);
-        // beyond the skin's allowance (also for a NaN), or in another cell than the one the row was built around
-        if (!(dot3(d, d) <= limit2) || cell_id(cNow.x, cNow.y, cNow.z, g) != rowCell[i]) *stale = 1;
-    }
+    if (watch.posBuild) skin_watch(watch, p, i, g);
 }
 // vel = (pos - posLast) / dt, PBDSolver.cu:55-60
 static __global__ void k_velocity_from_displacement(float3* __restrict__ vel, float4* __restrict__ vel4,
@@ -1325,10 +1314,9 @@ inline void launch_kick_remember_advect(float3* pos, float3* vel, float3* posLas
     if (n > 0) k_kick_remember_advect<<<blocks_for(n), 256, 0, stream()>>>(pos, vel, posLast, dv, dt, space, n);
 }
 inline void launch_apply_delta_clamp(float3* pos, float4* posm, float4* posf, const float3* dpos, float3 space, int n,
-                                     const float4* posBuild = nullptr, const int* rowCell = nullptr, GridDesc g = GridDesc{},
-                                     int* stale = nullptr, float limit2 = 0.0f)
+                                     const SkinWatch& watch = SkinWatch{}, GridDesc g = GridDesc{})
 {
-    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n, posBuild, rowCell, g, stale, limit2);
+    if (n > 0) k_apply_delta_clamp<<<blocks_for(n), 256, 0, stream()>>>(pos, posm, posf, dpos, space, n, watch, g);
 }
 inline void launch_velocity_from_displacement(float3* vel, float4* vel4, const float3* pos, const float3* posLast, float dt, int n)
 {

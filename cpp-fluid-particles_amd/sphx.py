@@ -68,7 +68,7 @@ class Tuning(C.Structure):
         ("range_order_min", C.c_int), ("force_tile_order", C.c_int), ("no_fastmath", C.c_int), ("no_graph", C.c_int), ("graph_debug", C.c_int),
         ("dfsph_host_loop", C.c_int), ("dfsph_window", C.c_int), ("dfsph_no_tail", C.c_int), ("no_kick_fusion", C.c_int),
         ("pbd_skin", C.c_float), ("pbd_skin_fixed", C.c_int), ("persist_controller", C.c_int), ("slab_edge_stream", C.c_int),
-        ("slab_comm_priority", C.c_int), ("dfsph_tail_flat", C.c_int), ("group_build_max", C.c_int), ("reserved", C.c_int * 6),
+        ("slab_comm_priority", C.c_int), ("dfsph_tail_flat", C.c_int), ("group_build_max", C.c_int), ("pbd_no_partial", C.c_int), ("reserved", C.c_int * 5),
     ]
 
 
@@ -276,6 +276,13 @@ class System:
         v = C.c_int()
         lib().sphx_rows_stale.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _check(lib().sphx_rows_stale(self._h, C.byref(v)))
+        return v.value
+
+    def rows_partial(self):
+        """PBD skin rows: launches so far that rebuilt only the rows of particles which had changed their cell"""
+        v = C.c_int()
+        lib().sphx_rows_partial.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _check(lib().sphx_rows_partial(self._h, C.byref(v)))
         return v.value
 
     def persistent_stats(self):

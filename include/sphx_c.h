@@ -145,7 +145,8 @@ typedef struct sphx_tuning {
     int   slab_comm_priority; /* RCCL transport's communication stream: 0 highest priority (default), 1 default priority, 2 lowest */
     int   dfsph_tail_flat;    /* (live) 1: the loop tail's sweeps are separated by the r04 barrier (one counter, a fence pair per block) instead of the XCD-hierarchical one */
     int   group_build_max;    /* particles up to which the row builder works with 16 lanes per particle (0: 81,920; < 0: never) */
-    int   reserved[6];
+    int   pbd_no_partial;     /* 1: PBD skin rows are rebuilt as a whole when a particle changes its cell inside a step (until r05) instead of row by row */
+    int   reserved[5];
 } sphx_tuning;
 int  sphx_tuning_defaults(sphx_tuning *out);
 int  sphx_set_tuning(const sphx_tuning *tuning);       /* NULL: back to the defaults */
@@ -254,6 +255,8 @@ int  sphx_row_capacity(const sphx_system *sys, int *capacity);
 /* PBD diagnostics: how many times since creation the once-per-step neighbour rows had to be rebuilt inside a step because
  * a particle moved farther than their skin allows (decided and done on the device; always 0 for other solvers)      */
 int  sphx_rows_stale(const sphx_system *sys, int *rebuilds);
+/* PBD skin rows: launches so far that rebuilt only the rows of particles which had changed their cell (r06; 0 for the other solvers) */
+int  sphx_rows_partial(const sphx_system *sys, int *partial_rebuilds);
 /* persistent rows (reserved[3] = 2): 1/0 whether the mode is in use for this system, row builds and steps since creation
  * (both 0 when it is not in use: every step builds its rows then)                                                      */
 int  sphx_persistent_stats(const sphx_system *sys, int *in_use, int *row_builds, int *steps);

@@ -218,12 +218,16 @@ def test_pbd_skin_rows_are_exact(sphx, oracle, skin, speed, monkeypatch):
     assert rebuilds_eager >= 0
 
 
-@pytest.mark.parametrize("skin", ["0.05", "0.3"])
-def test_pbd_skin_rows_kept_across_iterations(sphx, oracle, skin, monkeypatch):
+@pytest.mark.parametrize("skin,partial", [("0.05", True), ("0.3", True), ("0.05", False), ("0.3", False)])
+def test_pbd_skin_rows_kept_across_iterations(sphx, oracle, skin, partial, monkeypatch):
     """the dam-break column landing gently (nx = 12: contact after ~50 steps): particles move a little in every Jacobi
-    iteration, mostly inside their cells, so rows are re-used across iterations and only sometimes rebuilt"""
+    iteration, mostly inside their cells, so rows are re-used across iterations and only sometimes rebuilt -- as a whole when a
+    particle has moved farther than the skin allows, row by row for particles that changed their cell (r06; `partial` off: as a
+    whole for those too, the r03-r05 rule)"""
     monkeypatch.setenv("SPHX_PBD_SKIN", skin)
     monkeypatch.setenv("SPHX_PBD_SKIN_FIXED", "1")
+    if not partial:
+        monkeypatch.setenv("SPHX_PBD_NO_PARTIAL", "1")
     def tweak(P):
         P.pbd_iters = 4
     gs, os_, P = make_pair(sphx, oracle, 12, sphx.PBD, tweak=tweak)
@@ -233,8 +237,13 @@ def test_pbd_skin_rows_kept_across_iterations(sphx, oracle, skin, monkeypatch):
         iterations += 4
         if s % 10 == 0 or s > 80:
             compare(sphx, oracle, gs, os_, FIELDS_COMMON + FIELDS_PBD, "gentle landing skin %s step %d" % (skin, s))
-    rebuilds = gs.rows_stale()
-    assert 0 < rebuilds < iterations, "expected some, not all, iterations to rebuild: %d of %d" % (rebuilds, iterations)
+    rebuilds, rowwise = gs.rows_stale(), gs.rows_partial()
+    if partial:
+        assert rowwise > 0, "no particle changed its cell inside a step?"
+        assert rebuilds < iterations, "every iteration rebuilt all rows: %d of %d" % (rebuilds, iterations)
+    else:
+        assert rowwise == 0
+        assert 0 < rebuilds < iterations, "expected some, not all, iterations to rebuild: %d of %d" % (rebuilds, iterations)
 
 
 def test_pbd_skin_controller_switches_modes_exactly(sphx, oracle):

@@ -40,6 +40,7 @@ ENV = {
     "SPHX_NO_KICK_FUSION": ("no_kick_fusion", _PRESENT),
     "SPHX_PBD_SKIN": ("pbd_skin", float),
     "SPHX_PBD_SKIN_FIXED": ("pbd_skin_fixed", _PRESENT),
+    "SPHX_PBD_NO_PARTIAL": ("pbd_no_partial", _PRESENT),
     "SPHX_PERSIST_CONTROLLER": ("persist_controller", lambda v: int(int(v) != 0)),
     "SPHX_SLAB_EDGE_STREAM": ("slab_edge_stream", lambda v: int(v != "0")),
     "SPHX_COMM_PRIORITY": ("slab_comm_priority", _comm_priority),

@@ -9,6 +9,7 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 for arith in (0, 1):
     P, f, b = sphx.scene(nx)
     P.solver = sphx.PBD; P.dt = 0.002; P.reserved[3] = arith
+    if os.environ.get("ITERS"): P.pbd_iters = int(os.environ["ITERS"])
     s = sphx.System(P, f, b)
     s.step_n(10)
     for settle in (0, 200, 200):
