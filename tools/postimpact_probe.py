@@ -12,7 +12,7 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 190
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 275
 P, fluid, boundary = sphx.scene(nx)
 P.solver = sphx.DFSPH; P.dfsph_fixed_div = -1; P.dfsph_fixed_den = -1
-P.reserved[0] = int(os.environ.get("FLAGS", "0"))
+P.reserved[0] = int(os.environ.get("FLAGS", "0")); P.reserved[3] = int(os.environ.get("TOL", "0"))
 s = sphx.System(P, fluid, boundary)
 s.step_n(total)
 t0 = time.perf_counter(); s.step_n(10); dt = (time.perf_counter() - t0) / 10

@@ -1,6 +1,7 @@
 set -u
 mkdir -p gpurun_out
-(time timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8) > gpurun_out/r06_gpu_suite.txt 2>&1
+(time timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r06_gpu_suite.log 2>&1) 2> gpurun_out/r06_gpu_suite_time.txt
+(grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/r06_gpu_suite.log | tail -6; cat gpurun_out/r06_gpu_suite_time.txt) > gpurun_out/r06_gpu_suite.txt
 cat gpurun_out/r06_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 (time python bench.py --steps 20 --warmup 5 2> gpurun_out/r06_bench.log > gpurun_out/r06_bench.json) 2>&1 | tail -3
