@@ -34,7 +34,7 @@ EXPORTS = [
     "sphx_generate_dots", "sphx_kernel_timer", "sphx_kernel_timer_collect", "sphx_run_phase", "sphx_run_phase_reduce", "sphx_error_total_fixed", "sphx_set_count", "sphx_use_stream",
     "sphx_sync", "sphx_cell_columns", "sphx_fastmath_selftest", "sphx_snapshot_save", "sphx_snapshot_load",
     "sphx_tuning_defaults", "sphx_set_tuning", "sphx_get_tuning", "sphx_invalidate_order", "sphx_last_rate_kernel",
-    "sphx_get_params", "sphx_row_stats", "sphx_row_walk_stats", "sphx_row_capacity", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
+    "sphx_get_params", "sphx_row_stats", "sphx_row_walk_stats", "sphx_row_capacity", "sphx_rows_partial", "sphx_rows_stale", "sphx_persistent_stats", "sphx_device_pci_id", "sphx_sample_box", "sphx_sample_sphere", "sphx_sample_triangles",
 ]
 # symbols exported under the reference's own names (vbo.cu:46-51)
 REFERENCE_EXPORTS = ["generate_dots"]

@@ -295,6 +295,30 @@ def test_step_n_matches_step(sphx, oracle, solver):
     compare(sphx, oracle, gs, os_, FIELDS_COMMON, "step_n solver %d" % solver)
 
 
+def test_out_of_grid_ranks_across_many_scan_tiles(sphx, oracle):
+    """the stable ranks of the out-of-grid bucket come from ONE guarded launch (r06: decoupled look-back over tiles of 2,048 particles,
+    csrc/scan_chain.hpp): 263,424 particles = 129 tiles (three look-back windows), every 11th particle far outside the box, so that every
+    tile holds some; the sort (ids, cells, cell table) and the first steps equal the oracle's.  The cell table of this scene (216,001
+    words = 106 tiles) goes through the one-launch scan too."""
+    P, fluid, boundary = sphx.scene(56)
+    P.solver = sphx.WCSPH
+    pos = fluid.copy()
+    pos[::11] += np.float32(7.0)
+    pos[3::5000] = [-0.3, 0.1, 0.1]
+    Po = same_params(oracle.Params(), P)
+    gs = sphx.System(P, pos, boundary, ctor_step=False)
+    os_ = oracle.System(Po, pos, boundary, ctor_step=False)
+    names = ["POS", "VEL", "DENSITY", "PRESSURE", "CELL", "CELLSTART_F", "ID"]
+    compare(sphx, oracle, gs, os_, names, "many tiles init")
+    for s in range(2):
+        gs.step(); os_.step()
+        compare(sphx, oracle, gs, os_, names, "many tiles step %d" % (s + 1))
+    gs.step_n(3)
+    for _ in range(3):
+        os_.step()
+    compare(sphx, oracle, gs, os_, names, "many tiles, replayed steps")
+
+
 def test_edge_cases_no_boundary_and_out_of_grid(sphx, oracle):
     """no boundary particles at all; some particles outside the grid (sentinel cell)."""
     P, fluid, boundary = sphx.scene(8)

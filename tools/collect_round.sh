@@ -20,7 +20,8 @@ python bench.py > gpurun_out/bench_${TAG}_1gpu.json 2> gpurun_out/bench_${TAG}_1
 python tools/probe_step.py wcsph263k dfsph1m pbd1m dfsph10m 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/probe_$TAG.txt
 TOL=1 python tools/probe_step.py dfsph10m 2>/dev/null | grep -v "amdgpu\|^PBD" | sed 's/^dfsph10m/dfsph10m(tolerance)/' >> gpurun_out/probe_$TAG.txt
 TOL=2 python tools/probe_step.py dfsph10m 2>/dev/null | grep -v "amdgpu\|^PBD" | sed 's/^dfsph10m/dfsph10m(persistent)/' >> gpurun_out/probe_$TAG.txt
-python tools/small_probe.py 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/small_$TAG.txt
+(echo "# reference scene (20,736 particles), default solver settings, step_n batches of 100 behind 10 steps: free fall | landing | landed.  strict arithmetic:"; python tools/small_probe.py 2>/dev/null | grep -v "amdgpu\|^PBD"; echo "# headline arithmetic (TOL=2):"; TOL=2 python tools/small_probe.py 2>/dev/null | grep -v "amdgpu\|^PBD") > gpurun_out/small_$TAG.txt
+python tools/r06_small_probe.py 2>/dev/null | grep -v "amdgpu\|^PBD" > gpurun_out/small_configs_$TAG.txt
 python tools/pcie_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/pcie_$TAG.txt
 for A in tolerance strict; do for s in 1 8; do python bench.py --force-slab --slabs $s --arith $A --steps 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_${TAG}_loopback_${s}slabs_$A.json; done; done
 python bench.py --force-slab --slabs 8 --arith tolerance --slab-transport rccl --steps 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_${TAG}_rcclself_8slabs.json

@@ -23,6 +23,7 @@ for A in tolerance strict; do [ -s gpurun_out/bench_${T}_plain_$A.json ] && cp g
 cp gpurun_out/pcie_$T.txt                     profiles/${T}_pcie_inclusive.txt
 cp gpurun_out/probe_$T.txt                    profiles/${T}_probe_per_kernel_hipevents.txt
 cp gpurun_out/small_$T.txt                    profiles/${T}_reference_scene_step_n.txt
+[ -s gpurun_out/small_configs_$T.txt ] && cp gpurun_out/small_configs_$T.txt profiles/${T}_small_configs_per_kernel.txt
 cp gpurun_out/slab_probe_$T.txt               profiles/${T}_slab_probe_step.txt
 cp gpurun_out/big_$T.txt                      profiles/${T}_big_scenes.txt
 for k in parity tolerance persistent slab slab_tolerance; do [ -s gpurun_out/stress_${T}_$k.txt ] && cp gpurun_out/stress_${T}_$k.txt profiles/${T}_stress_$k.txt; done
