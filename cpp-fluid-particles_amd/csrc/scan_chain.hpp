@@ -18,6 +18,9 @@
 
 #include <hip/hip_runtime.h>
 #include <stdexcept>
+#ifdef SPHX_TEST_HOOKS
+#include <cstdlib>
+#endif
 
 namespace sphx {
 
@@ -26,6 +29,9 @@ struct ScanChain {
     unsigned int* ctl;           // [0] tickets handed out, [1] tiles finished, [2] generation of the launch in flight
     int* fault;                  // host-visible; non-zero once a look-back gave up
     int stride;                  // tiles per channel (state of channel c starts at c * stride)
+#ifdef SPHX_TEST_HOOKS
+    int dropTile;                // test build (tests/libsphx_hooks.so): this tile never publishes -- the tiles behind it must give up and report
+#endif
 };
 
 constexpr unsigned int kChainSpinLimit = 1u << 20;      // a look-back normally ends within a few reads; this is seconds
@@ -51,7 +57,15 @@ struct ChainScratch {
     }
     ChainScratch(const ChainScratch&) = delete;
     ChainScratch& operator=(const ChainScratch&) = delete;
+#ifdef SPHX_TEST_HOOKS
+    ScanChain chain() const
+    {
+        const char* drop = std::getenv("SPHX_CHAIN_DROP_TILE");
+        return ScanChain{state, ctl, fault, stride, drop ? std::atoi(drop) : -1};
+    }
+#else
     ScanChain chain() const { return ScanChain{state, ctl, fault, stride}; }
+#endif
     bool faulted() const { return fault && *fault != 0; }
     unsigned long long* state = nullptr;
     unsigned int* ctl = nullptr;
@@ -99,11 +113,16 @@ __device__ __forceinline__ int chain_exclusive(const ScanChain& c, int channel, 
     unsigned long long* state = c.state + (size_t)channel * (size_t)c.stride;
     const int lane = (int)(threadIdx.x & 63);
     const unsigned long long tag = (unsigned long long)(gen & 0x3fffffffu) << 34;
+#ifdef SPHX_TEST_HOOKS
+    const bool publish = lane == 0 && tile != c.dropTile;
+#else
+    const bool publish = lane == 0;
+#endif
     if (tile == 0) {
-        if (lane == 0) chain_store(state, tag | (2ull << 32) | (unsigned int)total);
+        if (publish) chain_store(state, tag | (2ull << 32) | (unsigned int)total);
         return 0;
     }
-    if (lane == 0) chain_store(state + tile, tag | (1ull << 32) | (unsigned int)total);
+    if (publish) chain_store(state + tile, tag | (1ull << 32) | (unsigned int)total);
     int before = 0;
     unsigned int spins = 0;
     for (int look = tile - 1;;) {
@@ -125,7 +144,7 @@ __device__ __forceinline__ int chain_exclusive(const ScanChain& c, int channel, 
         if (closed) break;
         look -= 64;
     }
-    if (lane == 0) chain_store(state + tile, tag | (2ull << 32) | (unsigned int)(before + total));
+    if (publish) chain_store(state + tile, tag | (2ull << 32) | (unsigned int)(before + total));
     return before;
 }
 

@@ -1007,6 +1007,38 @@ def test_loop_tail_that_cannot_be_resident_reports_a_fault_instead_of_hanging(tm
     assert r.returncode == 0 and "OK" in r.stdout and "grid barrier timed out" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_scan_tile_that_never_publishes_is_reported_instead_of_hanging(tmp_path):
+    """the one-launch scans of the grid pass (csrc/scan_chain.hpp) wait for the tiles in front of them: with one tile that never
+    publishes (test build of the library, SPHX_CHAIN_DROP_TILE) the tiles behind it must give up after their bounded spin, the step
+    must be reported invalid through the C ABI, and the next steps must run -- a hang here would take the device with it"""
+    import subprocess, sys, textwrap
+    hooks = os.path.join(ROOT, "tests", "libsphx_hooks.so")
+    assert os.path.exists(hooks), "tests/libsphx_hooks.so is built by __graft_entry__.build() (make -C tests)"
+    script = tmp_path / "dropped_tile.py"
+    script.write_text(textwrap.dedent("""
+        import sys, os, time
+        sys.path.insert(0, os.path.join(%r, "cpp-fluid-particles_amd"))
+        import sphx
+        P, f, b = sphx.scene(24); P.solver = sphx.WCSPH          # 36 k cells = 18 tiles of the cell-table scan
+        s = sphx.System(P, f, b)
+        s.step_n(5)
+        os.environ["SPHX_CHAIN_DROP_TILE"] = "3"
+        t0 = time.time(); failed = 0
+        try:
+            s.step()
+        except RuntimeError as e:
+            failed += 1; print("reported:", e, flush=True)
+        print("the faulty step took %%.1f s" %% (time.time() - t0), flush=True)
+        del os.environ["SPHX_CHAIN_DROP_TILE"]
+        assert failed == 1
+        s.step_n(5); s.step()                                      # the chain re-arms itself: later steps run and report nothing
+        print("OK", flush=True)
+    """ % ROOT))
+    env = dict(os.environ, SPHX_LIB=hooks)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout and "gave up waiting" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_adaptive_row_capacity_grows_and_stays_exact(sphx, oracle):
     """rows start at 48 entries per particle; a state denser than the lattice (two interleaved jittered lattices, ~60 neighbours)
     overflows them: the overflowing particles walk the cells directly (same bits), the builder reports the longest row, the
