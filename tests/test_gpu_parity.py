@@ -295,6 +295,33 @@ def test_step_n_matches_step(sphx, oracle, solver):
     compare(sphx, oracle, gs, os_, FIELDS_COMMON, "step_n solver %d" % solver)
 
 
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_row_builders_agree_below_their_crossover(sphx, solver, monkeypatch):
+    """69,984 particles (just under sphx_tuning.group_build_max, where the 16-lanes-per-particle builder is still the default): the
+    same disordered state stepped with that builder and with the lane-per-particle builder of large scenes -- every field, the row
+    statistics and the iteration counts are identical, bit for bit (engine against engine; the oracle pins both at 2,592 and 20,736
+    particles in the tests above)"""
+    P, fluid, boundary = sphx.scene(36)
+    P.solver = solver; P.pbd_iters = 4; P.dt = 0.001
+    pos, vel = _splash_state(len(fluid), P, 300 + solver)
+    names = FIELDS_COMMON + (FIELDS_DFSPH if solver == 1 else []) + (FIELDS_PBD if solver == 2 else [])
+    results = []
+    for group in (True, False):
+        monkeypatch.setenv("SPHX_GROUP_BUILD_MAX", "0" if group else "-1")
+        s = sphx.System(P, pos, boundary, ctor_step=False)
+        ids = s.get(sphx.F_ID)
+        s.set(sphx.F_VEL, vel[ids])
+        for _ in range(3):
+            s.step()
+        s.step_n(3)
+        results.append(({n: s.get(getattr(sphx, "F_" + n)) for n in names}, s.row_stats()[:2], s.iters() if solver == 1 else None))
+        s.close()
+    (a, ra, ia), (b, rb, ib) = results
+    for n in names:
+        assert_bit_equal(a[n], b[n], "builders, solver %d, %s" % (solver, n))
+    assert ra == rb and ia == ib
+
+
 def test_out_of_grid_ranks_across_many_scan_tiles(sphx, oracle):
     """the stable ranks of the out-of-grid bucket come from ONE guarded launch (r06: decoupled look-back over tiles of 2,048 particles,
     csrc/scan_chain.hpp): 263,424 particles = 129 tiles (three look-back windows), every 11th particle far outside the box, so that every
