@@ -901,8 +901,8 @@ void SweepCache::buildListForRange(const DArray<int>& csF, const DArray<int>& cs
 void SweepCache::launchBuild(const SweepCtx& c, float4* posBuildOut, const int* flagNow, int* flagNext)
 {
     unsigned int* rows = nbr->rows;
-    // few particles: the walk's latency, not its throughput, is the builder's time -- 16 lanes per particle while their waves still
-    // fit the device at once (kGroupBuildMax / 4 waves)
+    // few particles: the walk's latency, not its throughput, is the builder's time -- 16 lanes per particle up to the measured
+    // crossover with the lane-per-particle builder (kGroupBuildMax; profiles/r06_small_scene_builder.txt)
     if (tuning().group_build_max >= 0 && n <= (tuning().group_build_max > 0 ? tuning().group_build_max : kGroupBuildMax) && !(flags & kFlagTiles))
         k_build_list_group<<<blocks_for(n * kBuildGroup, kWideBlock), kWideBlock, 0, stream()>>>(c, rows, nbrCount.addr(), posBuildOut, rowCell ? rowCell->addr() : nullptr, flagNow, flagNext, staleFlag.addr(2));
     else if (allowTiles && (flags & kFlagTiles))
