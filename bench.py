@@ -289,8 +289,10 @@ def settled_leg(sphx, torch, nx, solver, div, den, settle, steps, arith="strict"
     return leg
 
 
-def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup, arith="strict"):
-    """one of the BASELINE configs that are parity-test cases rather than the headline: graph-replayed steps"""
+def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup, arith="strict", landed=0):
+    """one of the BASELINE configs that are parity-test cases rather than the headline: graph-replayed steps.
+    landed > 0 (the reference's own scene): the same number of steps is timed once more behind `landed` further steps, i.e. with the
+    column on the floor -- the regime a run spends most of its frames in (adaptive DFSPH then runs 20 divergence iterations per step)"""
     sim, P = make_system(sphx, nx, solver, div, den, pbd_iters, arith=arith)
     sim.step_n(warmup)
     wall, _ = timed_steps(torch, sim, steps)
@@ -306,6 +308,13 @@ def small_leg(sphx, torch, nx, solver, div, den, pbd_iters, steps, warmup, arith
     leg = {"workload": "dam-break nx=%d, %d particles, %s, dt=%g, %s arithmetic" % (nx, sim.n, what, P.dt, arith), "arithmetic": arith,
            "particles": sim.n, "steps": steps, "steps_per_s": sps, "ms_per_step": wall * 1e3 / steps,
            "algorithmic_GBps": bpp * sim.n * sps / 1e9, "hbm_roofline_frac": bpp * sim.n * sps / 1e9 / HBM_PEAK_GBPS}
+    if landed > 0:
+        sim.step_n(landed)
+        wall2, _ = timed_steps(torch, sim, steps)
+        leg["landed"] = {"behind_steps": warmup + steps + landed, "steps": steps, "ms_per_step": wall2 * 1e3 / steps, "steps_per_s": steps / wall2}
+        if solver == "dfsph" and not fixed:
+            leg["landed"]["last_step_iterations"] = list(sim.iters())
+        note("leg nx=%d %s (%s), landed: %.3f ms/step" % (nx, solver, arith, wall2 * 1e3 / steps))
     sim.close()
     return leg
 
@@ -463,7 +472,7 @@ def main():
             # the reference's own scene and defaults (20,736 particles; adaptive DFSPH, 20 PBD iterations), next to which
             # BASELINE.md quotes 4.4 / 23.0 / 11.3 ms per frame on a GTX 1070
             for sv, steps in (("wcsph", 300), ("dfsph", 100), ("pbd", 100)):
-                legs.append(small_leg(sphx, torch, 24, sv, -1, -1, 20, steps, 10, arith=arith))
+                legs.append(small_leg(sphx, torch, 24, sv, -1, -1, 20, steps, 10, arith=arith, landed=300 if sv == "wcsph" else 200))
         result["configs"] = legs
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, n)
